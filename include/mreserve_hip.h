@@ -1,0 +1,183 @@
+/* mreserve_hip.h -- C-ABI of libmreserve_hip.so: the MI355X (gfx950) kernels behind the
+ * MERLOT Reserve pretraining step.
+ *
+ * The reference (rowanz/merlot_reserve) has no FFI layer: its boundary for this path is the
+ * Python API (MerlotReservePretrainer.apply / loss_fn_given_preds / train_step), whose
+ * arithmetic is delegated to XLA.  The entry points below are what a binding for that path
+ * binds instead of XLA; each cites the reference lines whose arithmetic it replaces
+ * (M = mreserve/modeling.py, P = pretrain/pretrain_model.py, O = pretrain/optimization.py).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.
+ *  - every function returns 0 on success, a negative MR_E* code on failure;
+ *    mr_last_error() gives a thread-local message.
+ *  - all pointers are DEVICE pointers unless the name ends in _host; memory is owned by the
+ *    caller; the library never allocates, never synchronises, never throws.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it asynchronously
+ *    (capturable into a hipGraph).
+ *  - bf16 = raw uint16 payload (IEEE bfloat16); matrices are row-major with explicit leading
+ *    dimensions in ELEMENTS; leading dims and N of bf16 matrices must be multiples of 8
+ *    (16-byte vectors) -- pad on the host otherwise.
+ */
+#ifndef MRESERVE_HIP_H
+#define MRESERVE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_OK 0
+#define MR_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MR_ELAUNCH (-2)  /* HIP launch error */
+
+#define MR_DT_BF16 0
+#define MR_DT_F32 1
+
+/* activation applied in the GEMM epilogue */
+#define MR_ACT_NONE 0
+#define MR_ACT_GELU1702 1 /* x*sigmoid(1.702x): M:240-241 */
+
+int mr_version(void);
+const char* mr_last_error(void);
+
+/* ---- GEMM with fused epilogue (flax Dense / DenseGeneral: M:228-236, 252-255, 371, 402, 453, 631;
+ *      and their dgrad / wgrad) --------------------------------------------------------------
+ * C[M,N] = op(A) . op(B), bf16 inputs, fp32 accumulation on MFMA.
+ *   transA = 0: A stored [M,K] (lda = row stride)      transA = 1: A stored [K,M]
+ *   transB = 0: B stored [K,N] (flax kernel layout)    transB = 1: B stored [N,K]
+ * Epilogue, in this order (each optional, NULL / 0 disables):
+ *   v = acc + bias[n]                                  (bias bf16 [N])
+ *   v *= rot_tab[(m % rot_rows)*32 + (n & 63)]          for n < rot_cols and (n & 63) < 32
+ *        (the reference's "rotary": a per-position diagonal scaling, M:116-144; rot_tab fp32)
+ *   if c2: c2[m,n] = bf16(v)                           (pre-activation copy, same ldc / row map)
+ *   v = act(v)
+ *   v = bf16(v) + residual[m,n]                        (residual bf16, ld = ldr)
+ *   v = bf16(v) * gelu1702'(aux[m,n])                  (aux bf16 pre-activation, ld = ldaux)
+ * Output row map: row m is stored at row (m / out_grp) * out_grp_stride + out_grp_off + m % out_grp
+ * when out_grp > 0 (used to leave room for the CLS row, M:311-320), else at row m.
+ * c_dtype = MR_DT_F32 supports bias only (used for the contrastive logits, P:293).
+ */
+typedef struct {
+    int64_t M, N, K;
+    const void* A; int64_t lda; int32_t transA;
+    const void* B; int64_t ldb; int32_t transB;
+    void* C; int64_t ldc; int32_t c_dtype;
+    const void* bias;
+    const float* rot_tab; int64_t rot_rows; int64_t rot_cols;
+    void* c2;
+    int32_t act;
+    const void* residual; int64_t ldr;
+    const void* aux; int64_t ldaux;
+    int64_t out_grp, out_grp_stride, out_grp_off;
+} mr_gemm_args;
+int mr_gemm(const mr_gemm_args* args, void* stream);
+
+/* ---- LayerNorm (flax nn.LayerNorm eps=1e-5, fp32 stats, var = E[x^2]-E[x]^2: M:272,277,360,366) ---- */
+int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                     float* mean, float* rstd, int64_t rows, int64_t H, float eps, void* stream);
+/* dx = LN backward; dgamma/dbeta are reduced over rows into bf16 [H] each.
+ * partials: fp32 workspace of mr_layernorm_bwd_workspace(H) bytes. If add_to_dx != 0, dx += result. */
+int64_t mr_layernorm_bwd_workspace(int64_t H);
+int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+                     const float* mean, const float* rstd, void* dx, int64_t lddx, int32_t add_to_dx,
+                     void* dgamma, void* dbeta, void* partials, int64_t rows, int64_t H, void* stream);
+
+/* ---- column sum: out[n] = bf16(sum_m x[m,n])  (bias gradients) ---- */
+int64_t mr_colsum_workspace(int64_t N);
+int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream);
+
+/* ---- fused multi-head attention (M:188-200 + flax dot_product_attention_weights) ----
+ * qkv: [nseq*S, 3*H] bf16 rows = [Q(H) | K(H) | V(H)], head h at columns h*64..h*64+63, q/k already
+ * "rotary"-scaled by the QKV GEMM epilogue.  scores = (q/8).k + bias, bias = 0 where allowed else -1e10
+ * (M:353-356), allowed(i,j) = code[i] == code[j] && code[i] >= 0; code == NULL means no mask.
+ * out: [nseq*S, H] bf16; lse: [nseq, nh, S] fp32 (natural-log LSE of the biased scores).
+ */
+int mr_attention_fwd(const void* qkv, const int32_t* code, void* out, float* lse,
+                     int64_t nseq, int64_t S, int64_t nh, void* stream);
+/* dqkv [nseq*S, 3H] bf16 = gradient wrt the PRE-"rotary" qkv when rot_tab != NULL (the diagonal
+ * scaling is applied to dq, dk on the way out), else wrt qkv as given.  delta: fp32 [nseq, nh, S] workspace. */
+int mr_attention_bwd(const void* qkv, const int32_t* code, const void* out, const void* dout, const float* lse,
+                     float* delta, void* dqkv, const float* rot_tab, int64_t rot_rows,
+                     int64_t nseq, int64_t S, int64_t nh, void* stream);
+
+/* ---- attention pooling core (flax MultiHeadDotProductAttention with 1 query and R keys: M:419-427, 467-472)
+ * q [G, H]; k, v rows gathered by key_rows [G, R] (row indices into k/v, ld = ldkv); out [G, H].
+ * probs [G, nh, R] fp32 saved for backward.
+ */
+int mr_poolattn_fwd(const void* q, const void* k, const void* v, int64_t ldkv, const int32_t* key_rows,
+                    void* out, float* probs, int64_t G, int64_t R, int64_t nh, void* stream);
+/* dq [G,H]; dk, dv [rows, ldkv]: every k/v row belongs to at most one group, rows not referenced must be
+ * pre-zeroed by the caller. */
+int mr_poolattn_bwd(const void* q, const void* k, const void* v, int64_t ldkv, const int32_t* key_rows,
+                    const float* probs, const void* dout, void* dq, void* dk, void* dv,
+                    int64_t G, int64_t R, int64_t nh, void* stream);
+
+/* ---- row gather / segment sum (nn.Embed M:527, audio-span substitution M:685-695, vision tiling P:104,
+ *      one_hot_pool M:541-567, gathers P:183-190, 233-236, and all of their transposes) ----
+ * dst[i,:] = scale * sum_{j in [indptr[i], indptr[i+1])} src(indices[j]) for i < n_dst, H columns, bf16.
+ * src(code): code < n0 -> src0 row code; code < n0+n1 -> src1 row code-n0; else src2 row code-n0-n1.
+ * (src1/src2 may be NULL when n1 / n2 are 0).  Empty list -> zero row.  Accumulation in fp32, fixed order.
+ * If accumulate != 0, dst += result (dst read as bf16).  dst_dtype MR_DT_BF16 or MR_DT_F32.
+ */
+int mr_segment_sum(const void* src0, int64_t ld0, int64_t n0, const void* src1, int64_t ld1, int64_t n1,
+                   const void* src2, int64_t ld2, int64_t n2,
+                   const int32_t* indptr, const int32_t* indices, void* dst, int64_t ldd, int32_t dst_dtype,
+                   int64_t n_dst, int64_t H, float scale, int32_t accumulate, void* stream);
+
+/* mean over R rows: dst[g,:] = (1/R) sum_r src[rows[g,r],:]  (M:423, 471); bwd scatters dst-grad/R back
+ * (adds into dsrc, which holds the other gradient path already). */
+int mr_rows_mean_fwd(const void* src, int64_t lds, const int32_t* rows, void* dst, int64_t G, int64_t R, int64_t H,
+                     void* stream);
+int mr_rows_mean_bwd(const void* ddst, const int32_t* rows, void* dsrc, int64_t lds, int64_t G, int64_t R, int64_t H,
+                     void* stream);
+
+/* ---- elementwise helpers ---- */
+/* dst[r, 0:cols_out] = src[r, 0:cols_in] zero-padded (audio conv input 130 -> 136 columns, M:453) */
+int mr_pad_cols(const void* src, int64_t cols_in, void* dst, int64_t cols_out, int64_t rows, void* stream);
+/* dst[g*grp_stride + off, :] = vec  for g < ngroups  (CLS rows, M:316-320) */
+int mr_fill_rows(const void* vec, void* dst, int64_t ldd, int64_t ngroups, int64_t grp_stride, int64_t off, int64_t H,
+                 void* stream);
+/* out[n] = bf16(sum_g src[g*grp_stride + off, n])   (gradient of the CLS parameter) */
+int mr_sum_rows_strided(const void* src, int64_t lds, int64_t ngroups, int64_t grp_stride, int64_t off, int64_t H,
+                        void* out, void* stream);
+/* y = a + b (bf16, fp32 add) over n elements (n % 8 == 0) */
+int mr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* ---- unit_normalize * exp(min(log_scale, ln 100)/2)  (M:570-578, P:239-257) ----
+ * x [rows, H] bf16 -> y bf16; log_scale: pointer to ONE bf16 (the working copy of contrastive_scales[i]).
+ * inv_norm [rows] fp32 saved.  bwd returns dx and ADDS the temperature gradient into dlog_scale (fp32 scalar). */
+int mr_unit_norm_scale_fwd(const void* x, int64_t ldx, const void* log_scale, void* y, int64_t ldy, float* inv_norm,
+                           int64_t rows, int64_t H, void* stream);
+int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* log_scale, const float* inv_norm, const void* dy,
+                           int64_t lddy, void* dx, int64_t lddx, float* dlog_scale, int64_t rows, int64_t H,
+                           void* stream);
+
+/* ---- contrastive loss pieces (P:276-295) ----
+ * logits [L, V] fp32 (from mr_gemm); numer[l] = logits[l, own_off + l]; lse over the V columns (fp32).
+ * loss_out[0] += coef * sum_l (lse[l] - numer[l]);  when src != NULL, per-source sums / counts are added to
+ * diag[0..5] (three sums then three counts, P:296-300).  dlogits (in place) = coef * (softmax - onehot(own)).
+ */
+int mr_contrastive_lse(float* logits, int64_t ldl, int64_t L, int64_t V, int64_t own_off, float coef,
+                       const int32_t* src, float* loss_out, float* diag, void* stream);
+/* bf16 copy of an fp32 matrix (dlogits -> GEMM operand) */
+int mr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ---- optimizer: nan_to_num + bf16-state Adam + weight decay + schedule + apply (P:328, O:54-114, 180-195) ----
+ * Flat buffers of n elements (n % 2048 == 0): master fp32 params, bf16 grads, bf16 mu, bf16 cube-coded nu.
+ * decay_flag_per_block: one uint8 per 2048-element block (1 = weight decay applies: leaf ndim > 1, O:182-184).
+ * sched = schedule(count) (O:117-137) and neg_lr = -learning_rate are computed on the host and applied in the
+ * reference's order, u = (u * sched) * neg_lr.  bias_corr1/2 = 1 - beta^count_inc, or 1.0 when bias correction is off.
+ * Writes master, the bf16 working copy (what the next forward reads, P:323-324), mu, nu.
+ */
+int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                        const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2, float eps,
+                        float weight_decay, float sched, float neg_lr, float bias_corr1, float bias_corr2, void* stream);
+/* grads = nan_to_num(grads) in place (P:328), bf16, n % 8 == 0 */
+int mr_nan_to_num_bf16(void* g, int64_t n, void* stream);
+/* work_bf16 = bf16(master) (P:323-324) */
+int mr_cast_f32_to_bf16_params(const float* master, void* work_bf16, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

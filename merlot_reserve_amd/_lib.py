@@ -1,0 +1,83 @@
+"""ctypes binding of libmreserve_hip.so (include/mreserve_hip.h).  There is NO fallback: if the library is missing
+or a call fails, this raises -- the product path never routes through a CPU implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmreserve_hip.so')
+
+i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('M', i64), ('N', i64), ('K', i64),
+                ('A', vp), ('lda', i64), ('transA', i32),
+                ('B', vp), ('ldb', i64), ('transB', i32),
+                ('C', vp), ('ldc', i64), ('c_dtype', i32),
+                ('bias', vp),
+                ('rot_tab', vp), ('rot_rows', i64), ('rot_cols', i64),
+                ('c2', vp),
+                ('act', i32),
+                ('residual', vp), ('ldr', i64),
+                ('aux', vp), ('ldaux', i64),
+                ('out_grp', i64), ('out_grp_stride', i64), ('out_grp_off', i64)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/mreserve_hip.h
+PROTOTYPES = {
+    'mr_version': (i32, []),
+    'mr_last_error': (C.c_char_p, []),
+    'mr_gemm': (i32, [C.POINTER(GemmArgs), vp]),
+    'mr_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, vp]),
+    'mr_layernorm_bwd_workspace': (i64, [i64]),
+    'mr_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, vp]),
+    'mr_colsum_workspace': (i64, [i64]),
+    'mr_colsum': (i32, [vp, i64, i64, i64, vp, vp, vp]),
+    'mr_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    'mr_attention_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    'mr_poolattn_fwd': (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i64, i64, vp]),
+    'mr_poolattn_bwd': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    'mr_segment_sum': (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i32, i64, i64, f32, i32, vp]),
+    'mr_rows_mean_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
+    'mr_rows_mean_bwd': (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    'mr_pad_cols': (i32, [vp, i64, vp, i64, i64, vp]),
+    'mr_fill_rows': (i32, [vp, vp, i64, i64, i64, i64, i64, vp]),
+    'mr_sum_rows_strided': (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
+    'mr_add_bf16': (i32, [vp, vp, vp, i64, vp]),
+    'mr_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, vp, i64, i64, vp]),
+    'mr_unit_norm_scale_bwd': (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i64, vp]),
+    'mr_contrastive_lse': (i32, [vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
+    'mr_cast_f32_to_bf16': (i32, [vp, vp, i64, vp]),
+    'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    'mr_nan_to_num_bf16': (i32, [vp, i64, vp]),
+    'mr_cast_f32_to_bf16_params': (i32, [vp, vp, i64, vp]),
+}
+
+_lib = None
+
+
+class MreserveHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises if it has not been built: run `python -m merlot_reserve_amd.build`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MreserveHipError(f'{LIB_PATH} not found: the HIP extension is not built '
+                               f'(python -m merlot_reserve_amd.build). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mr_last_error()
+        raise MreserveHipError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')

@@ -1,0 +1,45 @@
+"""Builds libmreserve_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a plain
+C-ABI shared object (include/mreserve_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libmreserve_hip.so')
+SOURCES = ['gemm.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'mr_error.cpp']
+
+
+def _needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'mreserve_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _needs_build():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.o')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    if verbose:
+        print(f'built {LIB}', file=sys.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

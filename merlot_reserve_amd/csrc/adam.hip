@@ -1,0 +1,117 @@
+// Fused optimizer step for gfx950 (HBM-bound, 20 B/param): nan_to_num -> bf16-state Adam (momentum bf16, second moment
+// cube-coded "unsigned bf16") -> weight decay (leaves with ndim > 1) -> schedule -> -lr -> apply, and the bf16 working
+// copy of the parameters for the next forward.
+// Replaces pretrain/pretrain_model.py:323-324,328,339 + pretrain/optimization.py:36-51 (codec), :54-114 (Adam),
+// :180-195 (optax chain).
+#include "mr_common.h"
+
+namespace {
+
+constexpr float MISSING_PRECISION = 1.0f + 1.0f / 512.0f;   // optimization.py:36
+
+__device__ __forceinline__ float nan_to_num_f(float g) {
+    // jnp.nan_to_num on a bf16 leaf: nan -> 0, +-inf -> +-max finite bf16
+    if (g != g) return 0.f;
+    const float BF16_MAX = 3.3895313892515355e38f;
+    if (g > BF16_MAX) return BF16_MAX;
+    if (g < -BF16_MAX) return -BF16_MAX;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, __bf16* __restrict__ work,
+                                                   const __bf16* __restrict__ grad, __bf16* __restrict__ mu,
+                                                   __bf16* __restrict__ nu, const uint8_t* __restrict__ decay_flag, float c1,
+                                                   float b1, float c2, float b2, float eps, float wd, float sched, float neg_lr,
+                                                   float inv_bc1, float inv_bc2) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const bool decay = decay_flag[blockIdx.x] != 0;
+    float g[8], m[8], v[8], p[8];
+    unpack8(*reinterpret_cast<const u32x4*>(grad + i), g);
+    unpack8(*reinterpret_cast<const u32x4*>(mu + i), m);
+    unpack8(*reinterpret_cast<const u32x4*>(nu + i), v);
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(master + i), p1 = *reinterpret_cast<const f32x4*>(master + i + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[e] = p0[e]; p[4 + e] = p1[e]; }
+    float mo[8], vo[8], wo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float ge = nan_to_num_f(g[e]);
+        const float nm = c1 * ge + b1 * m[e];                                   // optimization.py:83-87
+        float va = fabsf(v[e]);
+        if (!(v[e] >= 0.f)) va *= MISSING_PRECISION;                             // :38-41 (v >= 0 also true for -0.0)
+        const float nv = c2 * (ge * ge) + b2 * cbrtf(va);                        // :89-92
+        mo[e] = nm;
+        const float v3 = nv * nv * nv;                                           // :44-51
+        const float vb = (float)(__bf16)v3;
+        const float err0 = fabsf(vb - v3), err1 = fabsf(vb * MISSING_PRECISION - v3);
+        vo[e] = (err0 < err1) ? vb : -vb;
+        float u = (nm * inv_bc1) / (sqrtf(nv * inv_bc2) + eps);                  // :104-110
+        if (decay) u += wd * p[e];                                               // :182-184
+        u = (u * sched) * neg_lr;                                                // :185-189
+        p[e] += u;
+        wo[e] = p[e];
+    }
+    *reinterpret_cast<u32x4*>(mu + i) = pack8(mo);
+    // -0.0 must survive as the sign-coded zero: pack via the sign-preserving conversion
+    *reinterpret_cast<u32x4*>(nu + i) = pack8(vo);
+    *reinterpret_cast<u32x4*>(work + i) = pack8(wo);
+    *reinterpret_cast<f32x4*>(master + i) = f32x4{p[0], p[1], p[2], p[3]};
+    *reinterpret_cast<f32x4*>(master + i + 4) = f32x4{p[4], p[5], p[6], p[7]};
+}
+
+__global__ void nan_to_num_kernel(__bf16* __restrict__ g, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(g + 8 * i), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = nan_to_num_f(v[e]);
+        *reinterpret_cast<u32x4*>(g + 8 * i) = pack8(v);
+    }
+}
+
+__global__ void cast_params_kernel(const float* __restrict__ master, __bf16* __restrict__ work, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(master + 8 * i), b = *reinterpret_cast<const f32x4*>(master + 8 * i + 4);
+        const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        *reinterpret_cast<u32x4*>(work + 8 * i) = pack8(f);
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                                   const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2, float eps,
+                                   float weight_decay, float sched, float neg_lr, float bias_corr1, float bias_corr2,
+                                   void* stream) {
+    MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && decay_flag_per_block, "mr_adam_bf16_update: null pointer");
+    MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update: n must be a positive multiple of 2048 (got %ld)", (long)n);
+    MR_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "mr_adam_bf16_update: bias corrections must be > 0 (1 disables)");
+    // (1 - b) evaluated like the reference: Python double subtraction, then cast to f32 (optimization.py:86, 91)
+    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                       static_cast<__bf16*>(work_bf16), static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16),
+                       static_cast<__bf16*>(nu_bf16), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, sched, neg_lr,
+                       1.0f / bias_corr1, 1.0f / bias_corr2);
+    MR_CHECK_LAUNCH("mr_adam_bf16_update");
+    return MR_OK;
+}
+
+extern "C" int mr_nan_to_num_bf16(void* g, int64_t n, void* stream) {
+    MR_CHECK_ARG(g && n > 0 && n % 8 == 0, "mr_nan_to_num_bf16: n must be a positive multiple of 8");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<__bf16*>(g), n / 8);
+    MR_CHECK_LAUNCH("mr_nan_to_num_bf16");
+    return MR_OK;
+}
+
+extern "C" int mr_cast_f32_to_bf16_params(const float* master, void* work_bf16, int64_t n, void* stream) {
+    MR_CHECK_ARG(master && work_bf16 && n > 0 && n % 8 == 0, "mr_cast_f32_to_bf16_params: n must be a positive multiple of 8");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_params_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                       static_cast<__bf16*>(work_bf16), n / 8);
+    MR_CHECK_LAUNCH("mr_cast_f32_to_bf16_params");
+    return MR_OK;
+}

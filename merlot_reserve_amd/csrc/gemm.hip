@@ -1,0 +1,274 @@
+// bf16 MFMA GEMM with fused epilogue for gfx950 (MI355X).
+//
+// Replaces what XLA generates for the reference's flax Dense/DenseGeneral calls
+// (mreserve/modeling.py:228-236, 252-255, 371, 402, 453, 631) and their transposes in backward.
+//
+// Structure (round 1): 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave a 64x64
+// sub-tile = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  Operands are staged global -> VGPR -> LDS
+// (the next K-tile's global loads are in flight while the current tile is multiplied).
+// An operand whose contraction index is contiguous in memory is read from LDS with ds_read_b128;
+// one whose contraction index is the ROW index (flax [in,out] kernels in forward, both operands in
+// wgrad) is kept row-major in LDS and read with ds_read_b64_tr_b16, so no transposed copy of any
+// weight or activation is ever materialised in HBM.
+// Epilogue: bias / "rotary" diagonal scale / activation in the MFMA layout, then the tile goes
+// through LDS so that residual / gelu' operands are read and C is written as 16-byte row segments.
+#include "mr_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDK = 72;    // K-contiguous tile  [128 rows][64 k + 8 pad]   (144-B rows)
+constexpr int LDT = 144;   // K-strided tile     [64 k][128 cols + 16 pad]  (288-B rows: 8 k-rows tile all 64 banks)
+constexpr int TILE_ELEMS = 128 * LDK;  // == 64 * LDT == 9216
+constexpr int LDC = 136;   // epilogue staging tile [128][128 + 8 pad] bf16
+static_assert(128 * LDK == 64 * LDT, "tile sizes");
+static_assert(128 * LDC <= 2 * TILE_ELEMS, "epilogue tile must fit the staging LDS");
+
+// One operand tile's 4 16-byte chunks per thread.
+//  TR = false: tile rows = the operand's own rows (128 of them), 8 chunks along K per row.
+//  TR = true : tile rows = K (64 of them), 16 chunks along the operand's own index per row.
+template <bool TR>
+__device__ __forceinline__ void load_tile(const __bf16* __restrict__ base, int64_t ld, int64_t own0, int64_t k0,
+                                          int64_t own_n, int64_t K, int tid, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = tid + 256 * it;
+        int64_t grow, gcol;
+        bool ok;
+        if (!TR) {
+            const int row = c >> 3, ch = c & 7;
+            grow = own0 + row;
+            gcol = k0 + 8 * ch;
+            ok = (grow < own_n) && (gcol < K);
+        } else {
+            const int row = c >> 4, ch = c & 15;
+            grow = k0 + row;
+            gcol = own0 + 8 * ch;
+            ok = (grow < K) && (gcol < own_n);
+        }
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(base + grow * ld + gcol);
+        r[it] = v;
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void store_tile(__bf16* tile, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = tid + 256 * it;
+        int off;
+        if (!TR) off = (c >> 3) * LDK + 8 * (c & 7);
+        else     off = (c >> 4) * LDT + 8 * (c & 15);
+        *reinterpret_cast<u32x4*>(tile + off) = r[it];
+    }
+}
+
+// Fragment of 16 "own" indices x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds own = own0 + (l & 15),
+// k = 8*(l >> 4) + j, j = 0..7.
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int own0, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!TR) {
+        return *reinterpret_cast<const bf16x8*>(tile + (own0 + i) * LDK + kk * 32 + g * 8);
+    } else {
+        // ds_read_b64_tr_b16: the 16-lane group reads a 4(k) x 16(own) block; lane 4q+p gives the address of
+        // row q, columns 4p..4p+3 and receives column (l & 15), rows 0..3.
+        const int q = i >> 2, p = i & 3;
+        const __bf16* a0 = tile + (kk * 32 + g * 8 + q) * LDT + own0 + 4 * p;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(MR_LDS_PTR(s16x4, a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(MR_LDS_PTR(s16x4, a0 + 4 * LDT));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * TILE_ELEMS];
+    __bf16* As = smem;
+    __bf16* Bs = smem + TILE_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    // XCD-aware (bijective) block -> tile map: blocks that share an XCD's L2 get neighbouring tiles.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int64_t m0 = (int64_t)(wgid / tiles_n) * BM;
+    const int64_t n0 = (int64_t)(wgid % tiles_n) * BN;
+
+    const __bf16* A = static_cast<const __bf16*>(p.A);
+    const __bf16* B = static_cast<const __bf16*>(p.B);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    const int64_t nk = (p.K + BK - 1) / BK;
+    load_tile<TA>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
+    load_tile<!TB>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    store_tile<TA>(As, tid, ra);
+    store_tile<!TB>(Bs, tid, rb);
+    __syncthreads();
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_tile<TA>(A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid, ra);
+            load_tile<!TB>(B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, tid, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(As, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<!TB>(Bs, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile<TA>(As, tid, ra);
+            store_tile<!TB>(Bs, tid, rb);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue, phase 1: MFMA layout (col = lane & 15, row = 4*(lane >> 4) + r) ----------------
+    const __bf16* bias = static_cast<const __bf16*>(p.bias);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t n = n0 + wn * 64 + j * 16 + li;
+        float bv = 0.f;
+        if (bias != nullptr && n < p.N) bv = (float)bias[n];
+        const bool rot = (p.rot_tab != nullptr) && (n < p.rot_cols) && ((n & 63) < 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv;
+                if (rot) {
+                    const int64_t m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                    if (m < p.M) v *= p.rot_tab[(m % p.rot_rows) * 32 + (n & 63)];
+                }
+                acc[i][j][r] = v;
+            }
+        }
+    }
+
+    if (p.c_dtype == MR_DT_F32) {
+        float* C = static_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                    if (m < p.M && n < p.N) C[m * p.ldc + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+
+    __bf16* Cs = smem;
+    const int npass = (p.c2 != nullptr) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const bool final_pass = (pass == npass - 1);
+        const bool do_act = final_pass && (p.act == MR_ACT_GELU1702);
+        // stage the tile as bf16
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r];
+                    if (do_act) v = gelu1702(v);
+                    Cs[(wm * 64 + i * 16 + g * 4 + r) * LDC + wn * 64 + j * 16 + li] = (__bf16)v;
+                }
+        __syncthreads();
+        // phase 2: 16-byte row segments
+        __bf16* Cout = static_cast<__bf16*>(final_pass ? p.C : p.c2);
+        const __bf16* R = final_pass ? static_cast<const __bf16*>(p.residual) : nullptr;
+        const __bf16* X = final_pass ? static_cast<const __bf16*>(p.aux) : nullptr;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c >> 4, ch = c & 15;
+            const int64_t gm = m0 + row, gn = n0 + 8 * ch;
+            if (gm < p.M && gn < p.N) {
+                u32x4 raw = *reinterpret_cast<const u32x4*>(Cs + row * LDC + 8 * ch);
+                int64_t orow = gm;
+                if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
+                if (R != nullptr || X != nullptr) {
+                    float f[8];
+                    unpack8(raw, f);
+                    if (R != nullptr) {
+                        float rr[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(R + orow * p.ldr + gn), rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+                    }
+                    if (X != nullptr) {
+                        float xx[8];
+                        unpack8(*reinterpret_cast<const u32x4*>(X + orow * p.ldaux + gn), xx);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = (float)(__bf16)f[e] * gelu1702_grad(xx[e]);
+                    }
+                    raw = pack8(f);
+                }
+                *reinterpret_cast<u32x4*>(Cout + orow * p.ldc + gn) = raw;
+            }
+        }
+        if (!final_pass) __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
+    MR_CHECK_ARG(a != nullptr, "mr_gemm: null args");
+    MR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "mr_gemm: empty problem M=%ld N=%ld K=%ld", (long)a->M, (long)a->N, (long)a->K);
+    MR_CHECK_ARG(a->A && a->B && a->C, "mr_gemm: null operand");
+    MR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mr_gemm: lda/ldb must be multiples of 8 (got %ld, %ld)", (long)a->lda, (long)a->ldb);
+    // the contiguous dimension of each operand is consumed in 16-byte chunks
+    MR_CHECK_ARG((a->transA ? a->M : a->K) % 8 == 0, "mr_gemm: contiguous dim of A must be a multiple of 8");
+    MR_CHECK_ARG((a->transB ? a->K : a->N) % 8 == 0, "mr_gemm: contiguous dim of B must be a multiple of 8");
+    MR_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
+                 "mr_gemm: operands must be 16-byte aligned");
+    if (a->c_dtype == MR_DT_BF16) {
+        MR_CHECK_ARG(a->N % 8 == 0 && a->ldc % 8 == 0, "mr_gemm: bf16 output needs N, ldc multiples of 8");
+        MR_CHECK_ARG(!a->residual || a->ldr % 8 == 0, "mr_gemm: ldr must be a multiple of 8");
+        MR_CHECK_ARG(!a->aux || a->ldaux % 8 == 0, "mr_gemm: ldaux must be a multiple of 8");
+    } else {
+        MR_CHECK_ARG(a->c_dtype == MR_DT_F32, "mr_gemm: bad c_dtype %d", a->c_dtype);
+        MR_CHECK_ARG(!a->residual && !a->aux && !a->c2 && a->act == MR_ACT_NONE && a->out_grp == 0,
+                     "mr_gemm: fp32 output supports bias only");
+    }
+    MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
+    const int64_t tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
+    MR_CHECK_ARG(tm * tn < (1LL << 30), "mr_gemm: grid too large");
+    dim3 grid((unsigned)(tm * tn)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, *a, (int)tn);
+    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, *a, (int)tn);
+    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, *a, (int)tn);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn);
+    MR_CHECK_LAUNCH("mr_gemm");
+    return MR_OK;
+}

@@ -1,0 +1,219 @@
+// LayerNorm forward / backward and column sums for gfx950 (HBM-bound: one wave per row, 16-byte vectors,
+// wavefront reductions).  Replaces flax nn.LayerNorm(epsilon=1e-5) as used at mreserve/modeling.py:272,277,360,366:
+// statistics in fp32 with var = E[x^2] - E[x]^2, y = (x - mean) * (rsqrt(var + eps) * scale) + bias.
+#include "mr_common.h"
+
+namespace {
+
+constexpr int MAXC = 4;           // 16-byte chunks per lane (template MC <= MAXC): H <= 64 * 8 * 4 = 2048
+constexpr int PART_ROWS = 256;    // rows of the fp32 partial-sum workspace
+
+template <int MC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ x, int64_t ldx, const __bf16* __restrict__ gamma,
+                                                     const __bf16* __restrict__ beta, __bf16* __restrict__ y, int64_t ldy,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
+                                                     int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H >> 3;
+    float v[MC][8];
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nch) {
+            unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + 8 * c), v[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s += v[k][e]; s2 += v[k][e] * v[k][e]; }
+        }
+    }
+    s = wave_sum(s);
+    s2 = wave_sum(s2);
+    const float mean = s / (float)H;
+    const float var = s2 / (float)H - mean * mean;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nch) {
+            float gm[8], bt[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(gamma + 8 * c), gm);
+            unpack8(*reinterpret_cast<const u32x4*>(beta + 8 * c), bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * (rstd * gm[e]) + bt[e];
+            *reinterpret_cast<u32x4*>(y + row * ldy + 8 * c) = pack8(o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial sums of dgamma = dy * xhat, dbeta = dy.
+template <int MC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, int64_t lddy, const __bf16* __restrict__ x,
+                                                     int64_t ldx, const __bf16* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, __bf16* __restrict__ dx, int64_t lddx,
+                                                     int add_to_dx, float* __restrict__ partials, int64_t rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2H]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = H >> 3;
+    float pg[MC][8], pb[MC][8], gm[MC][8];
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+        const int c = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pg[k][e] = 0.f; pb[k][e] = 0.f; gm[k][e] = 0.f; }
+        if (c < nch) unpack8(*reinterpret_cast<const u32x4*>(gamma + 8 * c), gm[k]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[MC][8], gg[MC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                float xv[8], dv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + 8 * c), xv);
+                unpack8(*reinterpret_cast<const u32x4*>(dy + row * lddy + 8 * c), dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[k][e] = (xv[e] - mu) * rs;
+                    gg[k][e] = dv[e] * gm[k][e];
+                    s1 += gg[k][e];
+                    s2 += gg[k][e] * xh[k][e];
+                    pg[k][e] += dv[e] * xh[k][e];
+                    pb[k][e] += dv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (gg[k][e] - s1 - xh[k][e] * s2);
+                if (add_to_dx) {
+                    float old[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(dx + row * lddx + 8 * c), old);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += old[e];
+                }
+                *reinterpret_cast<u32x4*>(dx + row * lddx + 8 * c) = pack8(o);
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS, one fp32 row [2H] per block
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[wave * 2 * H + 8 * c + e] = pg[k][e];
+                red[wave * 2 * H + H + 8 * c + e] = pb[k][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256)
+        partials[(int64_t)blockIdx.x * 2 * H + c] = red[c] + red[2 * H + c] + red[4 * H + c] + red[6 * H + c];
+}
+
+// out[c] = bf16(sum_p partials[p, c]);  columns [0, split) go to out0, [split, ncols) to out1
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int ncols, int split,
+                                       __bf16* __restrict__ out0, __bf16* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partials[(int64_t)p * ncols + c];
+    if (c < split) out0[c] = (__bf16)s;
+    else out1[c - split] = (__bf16)s;
+}
+
+// column sums: grid.x = 512-column groups, grid.y = row strips; partial[strip, N]
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ x, int64_t ldx, int64_t rows, int N,
+                                                     float* __restrict__ partials) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;     // chunk index
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < (N >> 3)) {
+        for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)gridDim.y * 4) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + 8 * c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 512; t += 256) {
+        const int col = blockIdx.x * 512 + t;
+        if (col < N) partials[(int64_t)blockIdx.y * N + col] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    }
+}
+
+}  // namespace
+
+extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                                float* mean, float* rstd, int64_t rows, int64_t H, float eps, void* stream) {
+    MR_CHECK_ARG(x && gamma && beta && y, "mr_layernorm_fwd: null pointer");
+    MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_fwd: H=%ld unsupported", (long)H);
+    MR_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0, "mr_layernorm_fwd: leading dims must be multiples of 8");
+    auto kern = (H <= 1024) ? ln_fwd_kernel<2> : ln_fwd_kernel<MAXC>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __bf16*>(x), ldx, static_cast<const __bf16*>(gamma), static_cast<const __bf16*>(beta),
+                       static_cast<__bf16*>(y), ldy, mean, rstd, rows, (int)H, eps);
+    MR_CHECK_LAUNCH("mr_layernorm_fwd");
+    return MR_OK;
+}
+
+extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)PART_ROWS * 2 * H * sizeof(float); }
+
+extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* mean,
+                                const float* rstd, void* dx, int64_t lddx, int32_t add_to_dx, void* dgamma, void* dbeta,
+                                void* partials, int64_t rows, int64_t H, void* stream) {
+    MR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partials, "mr_layernorm_bwd: null pointer");
+    MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_bwd: H=%ld unsupported", (long)H);
+    MR_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0, "mr_layernorm_bwd: leading dims must be multiples of 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t nblk = (rows + 3) / 4;
+    if (nblk > PART_ROWS) nblk = PART_ROWS;
+    auto kern = (H <= 1024) ? ln_bwd_kernel<2> : ln_bwd_kernel<MAXC>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), (size_t)(8 * H * sizeof(float)), s,
+                       static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
+                       static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, (int)add_to_dx,
+                       static_cast<float*>(partials), rows, (int)H);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((2 * H + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H, static_cast<__bf16*>(dgamma),
+                       static_cast<__bf16*>(dbeta));
+    MR_CHECK_LAUNCH("mr_layernorm_bwd");
+    return MR_OK;
+}
+
+constexpr int COLSUM_STRIPS = 64;
+extern "C" int64_t mr_colsum_workspace(int64_t N) { return (int64_t)COLSUM_STRIPS * N * sizeof(float); }
+
+extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream) {
+    MR_CHECK_ARG(x && out && partials, "mr_colsum: null pointer");
+    MR_CHECK_ARG(rows > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, "mr_colsum: N and ldx must be multiples of 8");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t strips = (rows + 3) / 4;
+    if (strips > COLSUM_STRIPS) strips = COLSUM_STRIPS;
+    dim3 grid((unsigned)((N / 8 + 63) / 64), (unsigned)strips);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(x), ldx, rows, (int)N,
+                       static_cast<float*>(partials));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(partials), (int)strips, (int)N, (int)N, static_cast<__bf16*>(out),
+                       static_cast<__bf16*>(out));
+    MR_CHECK_LAUNCH("mr_colsum");
+    return MR_OK;
+}

@@ -1,0 +1,216 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/mreserve_hip.h).  torch is plumbing here: device memory and the
+current HIP stream.  Every op launches asynchronously on torch's current stream; nothing allocates unless an output
+tensor is not passed in.  All 2-D operands must have unit stride in the last dim; the row stride is the leading dim."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+BF16, F32 = torch.bfloat16, torch.float32
+MR_DT_BF16, MR_DT_F32 = 0, 1
+ACT_NONE, ACT_GELU = 0, 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f'need a row-major 2-D view, got {tuple(t.shape)} / {t.stride()}'
+    return t.stride(0)
+
+
+def gemm(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
+         residual=None, aux=None, row_map=None):
+    """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
+    (or [N,K] if transB).  row_map = (grp, grp_stride, grp_off) remaps output rows (out must be big enough)."""
+    lib = _lib.load()
+    M, K = (a.shape[1], a.shape[0]) if transA else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if transB else (b.shape[0], b.shape[1])
+    assert K == Kb, f'gemm: K mismatch {K} vs {Kb}'
+    assert a.dtype == BF16 and b.dtype == BF16
+    g = GemmArgs()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.lda, g.transA = a.data_ptr(), _ld(a), int(transA)
+    g.B, g.ldb, g.transB = b.data_ptr(), _ld(b), int(transB)
+    g.C, g.ldc = out.data_ptr(), _ld(out)
+    g.c_dtype = MR_DT_F32 if out.dtype == F32 else MR_DT_BF16
+    g.bias = _ptr(bias)
+    if rot_tab is not None:
+        assert rot_tab.dtype == F32 and rot_tab.is_contiguous() and rot_tab.shape[-1] == 32
+        g.rot_tab, g.rot_rows, g.rot_cols = rot_tab.data_ptr(), rot_tab.numel() // 32, rot_cols
+    else:
+        g.rot_tab, g.rot_rows, g.rot_cols = None, 0, 0
+    g.c2 = _ptr(c2)
+    if c2 is not None:
+        assert _ld(c2) == g.ldc
+    g.act = act
+    g.residual, g.ldr = (_ptr(residual), _ld(residual)) if residual is not None else (None, 0)
+    g.aux, g.ldaux = (_ptr(aux), _ld(aux)) if aux is not None else (None, 0)
+    if row_map is not None:
+        g.out_grp, g.out_grp_stride, g.out_grp_off = row_map
+        assert out.shape[0] >= ((M - 1) // row_map[0]) * row_map[1] + row_map[2] + (M - 1) % row_map[0] + 1
+    else:
+        g.out_grp = g.out_grp_stride = g.out_grp_off = 0
+        assert out.shape[0] >= M and out.shape[1] >= N
+    check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
+    rows, H = x.shape
+    check(_lib.load().mr_layernorm_fwd(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ld(y),
+                                       _ptr(mean), _ptr(rstd), rows, H, eps, _stream()), 'mr_layernorm_fwd')
+    return y
+
+
+def layernorm_bwd_workspace(H, device):
+    return torch.empty(_lib.load().mr_layernorm_bwd_workspace(H) // 4, dtype=F32, device=device)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False):
+    rows, H = x.shape
+    check(_lib.load().mr_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), dx.data_ptr(), _ld(dx), int(add_to_dx), dgamma.data_ptr(),
+                                       dbeta.data_ptr(), partials.data_ptr(), rows, H, _stream()), 'mr_layernorm_bwd')
+    return dx
+
+
+def colsum_workspace(N, device):
+    return torch.empty(_lib.load().mr_colsum_workspace(N) // 4, dtype=F32, device=device)
+
+
+def colsum(x, out, partials):
+    rows, N = x.shape
+    check(_lib.load().mr_colsum(x.data_ptr(), _ld(x), rows, N, out.data_ptr(), partials.data_ptr(), _stream()), 'mr_colsum')
+    return out
+
+
+def attention_fwd(qkv, code, out, lse, nseq, S, nh):
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (nseq * S, 3 * nh * 64)
+    check(_lib.load().mr_attention_fwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), lse.data_ptr(), nseq, S, nh, _stream()),
+          'mr_attention_fwd')
+    return out
+
+
+def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh):
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    rr = 0 if rot_tab is None else rot_tab.numel() // 32
+    check(_lib.load().mr_attention_bwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                       delta.data_ptr(), dqkv.data_ptr(), _ptr(rot_tab), rr, nseq, S, nh, _stream()),
+          'mr_attention_bwd')
+    return dqkv
+
+
+def poolattn_fwd(q, k, v, key_rows, out, probs, nh):
+    G, R = key_rows.shape
+    assert _ld(k) == _ld(v)
+    check(_lib.load().mr_poolattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), out.data_ptr(),
+                                      probs.data_ptr(), G, R, nh, _stream()), 'mr_poolattn_fwd')
+    return out
+
+
+def poolattn_bwd(q, k, v, key_rows, probs, dout, dq, dk, dv, nh):
+    G, R = key_rows.shape
+    assert _ld(k) == _ld(v) == _ld(dk) == _ld(dv)
+    check(_lib.load().mr_poolattn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), probs.data_ptr(),
+                                      dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), G, R, nh, _stream()),
+          'mr_poolattn_bwd')
+
+
+def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
+    """srcs: list of 1..3 row tables; indices address their row-wise concatenation."""
+    s = list(srcs) + [None] * (3 - len(srcs))
+    n = [0 if t is None else t.shape[0] for t in s]
+    ld = [0 if t is None else _ld(t) for t in s]
+    n_dst, H = dst.shape
+    assert indptr.numel() == n_dst + 1 and indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    check(_lib.load().mr_segment_sum(_ptr(s[0]), ld[0], n[0], _ptr(s[1]), ld[1], n[1], _ptr(s[2]), ld[2], n[2],
+                                     indptr.data_ptr(), indices.data_ptr(), dst.data_ptr(), _ld(dst),
+                                     MR_DT_F32 if dst.dtype == F32 else MR_DT_BF16, n_dst, H, scale, int(accumulate),
+                                     _stream()), 'mr_segment_sum')
+    return dst
+
+
+def rows_mean_fwd(src, rows, dst):
+    G, R = rows.shape
+    check(_lib.load().mr_rows_mean_fwd(src.data_ptr(), _ld(src), rows.data_ptr(), dst.data_ptr(), G, R, dst.shape[1], _stream()),
+          'mr_rows_mean_fwd')
+    return dst
+
+
+def rows_mean_bwd(ddst, rows, dsrc):
+    G, R = rows.shape
+    check(_lib.load().mr_rows_mean_bwd(ddst.data_ptr(), rows.data_ptr(), dsrc.data_ptr(), _ld(dsrc), G, R, ddst.shape[1],
+                                       _stream()), 'mr_rows_mean_bwd')
+
+
+def pad_cols(src, dst):
+    assert src.is_contiguous() and dst.is_contiguous()
+    check(_lib.load().mr_pad_cols(src.data_ptr(), src.shape[1], dst.data_ptr(), dst.shape[1], src.shape[0], _stream()),
+          'mr_pad_cols')
+    return dst
+
+
+def fill_rows(vec, dst, ngroups, grp_stride, off):
+    check(_lib.load().mr_fill_rows(vec.data_ptr(), dst.data_ptr(), _ld(dst), ngroups, grp_stride, off, dst.shape[1], _stream()),
+          'mr_fill_rows')
+
+
+def sum_rows_strided(src, ngroups, grp_stride, off, out):
+    check(_lib.load().mr_sum_rows_strided(src.data_ptr(), _ld(src), ngroups, grp_stride, off, src.shape[1], out.data_ptr(),
+                                          _stream()), 'mr_sum_rows_strided')
+    return out
+
+
+def add_(a, b, y=None):
+    y = a if y is None else y
+    check(_lib.load().mr_add_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), 'mr_add_bf16')
+    return y
+
+
+def unit_norm_scale_fwd(x, log_scale, y, inv_norm):
+    rows, H = x.shape
+    check(_lib.load().mr_unit_norm_scale_fwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), y.data_ptr(), _ld(y),
+                                             inv_norm.data_ptr(), rows, H, _stream()), 'mr_unit_norm_scale_fwd')
+    return y
+
+
+def unit_norm_scale_bwd(x, log_scale, inv_norm, dy, dx, dlog_scale):
+    rows, H = x.shape
+    check(_lib.load().mr_unit_norm_scale_bwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), inv_norm.data_ptr(), dy.data_ptr(),
+                                             _ld(dy), dx.data_ptr(), _ld(dx), dlog_scale.data_ptr(), rows, H, _stream()),
+          'mr_unit_norm_scale_bwd')
+    return dx
+
+
+def contrastive_lse(logits, own_off, coef, src, loss_out, diag):
+    L, V = logits.shape
+    check(_lib.load().mr_contrastive_lse(logits.data_ptr(), _ld(logits), L, V, own_off, coef, _ptr(src), loss_out.data_ptr(),
+                                         _ptr(diag), _stream()), 'mr_contrastive_lse')
+
+
+def cast_f32_to_bf16(src, dst):
+    check(_lib.load().mr_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), 'mr_cast_f32_to_bf16')
+    return dst
+
+
+def adam_bf16_update(master, work, grad, mu, nu, decay_flags, b1, b2, eps, weight_decay, sched, neg_lr, bc1=1.0, bc2=1.0):
+    check(_lib.load().mr_adam_bf16_update(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
+                                          decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay, sched, neg_lr,
+                                          bc1, bc2, _stream()), 'mr_adam_bf16_update')
+
+
+def nan_to_num_(g):
+    check(_lib.load().mr_nan_to_num_bf16(g.data_ptr(), g.numel(), _stream()), 'mr_nan_to_num_bf16')
+
+
+def cast_params(master, work):
+    check(_lib.load().mr_cast_f32_to_bf16_params(master.data_ptr(), work.data_ptr(), master.numel(), _stream()),
+          'mr_cast_f32_to_bf16_params')

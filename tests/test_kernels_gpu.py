@@ -1,0 +1,399 @@
+"""Per-kernel numerics on the MI355X: each C-ABI entry point against a plain PyTorch fp32 reference of the same op
+(inputs are bf16-representable, so the reference sees exactly the kernel's inputs).  Tolerances are stated per test:
+outputs are bf16 (rel. precision 2^-8 = 3.9e-3), accumulation fp32."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF16).to(dev)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def assert_close(got, ref, rel, name=''):
+    e = relerr(got, ref)
+    assert math.isfinite(e) and e <= rel, f'{name}: rel-L2 err {e:.3e} > {rel:.1e}'
+    # elementwise: bf16 output rounding (4e-3 relative) plus accumulated noise relative to the tensor's scale
+    tol = 8e-3 * ref.float().abs() + 4 * rel * ref.float().abs().mean() + 1e-6
+    bad = ((got.float() - ref.float()).abs() > tol).float().mean().item()
+    assert bad < 1e-3, f'{name}: {bad * 100:.3f}% of elements outside tolerance'
+
+
+GEMM_CASES = [
+    # M, N, K, transA, transB
+    (128, 128, 64, False, False),
+    (300, 264, 200, False, False),   # ragged in every dim
+    (241 * 4, 384, 128, False, False),
+    (300, 264, 200, False, True),
+    (304, 264, 200, True, False),
+    (304, 264, 200, True, True),
+    (128, 3072, 768, False, False),
+    (1000, 768, 3072, False, True),
+    (768, 3072, 1000, True, False),
+    (64, 8, 136, False, False),      # tiny N, K = padded audio patch
+]
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', GEMM_CASES)
+def test_gemm_plain(dev, M, N, K, ta, tb):
+    from merlot_reserve_amd import ops
+    a = rnd((K, M) if ta else (M, K), dev, seed=1)
+    b = rnd((N, K) if tb else (K, N), dev, seed=2)
+    out = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
+    ops.gemm(a, b, out, transA=ta, transB=tb)
+    A = a.float().T if ta else a.float()
+    B = b.float().T if tb else b.float()
+    assert_close(out, A @ B, 3e-3, f'gemm {M}x{N}x{K} ta={ta} tb={tb}')
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches a transposed C write."""
+    from merlot_reserve_amd import ops
+    n = 128
+    a = torch.eye(n, dtype=BF16, device=dev)
+    b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(BF16)
+    out = torch.zeros(n, n, dtype=BF16, device=dev)
+    for ta in (False, True):
+        for tb in (False, True):
+            ops.gemm(a, b.T.contiguous() if tb else b, out, transA=ta, transB=tb)
+            assert torch.equal(out, b), f'ta={ta} tb={tb}'
+
+
+def test_gemm_f32_out_and_bias(dev):
+    from merlot_reserve_amd import ops
+    M, N, K = 100, 52, 768
+    a, b = rnd((M, K), dev, seed=3), rnd((N, K), dev, seed=4)
+    bias = rnd((N,), dev, seed=5)
+    out = torch.zeros(M, N, dtype=F32, device=dev)
+    ops.gemm(a, b, out, transB=True, bias=bias)
+    ref = a.float() @ b.float().T + bias.float()
+    assert relerr(out, ref) < 1e-5
+
+
+def test_gemm_epilogues(dev):
+    from merlot_reserve_amd import ops
+    M, N, K = 482, 384, 128           # 2 sequences of 241, 2 heads x 3 x 64
+    a, w = rnd((M, K), dev, seed=6), rnd((K, N), dev, scale=0.1, seed=7)
+    bias = rnd((N,), dev, seed=8)
+    tab = torch.rand(241, 32, device=dev) * 2 - 1
+    # qkv-style: bias + rotary scale on the first 256 columns (q and k heads)
+    out = torch.zeros(M, N, dtype=BF16, device=dev)
+    ops.gemm(a, w, out, bias=bias, rot_tab=tab, rot_cols=256)
+    ref = a.float() @ w.float() + bias.float()
+    scale = torch.ones(M, N, device=dev)
+    rows = torch.arange(M, device=dev) % 241
+    for h in range(4):
+        scale[:, h * 64:h * 64 + 32] = tab[rows]
+    assert_close(out, ref * scale, 3e-3, 'rot epilogue')
+    # mlp-in style: bias + gelu, pre-activation copy
+    pre = torch.zeros(M, N, dtype=BF16, device=dev)
+    ops.gemm(a, w, out, bias=bias, act=ops.ACT_GELU, c2=pre)
+    assert_close(pre, ref, 3e-3, 'c2')
+    assert_close(out, ref * torch.sigmoid(1.702 * ref), 4e-3, 'gelu')
+    # residual
+    res = rnd((M, N), dev, seed=9)
+    ops.gemm(a, w, out, residual=res)
+    assert_close(out, (a.float() @ w.float()).to(BF16).float() + res.float(), 3e-3, 'residual')
+    # in-place residual (C == residual)
+    buf = res.clone()
+    ops.gemm(a, w, buf, residual=buf)
+    assert torch.equal(buf, out)
+    # gelu' multiply
+    aux = rnd((M, N), dev, seed=10)
+    ops.gemm(a, w, out, aux=aux)
+    s = torch.sigmoid(1.702 * aux.float())
+    gp = s + 1.702 * aux.float() * s * (1 - s)
+    assert_close(out, (a.float() @ w.float()).to(BF16).float() * gp, 4e-3, 'gelu grad')
+    # row map: groups of 240 rows land after a CLS row
+    M2 = 480
+    a2 = rnd((M2, K), dev, seed=11)
+    big = torch.zeros(2 * 241, N, dtype=BF16, device=dev)
+    ops.gemm(a2, w, big, bias=bias, row_map=(240, 241, 1))
+    ref2 = (a2.float() @ w.float() + bias.float())
+    got = big.reshape(2, 241, N)
+    assert torch.all(got[:, 0] == 0)
+    assert_close(got[:, 1:].reshape(M2, N), ref2, 3e-3, 'row map')
+
+
+@pytest.mark.parametrize('rows,H', [(5, 128), (1000, 768), (333, 1024), (64, 2048)])
+def test_layernorm(dev, rows, H):
+    from merlot_reserve_amd import ops
+    x = rnd((rows, H), dev, scale=2.0, seed=1) + 0.5
+    gamma, beta = rnd((H,), dev, seed=2) + 1, rnd((H,), dev, seed=3)
+    y = torch.zeros_like(x)
+    mean = torch.zeros(rows, device=dev)
+    rstd = torch.zeros(rows, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd)
+    xf = x.float()
+    mu = xf.mean(-1, keepdim=True)
+    var = (xf * xf).mean(-1, keepdim=True) - mu * mu
+    ref = (xf - mu) * (torch.rsqrt(var + 1e-5) * gamma.float()) + beta.float()
+    assert_close(y, ref, 3e-3, 'ln fwd')
+    assert relerr(mean, mu[:, 0]) < 1e-5 and relerr(rstd, torch.rsqrt(var + 1e-5)[:, 0]) < 1e-5
+    # backward vs autograd
+    dy = rnd((rows, H), dev, seed=4)
+    xr = xf.clone().requires_grad_(True)
+    gr = gamma.float().clone().requires_grad_(True)
+    br = beta.float().clone().requires_grad_(True)
+    mu2 = xr.mean(-1, keepdim=True)
+    var2 = (xr * xr).mean(-1, keepdim=True) - mu2 * mu2
+    ((xr - mu2) * (torch.rsqrt(var2 + 1e-5) * gr) + br).backward(dy.float())
+    dx = torch.zeros_like(x)
+    dg, db = torch.zeros(H, dtype=BF16, device=dev), torch.zeros(H, dtype=BF16, device=dev)
+    ws = ops.layernorm_bwd_workspace(H, dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, ws)
+    assert_close(dx, xr.grad, 4e-3, 'ln dx')
+    assert_close(dg, gr.grad, 4e-3, 'ln dgamma')
+    assert_close(db, br.grad, 4e-3, 'ln dbeta')
+    # accumulate form
+    dx2 = dy.clone()
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx2, dg, db, ws, add_to_dx=True)
+    assert_close(dx2, xr.grad + dy.float(), 4e-3, 'ln dx accumulate')
+
+
+def test_colsum(dev):
+    from merlot_reserve_amd import ops
+    x = rnd((1234, 776), dev, seed=5)
+    out = torch.zeros(776, dtype=BF16, device=dev)
+    ops.colsum(x, out, ops.colsum_workspace(776, dev))
+    assert_close(out, x.float().sum(0), 4e-3, 'colsum')
+
+
+def ref_attention(qkv, code, nseq, S, nh):
+    H = nh * 64
+    q, k, v = qkv.float().reshape(nseq, S, 3, nh, 64).unbind(2)
+    s = torch.einsum('nqhd,nkhd->nhqk', q / 8.0, k)
+    if code is not None:
+        c = code.reshape(nseq, S)
+        allowed = (c[:, :, None] == c[:, None, :]) & (c[:, :, None] >= 0)
+        s = s + torch.where(allowed, 0.0, -1e10)[:, None]
+    p = torch.softmax(s, -1)
+    o = torch.einsum('nhqk,nkhd->nqhd', p, v).reshape(nseq * S, H)
+    return o, torch.logsumexp(s, -1)
+
+
+ATTN_CASES = [(3, 241, 2, False), (5, 31, 2, False), (2, 640, 3, True), (7, 16, 2, True), (2, 64, 1, False),
+              (1, 130, 12, True)]
+
+
+@pytest.mark.parametrize('nseq,S,nh,masked', ATTN_CASES)
+def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
+    from merlot_reserve_amd import ops
+    H = nh * 64
+    qkv = rnd((nseq * S, 3 * H), dev, seed=1)
+    code = None
+    if masked:
+        g = torch.Generator().manual_seed(7)
+        c = torch.randint(0, 2, (nseq, S), generator=g)
+        pad = torch.rand(nseq, S, generator=g) < 0.2
+        c[pad] = -1
+        c[:, 0] = 0
+        code = c.to(torch.int32).reshape(-1).to(dev)
+    out = torch.zeros(nseq * S, H, dtype=BF16, device=dev)
+    lse = torch.zeros(nseq, nh, S, device=dev)
+    ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref_o, ref_lse = ref_attention(qr, code, nseq, S, nh)
+    assert_close(out, ref_o, 4e-3, 'attn out')
+    valid = torch.ones(nseq, S, dtype=torch.bool, device=dev) if code is None else (code.reshape(nseq, S) >= 0)
+    vm = valid[:, None, :].expand(nseq, nh, S)
+    assert relerr(lse[vm], ref_lse[vm]) < 1e-3
+    # backward: upstream gradient zero on masked-out (padded) query rows, as on the real path
+    dout = rnd((nseq * S, H), dev, seed=2) * valid.reshape(-1, 1).to(BF16)
+    ref_o.backward(dout.float())
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.zeros(nseq, nh, S, device=dev)
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+    g = qr.grad
+    for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
+        assert_close(dqkv[:, sl], g[:, sl], 1.5e-2, f'attn {name}')
+    # rotary-scale on the way out
+    tab = torch.rand(S, 32, device=dev) * 2 - 1
+    dq2 = torch.zeros_like(qkv)
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dq2, tab, nseq, S, nh)
+    scale = torch.ones(nseq * S, 3 * H, device=dev)
+    rows = torch.arange(nseq * S, device=dev) % S
+    for h in range(2 * nh):
+        scale[:, h * 64:h * 64 + 32] = tab[rows]
+    assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
+
+
+def test_poolattn(dev):
+    from merlot_reserve_amd import ops
+    nh, H, G, R, rows = 2, 128, 37, 5, 37 * 5 + 3
+    q, k, v = rnd((G, H), dev, seed=1), rnd((rows, H), dev, seed=2), rnd((rows, H), dev, seed=3)
+    perm = torch.randperm(rows, generator=torch.Generator().manual_seed(0))[:G * R].reshape(G, R).to(torch.int32).to(dev)
+    out = torch.zeros(G, H, dtype=BF16, device=dev)
+    probs = torch.zeros(G, nh, R, device=dev)
+    ops.poolattn_fwd(q, k, v, perm, out, probs, nh)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    kk = kr[perm.long()].reshape(G, R, nh, 64)
+    vv = vr[perm.long()].reshape(G, R, nh, 64)
+    s = torch.einsum('ghd,grhd->ghr', qr.reshape(G, nh, 64) / 8.0, kk)
+    p = torch.softmax(s, -1)
+    ref = torch.einsum('ghr,grhd->ghd', p, vv).reshape(G, H)
+    assert_close(out, ref, 4e-3, 'poolattn out')
+    assert relerr(probs, p) < 1e-4
+    dout = rnd((G, H), dev, seed=4)
+    ref.backward(dout.float())
+    dq = torch.zeros_like(q)
+    dk, dv = torch.zeros_like(k), torch.zeros_like(v)
+    ops.poolattn_bwd(q, k, v, perm, probs, dout, dq, dk, dv, nh)
+    assert_close(dq, qr.grad, 6e-3, 'poolattn dq')
+    assert_close(dk, kr.grad, 6e-3, 'poolattn dk')
+    assert_close(dv, vr.grad, 6e-3, 'poolattn dv')
+
+
+def test_segment_sum_and_rows_mean(dev):
+    from merlot_reserve_amd import ops
+    H = 768
+    t0, t1, t2 = rnd((50, H), dev, seed=1), rnd((20, H), dev, seed=2), rnd((30, H), dev, seed=3)
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(0, 5, (40,), generator=g)
+    indptr = torch.zeros(41, dtype=torch.int32)
+    indptr[1:] = torch.cumsum(lens, 0)
+    idx = torch.randint(0, 100, (int(indptr[-1]),), generator=g).to(torch.int32)
+    dst = torch.full((40, H), float('nan'), dtype=BF16, device=dev)
+    ops.segment_sum([t0, t1, t2], indptr.to(dev), idx.to(dev), dst)
+    cat = torch.cat([t0, t1, t2]).float()
+    ref = torch.stack([cat[idx[indptr[i]:indptr[i + 1]].long()].sum(0) if lens[i] > 0 else torch.zeros(H, device=dev)
+                       for i in range(40)])
+    assert_close(dst, ref, 4e-3, 'segment_sum')
+    base = rnd((40, H), dev, seed=9)
+    dst2 = base.clone()
+    ops.segment_sum([t0, t1, t2], indptr.to(dev), idx.to(dev), dst2, scale=0.5, accumulate=True)
+    assert_close(dst2, base.float() + 0.5 * ref, 4e-3, 'segment_sum accumulate')
+    dst3 = torch.zeros(40, H, dtype=F32, device=dev)
+    ops.segment_sum([t0, t1, t2], indptr.to(dev), idx.to(dev), dst3)
+    assert relerr(dst3, ref) < 1e-6
+    rows = torch.randperm(50, generator=g)[:48].reshape(12, 4).to(torch.int32).to(dev)
+    m = torch.zeros(12, H, dtype=BF16, device=dev)
+    ops.rows_mean_fwd(t0, rows, m)
+    assert_close(m, t0.float()[rows.long()].mean(1), 4e-3, 'rows_mean')
+    d = rnd((12, H), dev, seed=5)
+    acc = t0.clone()
+    ops.rows_mean_bwd(d, rows, acc)
+    ref_acc = t0.float().clone()
+    ref_acc[rows.long().reshape(-1)] += (d.float() / 4).repeat_interleave(4, 0)
+    assert_close(acc, ref_acc, 4e-3, 'rows_mean bwd')
+
+
+def test_small_helpers(dev):
+    from merlot_reserve_amd import ops
+    src = rnd((90, 130), dev, seed=1)
+    dst = torch.full((90, 136), float('nan'), dtype=BF16, device=dev)
+    ops.pad_cols(src, dst)
+    assert torch.equal(dst[:, :130], src) and torch.all(dst[:, 130:] == 0)
+    vec = rnd((128,), dev, seed=2)
+    buf = torch.zeros(3 * 17, 128, dtype=BF16, device=dev)
+    ops.fill_rows(vec, buf, 3, 17, 0)
+    assert torch.equal(buf[0], vec) and torch.equal(buf[17], vec) and torch.equal(buf[34], vec) and torch.all(buf[1] == 0)
+    x = rnd((3 * 17, 128), dev, seed=3)
+    out = torch.zeros(128, dtype=BF16, device=dev)
+    ops.sum_rows_strided(x, 3, 17, 0, out)
+    assert_close(out, x.float()[[0, 17, 34]].sum(0), 4e-3, 'sum_rows_strided')
+    a, b = rnd((64, 128), dev, seed=4), rnd((64, 128), dev, seed=5)
+    y = torch.zeros_like(a)
+    ops.add_(a, b, y)
+    assert torch.equal(y, (a.float() + b.float()).to(BF16))
+    f = torch.randn(1000, device=dev)
+    o = torch.zeros(1000, dtype=BF16, device=dev)
+    ops.cast_f32_to_bf16(f, o)
+    assert torch.equal(o, f.to(BF16))
+
+
+@pytest.mark.parametrize('ls', [1.0, 5.0])
+def test_unit_norm_scale(dev, ls):
+    from merlot_reserve_amd import ops
+    rows, H = 77, 768
+    x = rnd((rows, H), dev, scale=3.0, seed=1)
+    lsb = torch.tensor([ls], dtype=BF16, device=dev)
+    y = torch.zeros_like(x)
+    inv = torch.zeros(rows, device=dev)
+    ops.unit_norm_scale_fwd(x, lsb, y, inv)
+    xr = x.float().clone().requires_grad_(True)
+    lr = lsb.float().clone().requires_grad_(True)
+    temp = torch.exp(torch.clamp(lr, max=math.log(100.0)) / 2)
+    ref = xr / torch.sqrt((xr * xr).sum(-1, keepdim=True) + 1e-5) * temp
+    assert_close(y, ref, 6e-3, 'unit_norm fwd')
+    dy = rnd((rows, H), dev, seed=2)
+    ref.backward(dy.float())
+    dx = torch.zeros_like(x)
+    dls = torch.zeros(1, device=dev)
+    ops.unit_norm_scale_bwd(x, lsb, inv, dy, dx, dls)
+    assert_close(dx, xr.grad, 6e-3, 'unit_norm dx')
+    if ls < math.log(100.0):
+        assert abs(dls.item() - lr.grad.item()) <= 2e-2 * abs(lr.grad.item()) + 1e-3
+    else:
+        assert dls.item() == 0.0
+
+
+def test_contrastive_lse(dev):
+    from merlot_reserve_amd import ops
+    L, V, off = 48, 192, 96
+    logits = torch.randn(L, V, device=dev) * 5
+    src = torch.randint(-1, 3, (L,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+    lr = logits.clone().requires_grad_(True)
+    lse = torch.logsumexp(lr, -1)
+    numer = lr[torch.arange(L), off + torch.arange(L)]
+    coef = 0.5 / L
+    ref_loss = coef * (lse - numer).sum()
+    ref_loss.backward()
+    loss = torch.zeros(1, device=dev)
+    diag = torch.zeros(6, device=dev)
+    work = logits.clone()
+    ops.contrastive_lse(work, off, coef, src, loss, diag)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item()) + 1e-6
+    assert relerr(work, lr.grad) < 1e-4
+    for i in range(3):
+        m = src == i
+        assert abs(diag[i].item() - (lse - numer)[m].sum().item()) < 1e-3 and diag[3 + i].item() == m.sum().item()
+
+
+def test_adam_bf16(dev):
+    from merlot_reserve_amd import ops
+    from oracle import ref_torch as R
+    n = 2048 * 3
+    g = torch.Generator().manual_seed(0)
+    master = torch.randn(n, generator=g) * 0.05
+    grad = (torch.randn(n, generator=g) * 1e-3).to(BF16)
+    grad[5] = float('nan'); grad[6] = float('inf'); grad[7] = -float('inf')
+    mu = (torch.randn(n, generator=g) * 1e-3).to(BF16)
+    nu = R.unsigned_bf16_encode((torch.rand(n, generator=g) * 1e-3).float())
+    nu[:10] = 0.0
+    flags = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    cfg = dict(learning_rate=4e-4, num_train_steps=750000, num_warmup_steps=3750, weight_decay_rate=0.1, beta_2=0.98,
+               eps=1e-6, use_bfloat16_adam=True)
+    count = 100
+    sched = float(R.lr_scale_linearwarmup_cosinedecay(count, 3750, 750000, 0.02))
+    d_master, d_mu, d_nu = master.to(dev), mu.to(dev), nu.to(dev)
+    work = torch.zeros(n, dtype=BF16, device=dev)
+    ops.adam_bf16_update(d_master, work, grad.to(dev), d_mu, d_nu, flags.to(dev), 0.9, 0.98, 1e-6, 0.1, sched, -4e-4)
+    gclean = torch.nan_to_num(grad.float(), nan=0.0, posinf=float(torch.finfo(BF16).max), neginf=-float(torch.finfo(BF16).max))
+    for blk in range(3):
+        sl = slice(blk * 2048, (blk + 1) * 2048)
+        p = master[sl].reshape(2048, 1) if flags[blk] else master[sl]          # ndim > 1 <=> decay
+        gg = gclean[sl].reshape(p.shape)
+        newp, nm, nv = R.adam_bf16_apply(p, gg, mu[sl].reshape(p.shape), nu[sl].reshape(p.shape), count, cfg)
+        finp = torch.isfinite(newp.reshape(-1))
+        assert relerr(d_master[sl].cpu()[finp], newp.reshape(-1)[finp]) < 1e-6, blk
+        finm = torch.isfinite(nm.reshape(-1).float())
+        assert (d_mu[sl].cpu().float()[finm] - nm.reshape(-1).float()[finm]).abs().max() <= 1e-2 * nm.float()[finm.reshape(nm.shape)].abs().max()
+        # the cube-root codec: decoded values must agree to codec precision
+        dec_got = R.unsigned_bf16_decode(d_nu[sl].cpu())
+        dec_ref = R.unsigned_bf16_decode(nv.reshape(-1))
+        fin = torch.isfinite(dec_ref)                      # +-inf grads (clamped to bf16 max) overflow g^2 in both
+        assert torch.equal(fin, torch.isfinite(dec_got))
+        assert relerr(dec_got[fin], dec_ref[fin]) < 2e-3
+        assert torch.equal(work[sl].cpu(), d_master[sl].cpu().to(BF16))
