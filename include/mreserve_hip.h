@@ -159,8 +159,11 @@ int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* log_scale, co
  */
 int mr_contrastive_lse(float* logits, int64_t ldl, int64_t L, int64_t V, int64_t own_off, float coef,
                        const int32_t* src, float* loss_out, float* diag, void* stream);
-/* bf16 copy of an fp32 matrix (dlogits -> GEMM operand) */
+/* bf16 copy of an fp32 array */
 int mr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* hi = bf16(x), lo = bf16(x - hi): 16-bit-mantissa split of dL/dlogits, so that the two bf16 MFMA GEMMs on hi and lo
+ * reproduce an fp32-operand product (the rows of dL/dlogits sum to zero; 8-bit rounding would break that cancellation) */
+int mr_split_f32_to_bf16_hilo(const float* src, void* hi, void* lo, int64_t n, void* stream);
 
 /* ---- optimizer: nan_to_num + bf16-state Adam + weight decay + schedule + apply (P:328, O:54-114, 180-195) ----
  * Flat buffers of n elements (n % 2048 == 0): master fp32 params, bf16 grads, bf16 mu, bf16 cube-coded nu.

@@ -1,0 +1,84 @@
+"""Configuration: the reference's two-level YAML schema (data / model / device / optimizer; pretrain/configs/*.yaml)
+plus a tiny configuration with the same structure for tests."""
+import copy
+import os
+
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_config(name_or_path):
+    path = name_or_path
+    if name_or_path in ('base', 'large'):
+        path = os.path.join(HERE, 'configs', f'{name_or_path}.yaml')
+    with open(path, 'r') as f:
+        return yaml.load(f, yaml.FullLoader)
+
+
+def tiny_config(hidden_size=128, grid=(4, 6), num_segments=4, seq_len=48, lang_seq_len=32):
+    """Same structure as base.yaml at toy sizes: 2 segment groups x 2 frames, 12 audio spans (3 targets per masked
+    stream), 12 text spans of which 8 are used, and a joint seq_len LONGER than text + vision so that the
+    padding branch of prepare_multimodal_inputs (modeling.py:731-739) is exercised."""
+    cfg = copy.deepcopy(load_config('base'))
+    d, m = cfg['data'], cfg['model']
+    d.update(num_segments=num_segments, num_segment_groups=2, num_audio_subsegments=3, seq_len=seq_len,
+             lang_seq_len=lang_seq_len, num_text_spans_to_include=8, text_span_budget=6, mask_rate=0.25)
+    m.update(hidden_size=hidden_size, joint_num_layers=2, audio_num_layers=2, vit_num_layers=2, span_num_layers=1,
+             output_grid=list(grid))
+    cfg['optimizer'].update(num_train_steps=1000, num_warmup_steps=10)
+    return cfg
+
+
+def resadapt_config(name, grid=(18, 32)):
+    """pretrain/train_fixres.py:78-90: higher-resolution grid, joint seq_len re-derived."""
+    cfg = load_config(name)
+    cfg['model']['output_grid'] = list(grid)
+    d = cfg['data']
+    per_group = d['num_segments'] // d['num_segment_groups']
+    d['seq_len'] = d['lang_seq_len'] + per_group * (grid[0] * grid[1]) // (cfg['model']['vit_pooling_ratio'] ** 2)
+    return cfg
+
+
+class Dims:
+    """Static shapes of one device's step, derived from config and B = records per device."""
+
+    def __init__(self, config, B):
+        d, m = config['data'], config['model']
+        self.B = B
+        self.H = m['hidden_size']
+        self.nh = self.H // 64
+        self.gh, self.gw = m['output_grid']
+        self.hw = self.gh * self.gw
+        self.pr = m['vit_pooling_ratio']
+        self.hw4 = self.hw // (self.pr ** 2)
+        self.pp3 = m['vit_patch_size'] ** 2 * 3
+        self.nseg = d['num_segments']
+        self.ngroups = d['num_segment_groups']
+        self.nspg = self.nseg // self.ngroups
+        self.nas = d['num_audio_subsegments']
+        self.nspans = self.nseg * self.nas
+        self.ntrg = int(self.nspans * d['mask_rate']) * d['num_text2audio_seqs']
+        self.lang = d['lang_seq_len']
+        self.seq_len = d['seq_len']
+        self.vis_len = self.nspg * self.hw4
+        assert self.lang + self.vis_len <= self.seq_len
+        self.a_raw = m['audio_seq_length']
+        self.a_patch = m['audio_patch_size']
+        self.a_len = self.a_raw // self.a_patch
+        self.a_tok = m['audio_token_length']
+        self.a_pool = self.a_raw // (self.a_tok * self.a_patch)
+        self.span_len = m['text_span_length']
+        self.n_inc = d['num_text_spans_to_include']
+        self.budget = d['text_span_budget']
+        self.ntext_spans = self.ntrg * 2 + self.budget        # rows of text_spans per record (62 for base)
+        self.Lv, self.La, self.Lj, self.Ls = m['vit_num_layers'], m['audio_num_layers'], m['joint_num_layers'], m['span_num_layers']
+        # sequence counts
+        self.Nv = B * self.nseg                # images
+        self.Sv = self.hw + 1
+        self.Na = B * self.nspans              # audio clips
+        self.Sa = self.a_len + 1
+        self.Nj = B * (2 * self.ngroups + 2)   # joint sequences: a2t(groups) + matching + random + t2a(groups)
+        self.Sj = self.seq_len
+        self.Ns = B * self.n_inc               # selected spans
+        self.Ss = self.span_len + 1

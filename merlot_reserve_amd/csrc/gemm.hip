@@ -246,9 +246,10 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "mr_gemm: empty problem M=%ld N=%ld K=%ld", (long)a->M, (long)a->N, (long)a->K);
     MR_CHECK_ARG(a->A && a->B && a->C, "mr_gemm: null operand");
     MR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mr_gemm: lda/ldb must be multiples of 8 (got %ld, %ld)", (long)a->lda, (long)a->ldb);
-    // the contiguous dimension of each operand is consumed in 16-byte chunks
-    MR_CHECK_ARG((a->transA ? a->M : a->K) % 8 == 0, "mr_gemm: contiguous dim of A must be a multiple of 8");
-    MR_CHECK_ARG((a->transB ? a->K : a->N) % 8 == 0, "mr_gemm: contiguous dim of B must be a multiple of 8");
+    // the contiguous dimension of each operand is consumed in 16-byte chunks: a ragged extent is allowed when the
+    // row is padded (with zeros, by the caller) up to the next multiple of 8 inside the leading dimension
+    MR_CHECK_ARG(((a->transA ? a->M : a->K) + 7) / 8 * 8 <= a->lda, "mr_gemm: A rows must be padded to a multiple of 8 elements");
+    MR_CHECK_ARG(((a->transB ? a->K : a->N) + 7) / 8 * 8 <= a->ldb, "mr_gemm: B rows must be padded to a multiple of 8 elements");
     MR_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
                  "mr_gemm: operands must be 16-byte aligned");
     if (a->c_dtype == MR_DT_BF16) {

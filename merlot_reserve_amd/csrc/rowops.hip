@@ -254,6 +254,17 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __re
         dst[i] = (__bf16)src[i];
 }
 
+// hi = bf16(x), lo = bf16(x - hi): a 16-bit-mantissa split, so that a bf16 MFMA GEMM run on hi and on lo reproduces an
+// fp32-operand product.  Used for dL/dlogits, whose rows sum to zero: rounding them to 8 bits breaks the cancellation.
+__global__ void split_hilo_kernel(const float* __restrict__ src, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = src[i];
+        const __bf16 h = (__bf16)x;
+        hi[i] = h;
+        lo[i] = (__bf16)(x - (float)h);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- unit-normalise * temperature
 constexpr float LN100 = 4.605170185988092f;
 
@@ -464,6 +475,16 @@ extern "C" int mr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void*
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src,
                        static_cast<__bf16*>(dst), n);
     MR_CHECK_LAUNCH("mr_cast_f32_to_bf16");
+    return MR_OK;
+}
+
+extern "C" int mr_split_f32_to_bf16_hilo(const float* src, void* hi, void* lo, int64_t n, void* stream) {
+    MR_CHECK_ARG(src && hi && lo && n > 0, "mr_split_f32_to_bf16_hilo: bad args");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_hilo_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), n);
+    MR_CHECK_LAUNCH("mr_split_f32_to_bf16_hilo");
     return MR_OK;
 }
 

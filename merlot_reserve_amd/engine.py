@@ -1,0 +1,408 @@
+"""Device program of one pretraining step: MerlotReservePretrainer.__call__ (pretrain/pretrain_model.py:38-259),
+loss_fn_given_preds (:262-303) and their hand-written backward, as a fixed sequence of C-ABI kernel launches over
+buffers allocated once (all shapes are static given config and B, so the whole step can be captured in a hipGraph).
+
+Data layout in HBM (bf16 unless noted; M = sequences x positions of a tower):
+  per tower and layer, kept for backward: X[l] layer input, ln1, qkv (post "rotary"), att, lse (fp32), xmid, ln2,
+  hpre, hact  = 16 H bf16 / token / layer;  LN statistics fp32.
+  joint input is ASSEMBLED by one index-driven gather from [token embedding | pooled audio | pooled vision] rows;
+  the [S,S] attention mask never exists (one int32 code per position); the "rotary" is a [positions, 32] fp32 table.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import Dims
+from .planner import VOCAB, build_plan, static_tables
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class TowerState:
+    """Saved activations of one TransformerEncoder (modeling.py:283-376) over M = nseq*S rows."""
+
+    def __init__(self, M, H, L, nseq, S, dev):
+        nh = H // 64
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        self.M, self.H, self.L, self.nseq, self.S = M, H, L, nseq, S
+        self.xin, self.xf = z(M, H), z(M, H)
+        self.X = z(L + 1, M, H)
+        self.ln1, self.ln2, self.xmid, self.att = z(L, M, H), z(L, M, H), z(L, M, H), z(L, M, H)
+        self.qkv = z(L, M, 3 * H)
+        self.hpre, self.hact = z(L, M, 4 * H), z(L, M, 4 * H)
+        self.lse = f(L, nseq, nh, S)
+        self.stats = f(2 * L + 2, 2, M)       # [ln index][mean|rstd][row]; index 0 = pre_ln, 1+2l / 2+2l = layer l, last = final
+
+
+class PretrainEngine:
+    def __init__(self, config, B, params, device, rank=0, world=1):
+        self.config, self.p, self.dev = config, params, torch.device(device)
+        self.d = d = Dims(config, B)
+        self.rank, self.world = rank, world
+        dev, H = self.dev, d.H
+        self.tables = {k: torch.as_tensor(v).to(dev) for k, v in static_tables(d).items()}
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+
+        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev)
+        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev)
+        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev)
+        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev)
+        Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
+
+        # attention pools
+        self.Gv, self.Ga = d.Nv * d.hw4, d.Na * d.a_tok
+        self.v_qin, self.v_q, self.v_po, self.imgs_seq = z(self.Gv, H), z(self.Gv, H), z(self.Gv, H), z(self.Gv, H)
+        self.v_k, self.v_v = z(self.tv.M, H), z(self.tv.M, H)
+        self.v_probs = f(self.Gv, d.nh, d.pr * d.pr)
+        self.v_cls = z(d.Nv, H)
+        self.a_pad_K = (d.a_patch * 65 + 7) // 8 * 8
+        self.a_in = z(d.Na * d.a_len, self.a_pad_K)
+        self.a_qin, self.a_q, self.a_po, self.audio_seq = z(self.Ga, H), z(self.Ga, H), z(self.Ga, H), z(self.Ga, H)
+        self.a_k, self.a_v = z(self.ta.M, H), z(self.ta.M, H)
+        self.a_probs = f(self.Ga, d.nh, d.a_pool)
+        self.a_cls = z(d.Na, H)
+        self.hj = z(self.tj.M, H)
+        self.s_cls = z(d.Ns, H)
+
+        # contrastive sections (rows per rank), order of the packed buffer E
+        n_i2a, n_t2a, n_ext, n_s2s = B * d.nseg, B * d.ntrg, B * (d.nspans - d.ntrg), B * d.n_inc
+        self.sec = {}
+        off = 0
+        for name, n in (('i2a_x', n_i2a), ('i2a_y', n_i2a), ('t2a_x', n_t2a), ('t2a_y', n_t2a), ('t2a_ye', n_ext),
+                        ('s2s_x', n_s2s), ('s2s_y', n_s2s)):
+            self.sec[name] = (off, n)
+            off += n
+        self.R = off
+        self.n_pool = n_i2a + n_t2a + n_s2s
+        self.Xpool = z(self.n_pool, H)
+        self.acls_g = z(d.Na, H)
+        self.E, self.dE = z(self.R, H), z(self.R, H)
+        self.inv_norm = f(self.R)
+        self.loss_acc = f(3)
+        self.diag = f(2, 6)
+        self.dls = f(3)
+        # objectives: (name, x section, y sections (gathered across ranks), scale index)
+        self.objectives = [('imgs_to_audio', 'i2a_x', ('i2a_y',), 0), ('text_to_audio', 't2a_x', ('t2a_y', 't2a_ye'), 1),
+                           ('stuff_to_span', 's2s_x', ('s2s_y',), 2)]
+        self.logit_bufs = {}
+        for name, xs, ys, _ in self.objectives:
+            nx = self.sec[xs][1]
+            ny = sum(self.sec[y][1] for y in ys)
+            ny0 = self.sec[ys[0]][1]
+            for direction, (L_, V_) in (('xy', (nx, world * ny)), ('yx', (ny0, world * nx))):
+                ldv = (V_ + 7) // 8 * 8
+                self.logit_bufs[(name, direction)] = (f(L_, ldv), z(L_, ldv), z(L_, ldv), V_)
+
+        # backward scratch
+        self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
+        self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
+        self.T_a = z(Mmax, H)
+        self.T_q = z(Mmax, 3 * H)
+        self.T_h = z(Mmax, 4 * H)
+        self.delta = f(max(t.nseq * t.S for t in (self.tv, self.ta, self.tj, self.ts)) * d.nh)
+        self.ln_ws = ops.layernorm_bwd_workspace(H, dev)
+        self.cs_ws = ops.colsum_workspace(4 * H, dev)
+        self.dXpool = z(self.n_pool, H)
+        self.d_hj = z(self.tj.M, H)
+        self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
+        self.d_audio_seq, self.d_imgs_seq = z(self.Ga, H), z(self.Gv, H)
+        self.d_pool_q, self.d_pool_po, self.d_pool_qin = z(max(self.Gv, self.Ga), H), z(max(self.Gv, self.Ga), H), z(max(self.Gv, self.Ga), H)
+        self.d_k, self.d_v = z(max(self.tv.M, self.ta.M), H), z(max(self.tv.M, self.ta.M), H)   # CLS rows stay zero
+        self.Dpatch = z(max(d.Nv * d.hw, d.Na * d.a_len), H)
+        # static gather lists: patch rows of a [nseq, S] grid without the CLS rows
+        self.unpad_v = self._unpad_csr(d.Nv, d.Sv)
+        self.unpad_a = self._unpad_csr(d.Na, d.Sa)
+
+        # device copies of the per-batch plan (fixed sizes where possible; index lists are padded to capacity)
+        self.plan_dev = {}
+        self._plan_caps = {}
+        self._plan_views = {}
+
+    def _unpad_csr(self, nseq, S):
+        rows = (np.arange(nseq)[:, None] * S + 1 + np.arange(S - 1)[None]).reshape(-1).astype(np.int32)
+        indptr = np.arange(len(rows) + 1, dtype=np.int32)
+        return torch.as_tensor(indptr).to(self.dev), torch.as_tensor(rows).to(self.dev)
+
+    # ------------------------------------------------------------------------------------------ plan upload
+    def set_plan(self, plan):
+        """Copy the host plan into persistent device buffers (same addresses every step: graph-capturable)."""
+        for k, v in plan.items():
+            if not isinstance(v, np.ndarray):
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(v))
+            cap = self._plan_caps.get(k, 0)
+            if k not in self.plan_dev or t.numel() > cap:
+                newcap = max(int(t.numel() * 1.25) + 16, 16)
+                self.plan_dev[k] = torch.zeros(newcap, dtype=t.dtype, device=self.dev)
+                self._plan_caps[k] = newcap
+            self.plan_dev[k][:t.numel()].copy_(t.reshape(-1), non_blocking=True)
+            self._plan_views[k] = self.plan_dev[k][:t.numel()].view(t.shape)
+        self.plan = plan
+
+    def _pl(self, k):
+        return self._plan_views[k]
+
+    # ------------------------------------------------------------------------------------------ encoder
+    def _names(self, prefix, l):
+        p = f'{prefix}/layer_{l:02d}'
+        return dict(g1=f'{p}/pre_attn_ln/scale', b1=f'{p}/pre_attn_ln/bias', wqkv=f'{p}/attention_layer/qkv/kernel',
+                    bqkv=f'{p}/attention_layer/qkv/bias', wo=f'{p}/attention_layer/attn_proj/kernel',
+                    g2=f'{p}/pre_mlp_ln/scale', b2=f'{p}/pre_mlp_ln/bias', w1=f'{p}/mlp_layer/intermediate/kernel',
+                    bb1=f'{p}/mlp_layer/intermediate/bias', w2=f'{p}/mlp_layer/out/kernel')
+
+    def encoder_forward(self, st, prefix, rot, code):
+        """TransformerEncoder body (modeling.py:360-366) on st.xin (CLS row already in place) -> st.xf."""
+        W, H, nh = self.p.w, st.H, st.H // 64
+        ops.layernorm_fwd(st.xin, W[f'{prefix}/pre_ln/scale'], W[f'{prefix}/pre_ln/bias'], st.X[0], st.stats[0, 0], st.stats[0, 1])
+        for l in range(st.L):
+            n = self._names(prefix, l)
+            x = st.X[l]
+            ops.layernorm_fwd(x, W[n['g1']], W[n['b1']], st.ln1[l], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1])
+            ops.gemm(st.ln1[l], W[n['wqkv']], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
+            ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
+            ops.gemm(st.att[l], W[n['wo']], st.xmid[l], residual=x)
+            ops.layernorm_fwd(st.xmid[l], W[n['g2']], W[n['b2']], st.ln2[l], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1])
+            ops.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=st.hpre[l])
+            ops.gemm(st.hact[l], W[n['w2']], st.X[l + 1], residual=st.xmid[l])
+        k = 2 * st.L + 1
+        ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
+
+    def encoder_backward(self, st, prefix, rot, code, D):
+        """D [M,H]: gradient wrt st.xf on entry, wrt st.xin on exit.  Weight gradients go to the flat grad buffer."""
+        W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
+        T_a, T_q, T_h = self.T_a[:M], self.T_q[:M], self.T_h[:M]
+        k = 2 * st.L + 1
+        ops.layernorm_bwd(D, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], D,
+                          G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.ln_ws)
+        for l in reversed(range(st.L)):
+            n = self._names(prefix, l)
+            ops.gemm(D, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                       # d hpre
+            ops.gemm(st.hact[l], D, G[n['w2']], transA=True)
+            ops.colsum(T_h, G[n['bb1']], self.cs_ws)
+            ops.gemm(st.ln2[l], T_h, G[n['w1']], transA=True)
+            ops.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
+            ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], D,
+                              G[n['g2']], G[n['b2']], self.ln_ws, add_to_dx=True)            # D = d xmid
+            ops.gemm(D, W[n['wo']], T_a, transB=True)                                      # d att
+            ops.gemm(st.att[l], D, G[n['wo']], transA=True)
+            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.delta, T_q, rot, st.nseq, st.S, nh)
+            ops.colsum(T_q, G[n['bqkv']], self.cs_ws)
+            ops.gemm(st.ln1[l], T_q, G[n['wqkv']], transA=True)
+            ops.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
+            ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], D,
+                              G[n['g1']], G[n['b1']], self.ln_ws, add_to_dx=True)            # D = d X[l]
+        ops.layernorm_bwd(D, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], D,
+                          G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.ln_ws)
+
+    # ------------------------------------------------------------------------------------------ CLS tower head + pool
+    def _cls_view(self, t, nseq, S):
+        return t.view(nseq, S * t.shape[1])[:, :t.shape[1]]
+
+    def _tower_with_pool_forward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, out_seq, out_cls):
+        W, nh = self.p.w, st.H // 64
+        ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
+        self.encoder_forward(st, prefix_t, rot, None)
+        ops.gemm(self._cls_view(st.xf, st.nseq, st.S), W[f'{prefix_t}/cls_proj/kernel'], out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
+        ops.rows_mean_fwd(st.xf, pool_rows, qin)
+        ops.gemm(qin, W[f'{prefix_pool}/query/kernel'], q, bias=W[f'{prefix_pool}/query/bias'])
+        ops.gemm(st.xf, W[f'{prefix_pool}/key/kernel'], k, bias=W[f'{prefix_pool}/key/bias'])
+        ops.gemm(st.xf, W[f'{prefix_pool}/value/kernel'], v, bias=W[f'{prefix_pool}/value/bias'])
+        ops.poolattn_fwd(q, k, v, pool_rows, po, probs, nh)
+        ops.gemm(po, W[f'{prefix_pool}/out/kernel'], out_seq, bias=W[f'{prefix_pool}/out/bias'])
+
+    def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D):
+        """d_seq: grad wrt the pooled sequence output; d_cls: grad wrt the cls output.  Returns D = grad wrt st.xin."""
+        W, G, nh, M = self.p.w, self.p.g, st.H // 64, st.M
+        Gn = qin.shape[0]
+        d_po, d_q, d_qin = self.d_pool_po[:Gn], self.d_pool_q[:Gn], self.d_pool_qin[:Gn]
+        d_k, d_v = self.d_k[:M], self.d_v[:M]
+        ops.colsum(d_seq, G[f'{prefix_pool}/out/bias'], self.cs_ws)
+        ops.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
+        ops.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
+        ops.poolattn_bwd(q, k, v, pool_rows, probs, d_po, d_q, d_k, d_v, nh)
+        ops.colsum(d_q, G[f'{prefix_pool}/query/bias'], self.cs_ws)
+        ops.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
+        ops.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
+        ops.colsum(d_k, G[f'{prefix_pool}/key/bias'], self.cs_ws)
+        ops.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
+        ops.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
+        ops.colsum(d_v, G[f'{prefix_pool}/value/bias'], self.cs_ws)
+        ops.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
+        ops.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
+        ops.rows_mean_bwd(d_qin, pool_rows, D)
+        # cls head
+        cls_in = self._cls_view(st.xf, st.nseq, st.S)
+        ops.colsum(d_cls, G[f'{prefix_t}/cls_proj/bias'], self.cs_ws)
+        ops.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
+        Dc = self._cls_view(D, st.nseq, st.S)
+        ops.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
+        self.encoder_backward(st, prefix_t, rot, None, D)
+        ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
+        return D
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, batch, plan=None, draws=None):
+        """batch: dict of synthetic.make_batch layout (images / audio_clips on device, integer streams numpy)."""
+        d, W, H = self.d, self.p.w, self.d.H
+        if plan is None:
+            from .synthetic import make_draws
+            splits, z = draws if draws is not None else make_draws(self.config, d.B, seed=int(batch['audio2text/text_ptr'].astype(np.uint32).sum() % (2 ** 31)))
+            plan = build_plan(batch, d, splits, z)
+        self.set_plan(plan)
+        tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
+
+        # vision tower (modeling.py:379-430)
+        images = self._images2d = batch['images'].reshape(d.Nv * d.hw, d.pp3)
+        ops.gemm(images, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
+                                      self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
+                                      self.v_probs, self.imgs_seq, self.v_cls)
+        # audio tower (modeling.py:433-476): the stride-2 conv is a GEMM over 2 consecutive hops = 130 inputs
+        audio = batch['audio_clips'].reshape(d.Na * d.a_len, d.a_patch * 65)
+        ops.pad_cols(audio, self.a_in)
+        a_view = self.a_in[:, :d.a_patch * 65]
+        ops.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
+        self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
+                                      self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
+                                      self.a_probs, self.audio_seq, self.a_cls)
+        # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
+        emb = W['token_encoder/Embed_0/embedding']
+        ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
+        self.encoder_forward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'))
+        ops.gemm(tj.xf, W['head/kernel'], self.hj, bias=W['head/bias'])
+        ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)
+        ops.segment_sum([self.a_cls], self._pl('acls_indptr'), self._pl('acls_idx'), self.acls_g)
+        # span tower on the chosen spans (modeling.py:479-504)
+        ops.segment_sum([emb], self._pl('span_gather_indptr'), self._pl('span_gather_idx'), ts.xin)
+        ops.fill_rows(W['span_encoder/transformer/cls'], ts.xin, ts.nseq, ts.S, 0)
+        self.encoder_forward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'))
+        ops.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
+                 bias=W['span_encoder/transformer/cls_proj/bias'])
+        # unit-normalise * temperature into the packed buffer E (pretrain_model.py:239-257)
+        for src, names, si in self._norm_sections():
+            o, n = self.sec[names[0]][0], sum(self.sec[k][1] for k in names)
+            ops.unit_norm_scale_fwd(src, W['contrastive_scales'][si:si + 1], self.E[o:o + n], self.inv_norm[o:o + n])
+        return self.E
+
+    def _norm_sections(self):
+        n1, n2 = self.sec['i2a_x'][1], self.sec['t2a_x'][1]
+        return [(self.Xpool[:n1], ('i2a_x',), 0), (self.v_cls, ('i2a_y',), 0),
+                (self.Xpool[n1:n1 + n2], ('t2a_x',), 1), (self.acls_g, ('t2a_y', 't2a_ye'), 1),
+                (self.Xpool[n1 + n2:], ('s2s_x',), 2), (self.s_cls, ('s2s_y',), 2)]
+
+    def outputs(self):
+        """The reference's output dict (pretrain_model.py:240-244 after :246-257), views of E."""
+        s = lambda k: self.E[self.sec[k][0]:self.sec[k][0] + self.sec[k][1]]
+        return {'imgs_to_audio': {'x': s('i2a_x'), 'y': s('i2a_y')},
+                'text_to_audio': {'x': s('t2a_x'), 'y': s('t2a_y'), 'y_extra': s('t2a_ye')},
+                'stuff_to_span': {'x': s('s2s_x'), 'y': s('s2s_y'), '_sources': torch.as_tensor(self.plan['t2sp_src'])}}
+
+    # ------------------------------------------------------------------------------------------ loss (+ its backward)
+    def loss_and_grad_outputs(self, gather_fn=None, scatter_fn=None):
+        """loss_fn_given_preds (pretrain_model.py:262-303) for this rank and dL/dE.
+        gather_fn(E) -> [world, R, H] rank-major all-gather; scatter_fn(dE_all [world,R,H]) -> [R,H] reduce-scatter(sum).
+        Returns the fp32 device vector loss_acc[3] (per-objective losses of this rank)."""
+        world, rank, H = self.world, self.rank, self.d.H
+        E_all = self.E[None] if gather_fn is None else gather_fn(self.E)
+        dE_all = torch.zeros_like(E_all) if world > 1 else self.dE[None]
+        self.dE.zero_()
+        self.loss_acc.zero_()
+        self.diag.zero_()
+        for oi, (name, xs, ys, _) in enumerate(self.objectives):
+            xo, nx = self.sec[xs]
+            yo, ny = self.sec[ys[0]][0], sum(self.sec[k][1] for k in ys)
+            ny0 = self.sec[ys[0]][1]
+            x_loc = self.E[xo:xo + nx]
+            y_loc0 = self.E[yo:yo + ny0]
+            for di, direction in enumerate(('xy', 'yx')):
+                logits, dl_hi, dl_lo, V = self.logit_bufs[(name, direction)]
+                if direction == 'xy':
+                    q_loc, q_off, k_off, nk = x_loc, xo, yo, ny
+                else:
+                    q_loc, q_off, k_off, nk = y_loc0, yo, xo, nx
+                Lq = q_loc.shape[0]
+                for r in range(world):                                         # rank-major columns (:290)
+                    ops.gemm(q_loc, E_all[r, k_off:k_off + nk], logits[:, r * nk:(r + 1) * nk], transB=True)
+                src = self._pl('t2sp_src') if name == 'stuff_to_span' else None
+                ops.contrastive_lse(logits[:, :V], rank * nk, 0.5 / Lq, src, self.loss_acc[oi:oi + 1],
+                                    self.diag[di] if src is not None else None)
+                ops.split_hilo(logits, dl_hi, dl_lo)                           # rows of dlogits sum to 0: keep 16 bits
+                dq = self.dE[q_off:q_off + Lq]
+                for r in range(world):
+                    keys = E_all[r, k_off:k_off + nk]
+                    dk = dE_all[r, k_off:k_off + nk] if world > 1 else self.dE[k_off:k_off + nk]
+                    for dlb in (dl_lo, dl_hi):
+                        blk = dlb[:, r * nk:(r + 1) * nk]
+                        ops.gemm(blk, keys, dq, residual=dq)                   # d(query side) += dlogits . keys
+                        ops.gemm(blk, q_loc, dk, transA=True, residual=dk)     # d(key side)   += dlogits^T . queries
+        if world > 1:
+            self.dE.add_(scatter_fn(dE_all))
+        return self.loss_acc
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self):
+        """Backward of forward() given self.dE; fills self.p.grad (bf16, per rank, un-reduced)."""
+        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
+        self.dls.zero_()
+        n1, n2 = self.sec['i2a_x'][1], self.sec['t2a_x'][1]
+        dsts = [self.dXpool[:n1], self.d_v_cls, self.dXpool[n1:n1 + n2], self.d_acls_g, self.dXpool[n1 + n2:], self.d_s_cls]
+        for (src, names, si), dst in zip(self._norm_sections(), dsts):
+            o, n = self.sec[names[0]][0], sum(self.sec[k][1] for k in names)
+            ops.unit_norm_scale_bwd(src, W['contrastive_scales'][si:si + 1], self.inv_norm[o:o + n], self.dE[o:o + n], dst,
+                                    self.dls[si:si + 1])
+        ops.cast_f32_to_bf16(self.dls, G['contrastive_scales'])
+
+        # span tower (only its cls output is used: gradient enters at the CLS rows)
+        Ds = self.Ds
+        Ds.zero_()
+        cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
+        ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cs_ws)
+        ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
+        ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
+        self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
+        ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
+
+        # joint tower
+        ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
+        ops.colsum(self.d_hj, G['head/bias'], self.cs_ws)
+        ops.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
+        Dj = self.Dj
+        ops.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
+        self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
+        # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
+        ops.segment_sum([Dj, self.Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
+        ops.segment_sum([Dj], self._pl('audT_indptr'), self._pl('audT_idx'), self.d_audio_seq)
+        ops.segment_sum([Dj], self._pl('visT_indptr'), self._pl('visT_idx'), self.d_imgs_seq)
+        ops.segment_sum([self.d_acls_g], self._pl('aclsT_indptr'), self._pl('aclsT_idx'), self.d_a_cls)
+
+        # audio tower
+        Da = self._tower_with_pool_backward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
+                                            self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
+                                            self.a_probs, self.d_audio_seq, self.d_a_cls, self.Da)
+        Dp = self.Dpatch[:d.Na * d.a_len]
+        ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
+        ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cs_ws)
+        ops.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
+        # vision tower
+        Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
+                                            self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
+                                            self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv)
+        Dp = self.Dpatch[:d.Nv * d.hw]
+        ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
+        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cs_ws)
+        ops.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
+
+    def loss_info(self):
+        """Host dict like the reference's loss_info (pretrain_model.py:263-303) from the device accumulators."""
+        la = self.loss_acc.tolist()
+        dg = self.diag.tolist()
+        info = {k: la[i] for i, (k, *_r) in enumerate(self.objectives)}
+        for i, t in enumerate(['text2audio', 'audio2text', 'random_text']):
+            info[f'_stuff_to_span_from_{t}'] = sum(dg[di][i] / (dg[di][3 + i] + 1e-5) / 2.0 for di in range(2))
+        info['loss'] = sum(la)
+        return info

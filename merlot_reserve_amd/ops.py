@@ -201,6 +201,11 @@ def cast_f32_to_bf16(src, dst):
     return dst
 
 
+def split_hilo(src, hi, lo):
+    check(_lib.load().mr_split_f32_to_bf16_hilo(src.data_ptr(), hi.data_ptr(), lo.data_ptr(), src.numel(), _stream()),
+          'mr_split_f32_to_bf16_hilo')
+
+
 def adam_bf16_update(master, work, grad, mu, nu, decay_flags, b1, b2, eps, weight_decay, sched, neg_lr, bc1=1.0, bc2=1.0):
     check(_lib.load().mr_adam_bf16_update(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
                                           decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay, sched, neg_lr,

@@ -1,0 +1,128 @@
+"""End-to-end parity of the HIP pretraining step against the oracle (fp32 restatement of the reference) on the tiny
+configuration: forward outputs, loss, and every parameter gradient.
+
+Tolerances (stated, bf16 compute vs fp32 oracle; the oracle reads the SAME bf16-rounded weights and inputs):
+  forward x / y tensors: relative L2 <= 2e-2   (activations are stored in bf16: 2^-8 per rounding, a few dozen roundings)
+  loss: |d| <= 2e-2 * |loss|
+  gradients: relative L2 <= 8e-2 and cosine >= 0.995 per leaf (bf16 activations, bf16 gradient storage)
+Integer decisions (selections, pooling targets) are bit-exact by construction: tests/test_planner_vs_oracle.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import oracle_batch, oracle_draws, relerr, tiny_setup, tree_to
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, B=2, seed=3, hidden_size=128):
+    from merlot_reserve_amd.config import Dims
+    from merlot_reserve_amd.engine import PretrainEngine
+    from merlot_reserve_amd.planner import build_plan
+    cfg, store, batch, splits, z = tiny_setup(B=B, seed=seed, device=dev, hidden_size=hidden_size)
+    eng = PretrainEngine(cfg, B, store, dev)
+    plan = build_plan(batch, Dims(cfg, B), splits, z)
+    eng.forward(batch, plan=plan)
+    torch.cuda.synchronize()
+    return cfg, store, eng, batch, splits, z
+
+
+SECTIONS = (('imgs_to_audio', 'x', 'i2a_x'), ('imgs_to_audio', 'y', 'i2a_y'), ('text_to_audio', 'x', 't2a_x'),
+            ('text_to_audio', 'y', 't2a_y'), ('text_to_audio', 'y_extra', 't2a_ye'), ('stuff_to_span', 'x', 's2s_x'),
+            ('stuff_to_span', 'y', 's2s_y'))
+
+
+def test_tiny_forward_and_loss_parity(dev):
+    from oracle import ref_torch as R
+    cfg, store, eng, batch, splits, z = _setup(dev)
+    eng.loss_and_grad_outputs()
+    torch.cuda.synchronize()
+    params = tree_to(store.work_tree(), torch.float32)
+    osp, oz = oracle_draws(splits, z)
+    with torch.no_grad():
+        preds = R.pretrain_forward(params, cfg, oracle_batch(batch), osp, oz)
+        loss, info = R.loss_fn_given_preds([preds])
+    outs = eng.outputs()
+    for k, k2, _ in SECTIONS:
+        e = relerr(outs[k][k2], preds[k][k2])
+        print(f'forward {k}/{k2}: rel-L2 {e:.3e}')
+        assert e <= 2e-2, f'{k}/{k2}: rel err {e:.3e}'
+    li = eng.loss_info()
+    print('loss', li['loss'], float(loss))
+    for k in ('imgs_to_audio', 'text_to_audio', 'stuff_to_span'):
+        assert abs(li[k] - float(info[k])) <= 2e-2 * abs(float(info[k])), (k, li[k], float(info[k]))
+    assert abs(li['loss'] - float(loss)) <= 2e-2 * abs(float(loss))
+    for t in ('text2audio', 'audio2text', 'random_text'):
+        k = f'_stuff_to_span_from_{t}'
+        assert abs(li[k] - float(info[k])) <= 3e-2 * abs(float(info[k])) + 1e-3, (k, li[k], float(info[k]))
+
+
+def test_loss_gradient_wrt_outputs(dev):
+    """loss_fn_given_preds and dL/d(x, y) on well-conditioned embeddings (a random-init tower emits near-identical
+    rows, for which the contrastive gradient is a difference of near-equal vectors: ill-conditioned in bf16 for the
+    reference too).  E holds bf16 values, the oracle reads the same values: tolerance 1e-2 (bf16 storage of dE)."""
+    from oracle import ref_torch as R
+    cfg, store, eng, batch, splits, z = _setup(dev)
+    g = torch.Generator().manual_seed(0)
+    E = torch.randn(eng.R, eng.d.H, generator=g)
+    E = (E / E.norm(dim=-1, keepdim=True) * 1.6).to(torch.bfloat16)
+    eng.E.copy_(E.to(dev))
+    eng.loss_and_grad_outputs()
+    torch.cuda.synchronize()
+    Ef = E.float().requires_grad_(True)
+    preds = {}
+    for k, k2, name in SECTIONS:
+        o, n = eng.sec[name]
+        preds.setdefault(k, {})[k2] = Ef[o:o + n]
+    preds['stuff_to_span']['_sources'] = torch.as_tensor(eng.plan['t2sp_src']).long()
+    loss, info = R.loss_fn_given_preds([preds])
+    loss.backward()
+    li = eng.loss_info()
+    assert abs(li['loss'] - float(loss)) <= 1e-3 * abs(float(loss)), (li['loss'], float(loss))
+    for k, k2, name in SECTIONS:
+        o, n = eng.sec[name]
+        e = relerr(eng.dE[o:o + n], Ef.grad[o:o + n])
+        print(f'dE {name}: {e:.3e}')
+        assert e <= 1e-2, (name, e)
+
+
+def test_tiny_backward_parity(dev):
+    """Backward of the whole forward graph for a GIVEN upstream gradient dE (so the check is independent of the
+    conditioning of the loss at random init): every parameter gradient against autograd of the oracle."""
+    from oracle import ref_torch as R
+    cfg, store, eng, batch, splits, z = _setup(dev)
+    g = torch.Generator().manual_seed(1)
+    dE = (torch.randn(eng.R, eng.d.H, generator=g) * 1e-2).to(torch.bfloat16)
+    eng.dE.copy_(dE.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    params = tree_to(store.work_tree(), torch.float32)
+    params = R.tree_map(lambda t: t.clone().requires_grad_(True), params)
+    osp, oz = oracle_draws(splits, z)
+    preds = R.pretrain_forward(params, cfg, oracle_batch(batch), osp, oz)
+    total = 0.0
+    for k, k2, name in SECTIONS:
+        o, n = eng.sec[name]
+        total = total + (preds[k][k2] * dE[o:o + n].float()).sum()
+    total.backward()
+    grads = R.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), params)
+    gt = store.grad_tree()
+    gmax = max(float(g.norm()) for _, g in R.tree_leaves(grads))
+    worst = []
+    for name, g in R.tree_leaves(grads):
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn = float(g.norm())
+        err = float((mine.double() - g.double()).norm())
+        cos = float((mine.double().flatten() @ g.double().flatten()) / (mine.double().norm() * g.double().norm() + 1e-30))
+        worst.append((err / (gn + 1e-30), cos, name, err, gn))
+    worst.sort(key=lambda t: -t[3] / (8e-2 * t[4] + 1.5e-2 * gmax))
+    msg = '\n'.join(f'rel={e:.3e} cos={c:.5f} abs={a:.3e} |g|={n2:.3e} {n}' for e, c, n, a, n2 in worst[:30])
+    print('gmax', gmax)
+    print('worst gradient leaves:\n' + msg)
+    # |mine - ref| <= 8e-2 |ref| + 1.5e-2 max_leaf|ref|  (second term: bf16 noise floor of near-cancelling sums);
+    # direction checked on every leaf that carries a non-negligible gradient
+    bad = [(e, c, n) for e, c, n, a, n2 in worst if a > 8e-2 * n2 + 1.5e-2 * gmax or (n2 > 5e-2 * gmax and c < 0.995)]
+    assert not bad, 'gradient parity failures:\n' + '\n'.join(f'{e:.3e} cos={c:.5f} {n}' for e, c, n in bad)
