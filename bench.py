@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Benchmark of the MERLOT Reserve pretraining step on MI355X (contract: see the task's bench.py section).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model base|large] [--records-per-gpu B]
+
+One "step" = one full pretraining step (plan + forward + contrastive loss + backward + gradient all-reduce + fused
+bf16-Adam update) on B records (= 2B video-segment groups of 8 frames) per GPU of synthetic data already resident in
+HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU, RCCL ("nccl") over xGMI, weak scaling.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of its
+launches / their HIP-event durations, measured in an instrumented pass of the same steps right after the timed region;
+`cpu_baseline` times the oracle (a CPU port of the reference's step) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_flops_per_record(config, train=True):
+    """2 FLOP per MAC, matmuls and attention only, train = 3 x forward."""
+    from merlot_reserve_amd.config import Dims
+    d = Dims(config, 1)
+    H = d.H
+
+    def enc(n, S, L):
+        return n * S * L * (24 * H * H + 4 * S * H)
+    fwd = enc(d.nseg, d.Sv, d.Lv) + enc(d.nspans, d.Sa, d.La) + enc(2 * d.ngroups + 2, d.Sj, d.Lj) + enc(d.n_inc, d.Ss, d.Ls)
+    fwd += d.nseg * d.hw * 2 * d.pp3 * H + d.nspans * d.a_len * 2 * 130 * H
+    fwd += d.nseg * d.hw4 * 20 * H * H + d.nspans * d.a_tok * 24 * H * H
+    fwd += (d.nseg + d.nspans + d.n_inc) * 2 * H * H + (2 * d.ngroups + 2) * d.Sj * 2 * H * H
+    return fwd * (3 if train else 1)
+
+
+def cpu_baseline(config, seconds_hint=20):
+    """The oracle (torch CPU restatement of the reference's step, fp32) on ONE record: forward + backward."""
+    import torch
+    from oracle import ref_torch as R
+    from merlot_reserve_amd.params import ParamStore
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from tests.util import oracle_batch, oracle_draws
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    store = ParamStore(config, 'cpu', seed=0, with_optimizer=False)
+    params = store.master_tree()
+    batch = make_batch(config, 1, seed=1234, device='cpu', float_dtype=torch.float32)
+    splits, z = make_draws(config, 1, seed=1234)
+    osp, oz = oracle_draws(splits, z)
+    ob = oracle_batch(batch)
+    t0 = time.time()
+    R.loss_and_grads(params, config, ob, osp, oz)
+    dt = time.time() - t0
+    return {'value': 2.0 / dt, 'unit': 'video-segments/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 record (2 video-segment groups x 8 frames) forward+backward, fp32 torch-CPU oracle, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--model', default='base')
+    ap.add_argument('--records-per-gpu', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from merlot_reserve_amd import ops
+    from merlot_reserve_amd.config import load_config
+    from merlot_reserve_amd.synthetic import make_batch
+    from merlot_reserve_amd.trainer import Trainer
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    config = load_config(args.model)
+    B = args.records_per_gpu
+    trainer = Trainer(config, B, dev, rank=rank, world=world, seed=0)
+    batches = [make_batch(config, B, seed=1234 + rank + 1000 * i, device=dev) for i in range(2)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(nsteps):
+        plan = trainer.plan(batches[0])
+        for i in range(nsteps):
+            b = batches[i % 2]
+            trainer.train_step(b, plan=plan)
+            if i + 1 < nsteps:
+                plan = trainer.plan(batches[(i + 1) % 2])     # host-side planning overlaps the GPU's step
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = trainer.loss_info()['loss']
+
+    roof = None
+    if not args.no_roofline:
+        ops.GEMM_PROFILE = []
+        run(min(args.steps, 3))
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ops.GEMM_PROFILE)
+        fl = sum(f for _, _, f in ops.GEMM_PROFILE)
+        n = len(ops.GEMM_PROFILE)
+        ops.GEMM_PROFILE = None
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': ach, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': None, 'launches': n,
+                'avg_launch_us': ms * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
+
+    if rank == 0:
+        vseg = 2 * B * world * args.steps
+        step_flops = algorithmic_flops_per_record(config) * B
+        out = {
+            'metric': 'video-segments/sec (whole node) pretrain step', 'value': vseg / dt, 'unit': 'video-segments/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'{args.model} pretrain step, {B} records (= {2 * B} video-segment groups x 8 frames '
+                                   f'{config["model"]["output_grid"][0] * 16}x{config["model"]["output_grid"][1] * 16} + audio + text) per GPU',
+                       'records_per_gpu': B, 'parallelism': f'dp{world}', 'final_loss': loss,
+                       'step_tflop_algorithmic': step_flops / 1e12,
+                       'step_mfma_frac': step_flops / (dt / args.steps) / MFMA_BF16_PEAK},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(config)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -56,6 +56,8 @@ const char* mr_last_error(void);
  * Output row map: row m is stored at row (m / out_grp) * out_grp_stride + out_grp_off + m % out_grp
  * when out_grp > 0 (used to leave room for the CLS row, M:311-320), else at row m.
  * c_dtype = MR_DT_F32 supports bias only (used for the contrastive logits, P:293).
+ * With a workspace and no epilogue beyond bias, problems with few 128x128 output tiles and a long K (every weight
+ * gradient: K = tokens) are split along K over gridDim.y and summed by a second kernel (fixed order: deterministic).
  */
 typedef struct {
     int64_t M, N, K;
@@ -69,6 +71,7 @@ typedef struct {
     const void* residual; int64_t ldr;
     const void* aux; int64_t ldaux;
     int64_t out_grp, out_grp_stride, out_grp_off;
+    void* workspace; int64_t workspace_bytes; /* optional fp32 scratch: enables split-K for few-tile / long-K problems */
 } mr_gemm_args;
 int mr_gemm(const mr_gemm_args* args, void* stream);
 

@@ -20,7 +20,8 @@ class GemmArgs(C.Structure):
                 ('act', i32),
                 ('residual', vp), ('ldr', i64),
                 ('aux', vp), ('ldaux', i64),
-                ('out_grp', i64), ('out_grp_stride', i64), ('out_grp_off', i64)]
+                ('out_grp', i64), ('out_grp_stride', i64), ('out_grp_off', i64),
+                ('workspace', vp), ('workspace_bytes', i64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/mreserve_hip.h
@@ -69,6 +70,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MreserveHipError(f'{LIB_PATH} not found: the HIP extension is not built '
                                f'(python -m merlot_reserve_amd.build). There is no CPU fallback.')
+    # torch ships its own HIP runtime: it must be in the process BEFORE this library resolves libamdhip64, otherwise two
+    # runtimes coexist and launches from here see no device
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported

@@ -84,8 +84,10 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int own0, int kk
     }
 }
 
+// gridDim.y = number of K splits: split s handles k-tiles [s*kt_per_split, min((s+1)*kt_per_split, nk)) and, when
+// gridDim.y > 1, stores its fp32 partial tile to p.workspace[s][M][N] (summed by splitk_reduce_kernel).
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p, int tiles_n, int kt_per_split) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * TILE_ELEMS];
     __bf16* As = smem;
     __bf16* Bs = smem + TILE_ELEMS;
@@ -113,14 +115,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[4], rb[4];
-    const int64_t nk = (p.K + BK - 1) / BK;
-    load_tile<TA>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
-    load_tile<!TB>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    const int64_t nk_all = (p.K + BK - 1) / BK;
+    const int64_t kt0 = (int64_t)blockIdx.y * kt_per_split;
+    const int64_t nk = (kt0 + kt_per_split < nk_all) ? kt0 + kt_per_split : nk_all;
+    load_tile<TA>(A, p.lda, m0, kt0 * BK, p.M, p.K, tid, ra);
+    load_tile<!TB>(B, p.ldb, n0, kt0 * BK, p.N, p.K, tid, rb);
     store_tile<TA>(As, tid, ra);
     store_tile<!TB>(Bs, tid, rb);
     __syncthreads();
 
-    for (int64_t kt = 0; kt < nk; ++kt) {
+    for (int64_t kt = kt0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {
             load_tile<TA>(A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid, ra);
@@ -145,6 +149,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
             store_tile<!TB>(Bs, tid, rb);
             __syncthreads();
         }
+    }
+
+    if (gridDim.y > 1) {   // split-K partial: raw fp32 accumulators
+        float* Wp = static_cast<float*>(p.workspace) + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                    if (m < p.M && n < p.N) Wp[m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
     }
 
     // ---------------- epilogue, phase 1: MFMA layout (col = lane & 15, row = 4*(lane >> 4) + r) ----------------
@@ -239,6 +259,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
     }
 }
 
+// C[m,n] = sum_s partial[s][m][n] (+ bias[n]); bf16 or fp32 output; N % 4 == 0
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t M, int64_t N, const __bf16* __restrict__ bias,
+                                     void* __restrict__ C, int64_t ldc, int c_dtype) {
+    const int64_t MN = M * N;
+    for (int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < MN; i4 += (int64_t)gridDim.x * blockDim.x * 4) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + i4);
+        for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + (int64_t)s * MN + i4);
+        const int64_t m = i4 / N, n = i4 % N;
+        if (bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (float)bias[n + e];
+        }
+        if (c_dtype == MR_DT_F32) {
+            *reinterpret_cast<f32x4*>(static_cast<float*>(C) + m * ldc + n) = acc;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[e];
+            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(C) + m * ldc + n) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
@@ -264,12 +307,33 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
     const int64_t tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
     MR_CHECK_ARG(tm * tn < (1LL << 30), "mr_gemm: grid too large");
-    dim3 grid((unsigned)(tm * tn)), block(256);
+    // split-K: problems with few output tiles and a long contraction (every wgrad) cannot fill 256 CUs otherwise
+    const int64_t nk = (a->K + BK - 1) / BK;
+    int64_t splits = 1;
+    const bool plain = !a->rot_tab && !a->c2 && a->act == MR_ACT_NONE && !a->residual && !a->aux && a->out_grp == 0;
+    if (a->workspace && plain && a->N % 4 == 0 && tm * tn < 384 && nk >= 16) {
+        splits = (768 + tm * tn - 1) / (tm * tn);
+        if (splits > nk / 8) splits = nk / 8;
+        if (splits > 32) splits = 32;
+        const int64_t fit = a->workspace_bytes / (a->M * a->N * (int64_t)sizeof(float));
+        if (splits > fit) splits = fit;
+        if (splits < 2) splits = 1;
+    }
+    int64_t kt_per_split = (nk + splits - 1) / splits;
+    splits = (nk + kt_per_split - 1) / kt_per_split;
+    dim3 grid((unsigned)(tm * tn), (unsigned)splits), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, *a, (int)tn);
-    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, *a, (int)tn);
-    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, *a, (int)tn);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn);
+    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
+    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
+    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
+    if (splits > 1) {
+        const int64_t n4 = a->M * a->N / 4;
+        int64_t blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(a->workspace),
+                           (int)splits, a->M, a->N, static_cast<const __bf16*>(a->bias), a->C, a->ldc, (int)a->c_dtype);
+    }
     MR_CHECK_LAUNCH("mr_gemm");
     return MR_OK;
 }

@@ -104,6 +104,8 @@ class PretrainEngine:
         self.T_q = z(Mmax, 3 * H)
         self.T_h = z(Mmax, 4 * H)
         self.delta = f(max(t.nseq * t.S for t in (self.tv, self.ta, self.tj, self.ts)) * d.nh)
+        if ops.GEMM_WORKSPACE is None or ops.GEMM_WORKSPACE.device != dev:
+            ops.GEMM_WORKSPACE = f(32 * 1024 * 1024)            # 128 MiB of fp32 split-K partials
         self.ln_ws = ops.layernorm_bwd_workspace(H, dev)
         self.cs_ws = ops.colsum_workspace(4 * H, dev)
         self.dXpool = z(self.n_pool, H)
@@ -308,7 +310,7 @@ class PretrainEngine:
         Returns the fp32 device vector loss_acc[3] (per-objective losses of this rank)."""
         world, rank, H = self.world, self.rank, self.d.H
         E_all = self.E[None] if gather_fn is None else gather_fn(self.E)
-        dE_all = torch.zeros_like(E_all) if world > 1 else self.dE[None]
+        dE_all = self.dE_all_buf if world > 1 else self.dE[None]
         self.dE.zero_()
         self.loss_acc.zero_()
         self.diag.zero_()

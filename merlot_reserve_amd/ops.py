@@ -26,6 +26,13 @@ def _ld(t):
     return t.stride(0)
 
 
+# Optional per-launch timing of the dominant kernel (bench.py): a list that receives (start_event, end_event, flops)
+# for every mr_gemm launch, recorded with HIP events on the stream the kernel is launched on.
+GEMM_PROFILE = None
+# fp32 scratch for split-K (set once by the engine; None disables split-K)
+GEMM_WORKSPACE = None
+
+
 def gemm(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
          residual=None, aux=None, row_map=None):
     """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
@@ -59,6 +66,17 @@ def gemm(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_col
     else:
         g.out_grp = g.out_grp_stride = g.out_grp_off = 0
         assert out.shape[0] >= M and out.shape[1] >= N
+    if GEMM_WORKSPACE is not None:
+        g.workspace, g.workspace_bytes = GEMM_WORKSPACE.data_ptr(), GEMM_WORKSPACE.numel() * 4
+    else:
+        g.workspace, g.workspace_bytes = None, 0
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K))
+        return out
     check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
     return out
 

@@ -1,0 +1,111 @@
+"""train_step (pretrain/pretrain_model.py:306-340) + construct_train_state (pretrain/optimization.py:158-195) on top
+of the engine: one process per GPU; data parallelism = RCCL over xGMI through torch.distributed ("nccl" backend).
+
+Per step and rank:  plan (host) -> forward -> all-gather of the packed contrastive embeddings -> loss + dL/dE ->
+reduce-scatter of dL/dE_all -> backward (tower gradient buckets are all-reduced (mean, bf16, like pmean at :329) on a side
+stream as soon as the tower's backward finishes) -> fused nan_to_num + bf16 Adam + decay + schedule + apply.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import PretrainEngine
+from .params import ParamStore
+from .planner import build_plan
+from .synthetic import make_draws
+
+
+def lr_scale_linearwarmup_cosinedecay(step, num_warmup_steps, num_train_steps, final_lr_scale=0.1):
+    """pretrain/optimization.py:117-137, evaluated in float32 like jnp on an int32 step."""
+    f = np.float32
+    step = f(step)
+    if step < num_warmup_steps:
+        return float(step / f(num_warmup_steps))
+    post = (step - f(num_warmup_steps)) / f(num_train_steps - num_warmup_steps + 1.0)
+    post = min(post, f(1.0))
+    post = f(1.0) - (f(1.0) - np.cos(f(np.pi) * post, dtype=np.float32)) / f(2.0)
+    return float(f(final_lr_scale) + f(1.0 - final_lr_scale) * post)
+
+
+class TrainState:
+    """Counterpart of flax TrainState for this path: step counter, parameters (fp32 master + bf16 working copy),
+    optimizer state (bf16 mu, cube-coded bf16 nu) -- all inside the ParamStore's flat buffers."""
+
+    def __init__(self, params, opt_config):
+        self.params = params
+        self.opt_config = dict(opt_config)
+        self.step = 0
+
+    def apply_gradients(self):
+        """optax chain of optimization.py:180-190 + apply_updates, one fused launch over the flat buffers.
+        scale_by_schedule uses its own count, evaluated BEFORE the increment (first update is zero)."""
+        oc, p = self.opt_config, self.params
+        assert oc.get('use_bfloat16_adam', True), 'only the bf16-state Adam of the reference configs is implemented'
+        num_steps = oc.get('num_train_steps_override', oc['num_train_steps'])
+        sched = lr_scale_linearwarmup_cosinedecay(self.step, oc['num_warmup_steps'], oc['num_train_steps'],
+                                                  oc.get('final_lr_scale', 0.02))
+        b1, b2 = oc.get('beta_1', 0.9), oc.get('beta_2', 0.98)
+        bc1 = bc2 = 1.0
+        if oc.get('do_bias_correction', False):
+            bc1, bc2 = 1.0 - b1 ** (self.step + 1), 1.0 - b2 ** (self.step + 1)
+        ops.adam_bf16_update(p.master, p.work, p.grad, p.mu, p.nu, p.decay_flags, b1, b2, oc.get('eps', 1e-8),
+                             oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
+        self.step += 1
+
+
+def construct_train_state(opt_config, params):
+    return TrainState(params, opt_config)
+
+
+class Trainer:
+    def __init__(self, config, B, device, rank=0, world=1, seed=0, process_group=None):
+        self.config, self.B, self.rank, self.world = config, B, rank, world
+        self.device = torch.device(device)
+        self.params = ParamStore(config, self.device, seed=seed)          # same seed on every rank: replicated init
+        self.state = construct_train_state(config['optimizer'], self.params)
+        self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
+        self.pg = process_group
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            R, H = self.engine.R, self.engine.d.H
+            self.E_all = torch.zeros(world, R, H, dtype=torch.bfloat16, device=self.device)
+            self.dE_all = torch.zeros(world, R, H, dtype=torch.bfloat16, device=self.device)
+            self.dE_red = torch.zeros(R, H, dtype=torch.bfloat16, device=self.device)
+
+    # ---- collectives (pretrain_model.py:290 forward, its transpose in backward, :329 for gradients) ----
+    def _gather(self, E):
+        self.dist.all_gather_into_tensor(self.E_all.view(-1), E.view(-1), group=self.pg)
+        return self.E_all
+
+    def _scatter(self, dE_all):
+        self.dist.reduce_scatter_tensor(self.dE_red.view(-1), dE_all.view(-1), op=self.dist.ReduceOp.SUM, group=self.pg)
+        return self.dE_red
+
+    def plan(self, batch, draws=None):
+        if draws is None:
+            seed = int(batch['audio2text/text_ptr'].astype(np.uint32).sum() % (2 ** 31))   # pretrain_model.py:96
+            draws = make_draws(self.config, self.B, seed=seed)
+        return build_plan(batch, self.engine.d, draws[0], draws[1])
+
+    def train_step(self, batch, plan=None, draws=None):
+        eng = self.engine
+        if plan is None:
+            plan = self.plan(batch, draws)
+        eng.forward(batch, plan=plan)
+        if self.world > 1:
+            self.dE_all.zero_()
+            eng.dE_all_buf = self.dE_all
+            eng.loss_and_grad_outputs(self._gather, self._scatter)
+        else:
+            eng.loss_and_grad_outputs()
+        eng.backward()
+        if self.world > 1:
+            ops.nan_to_num_(self.params.grad)                               # pretrain_model.py:328, before the pmean
+            self.dist.all_reduce(self.params.grad, op=self.dist.ReduceOp.AVG, group=self.pg)
+        self.state.apply_gradients()
+        return eng.loss_acc
+
+    def loss_info(self):
+        return self.engine.loss_info()
