@@ -83,14 +83,16 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    pg = None
+    comm = None
     if world > 1:
         import torch.distributed as dist
+        from merlot_reserve_amd.dist import Comm
         dist.init_process_group('nccl', device_id=dev)
+        comm = Comm()
 
     config = load_config(args.model)
     B = args.records_per_gpu
-    trainer = Trainer(config, B, dev, rank=rank, world=world, seed=0)
+    trainer = Trainer(config, B, dev, rank=rank, world=world, seed=0, comm=comm)
     batches = [make_batch(config, B, seed=1234 + rank + 1000 * i, device=dev) for i in range(2)]
 
     def barrier():

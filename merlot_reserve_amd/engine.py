@@ -304,13 +304,18 @@ class PretrainEngine:
                 'stuff_to_span': {'x': s('s2s_x'), 'y': s('s2s_y'), '_sources': torch.as_tensor(self.plan['t2sp_src'])}}
 
     # ------------------------------------------------------------------------------------------ loss (+ its backward)
-    def loss_and_grad_outputs(self, gather_fn=None, scatter_fn=None):
+    def loss_and_grad_outputs(self, E_all=None, dE_all=None):
         """loss_fn_given_preds (pretrain_model.py:262-303) for this rank and dL/dE.
-        gather_fn(E) -> [world, R, H] rank-major all-gather; scatter_fn(dE_all [world,R,H]) -> [R,H] reduce-scatter(sum).
+        world > 1: E_all [world,R,H] is the rank-major all-gather of every rank's E (:290); the gradient wrt this rank's
+        queries accumulates in self.dE, the gradient wrt EVERY rank's keys in dE_all [world,R,H] (zeroed here), which
+        the caller reduce-scatters (sum) and adds to self.dE before backward().
         Returns the fp32 device vector loss_acc[3] (per-objective losses of this rank)."""
         world, rank, H = self.world, self.rank, self.d.H
-        E_all = self.E[None] if gather_fn is None else gather_fn(self.E)
-        dE_all = self.dE_all_buf if world > 1 else self.dE[None]
+        if world == 1:
+            E_all, dE_all = self.E[None], self.dE[None]
+        else:
+            assert E_all is not None and dE_all is not None and E_all.shape[0] == world
+            dE_all.zero_()
         self.dE.zero_()
         self.loss_acc.zero_()
         self.diag.zero_()
@@ -336,13 +341,11 @@ class PretrainEngine:
                 dq = self.dE[q_off:q_off + Lq]
                 for r in range(world):
                     keys = E_all[r, k_off:k_off + nk]
-                    dk = dE_all[r, k_off:k_off + nk] if world > 1 else self.dE[k_off:k_off + nk]
+                    dk = dE_all[r, k_off:k_off + nk]
                     for dlb in (dl_lo, dl_hi):
                         blk = dlb[:, r * nk:(r + 1) * nk]
                         ops.gemm(blk, keys, dq, residual=dq)                   # d(query side) += dlogits . keys
                         ops.gemm(blk, q_loc, dk, transA=True, residual=dk)     # d(key side)   += dlogits^T . queries
-        if world > 1:
-            self.dE.add_(scatter_fn(dE_all))
         return self.loss_acc
 
     # ------------------------------------------------------------------------------------------ backward

@@ -58,30 +58,19 @@ def construct_train_state(opt_config, params):
 
 
 class Trainer:
-    def __init__(self, config, B, device, rank=0, world=1, seed=0, process_group=None):
+    def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None):
         self.config, self.B, self.rank, self.world = config, B, rank, world
         self.device = torch.device(device)
         self.params = ParamStore(config, self.device, seed=seed)          # same seed on every rank: replicated init
         self.state = construct_train_state(config['optimizer'], self.params)
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
-        self.pg = process_group
+        self.comm = comm
         if world > 1:
-            import torch.distributed as dist
-            self.dist = dist
-            self.comm_stream = torch.cuda.Stream(device=self.device)
+            assert comm is not None and comm.world == world and comm.rank == rank
+            assert (B * self.engine.d.ntrg) % 8 == 0, 'world > 1 needs 8-aligned contrastive blocks (even B for the stock configs)'
             R, H = self.engine.R, self.engine.d.H
-            self.E_all = torch.zeros(world, R, H, dtype=torch.bfloat16, device=self.device)
-            self.dE_all = torch.zeros(world, R, H, dtype=torch.bfloat16, device=self.device)
-            self.dE_red = torch.zeros(R, H, dtype=torch.bfloat16, device=self.device)
-
-    # ---- collectives (pretrain_model.py:290 forward, its transpose in backward, :329 for gradients) ----
-    def _gather(self, E):
-        self.dist.all_gather_into_tensor(self.E_all.view(-1), E.view(-1), group=self.pg)
-        return self.E_all
-
-    def _scatter(self, dE_all):
-        self.dist.reduce_scatter_tensor(self.dE_red.view(-1), dE_all.view(-1), op=self.dist.ReduceOp.SUM, group=self.pg)
-        return self.dE_red
+            z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)
+            self.E_all, self.dE_all, self.dE_red = z(world, R, H), z(world, R, H), z(R, H)
 
     def plan(self, batch, draws=None):
         if draws is None:
@@ -95,15 +84,16 @@ class Trainer:
             plan = self.plan(batch, draws)
         eng.forward(batch, plan=plan)
         if self.world > 1:
-            self.dE_all.zero_()
-            eng.dE_all_buf = self.dE_all
-            eng.loss_and_grad_outputs(self._gather, self._scatter)
+            self.comm.gather_embeddings(eng.E, self.E_all)                  # pretrain_model.py:290
+            eng.loss_and_grad_outputs(self.E_all, self.dE_all)
+            self.comm.scatter_grad(self.dE_all, self.dE_red)                # transpose of the all-gather
+            ops.add_(eng.dE.view(-1), self.dE_red.view(-1))
         else:
             eng.loss_and_grad_outputs()
         eng.backward()
         if self.world > 1:
             ops.nan_to_num_(self.params.grad)                               # pretrain_model.py:328, before the pmean
-            self.dist.all_reduce(self.params.grad, op=self.dist.ReduceOp.AVG, group=self.pg)
+            self.comm.allreduce_mean(self.params.grad)                      # :329 (bf16, like the reference)
         self.state.apply_gradients()
         return eng.loss_acc
 

@@ -126,3 +126,55 @@ def test_tiny_backward_parity(dev):
     # direction checked on every leaf that carries a non-negligible gradient
     bad = [(e, c, n) for e, c, n, a, n2 in worst if a > 8e-2 * n2 + 1.5e-2 * gmax or (n2 > 5e-2 * gmax and c < 0.995)]
     assert not bad, 'gradient parity failures:\n' + '\n'.join(f'{e:.3e} cos={c:.5f} {n}' for e, c, n in bad)
+
+
+def test_two_rank_contrastive_path_on_one_gpu(dev):
+    """The N > 1 loss path (rank-major all-gather of E, logits against every rank's keys, own-block offset, gradient wrt
+    the gathered keys reduce-scattered back) driven for two ranks inside one process, collectives emulated with
+    tensor copies, against the oracle's virtual-device loss_fn_given_preds."""
+    from merlot_reserve_amd.config import Dims
+    from merlot_reserve_amd.engine import PretrainEngine
+    from merlot_reserve_amd.params import ParamStore
+    from merlot_reserve_amd.planner import build_plan
+    from oracle import ref_torch as R
+    from tests.util import tiny_setup
+    B, world = 8, 2
+    engines, Es = [], []
+    for r in range(world):
+        cfg, store, batch, splits, z = tiny_setup(B=B, seed=3 + r, device=dev)
+        eng = PretrainEngine(cfg, B, store, dev, rank=r, world=world)
+        eng.set_plan(build_plan(batch, Dims(cfg, B), splits, z))
+        g = torch.Generator().manual_seed(10 + r)
+        E = torch.randn(eng.R, eng.d.H, generator=g)
+        E = (E / E.norm(dim=-1, keepdim=True) * 1.6).to(torch.bfloat16)
+        eng.E.copy_(E.to(dev))
+        engines.append(eng)
+        Es.append(E.float().requires_grad_(True))
+    E_all = torch.stack([e.E for e in engines])
+    dE_alls = [torch.zeros_like(E_all) for _ in range(world)]
+    for r, eng in enumerate(engines):
+        eng.loss_and_grad_outputs(E_all, dE_alls[r])
+    torch.cuda.synchronize()
+    red = sum(d.float() for d in dE_alls)                       # reduce-scatter(sum): rank r receives block r
+    preds = []
+    for r, eng in enumerate(engines):
+        p = {}
+        for k, k2, name in SECTIONS:
+            o, n = eng.sec[name]
+            p.setdefault(k, {})[k2] = Es[r][o:o + n]
+        p['stuff_to_span']['_sources'] = torch.as_tensor(eng.plan['t2sp_src']).long()
+        preds.append(p)
+    losses = [R.loss_fn_given_preds(preds, rank=r) for r in range(world)]
+    sum(l for l, _ in losses).backward()
+    for r, eng in enumerate(engines):
+        li = eng.loss_info()
+        assert abs(li['loss'] - float(losses[r][0])) <= 1e-3 * abs(float(losses[r][0])), (r, li['loss'], float(losses[r][0]))
+        for t in ('text2audio', 'audio2text', 'random_text'):
+            k = f'_stuff_to_span_from_{t}'
+            assert abs(li[k] - float(losses[r][1][k])) <= 2e-3 * abs(float(losses[r][1][k])) + 1e-4
+        total = eng.dE.float() + red[r]
+        for k, k2, name in SECTIONS:
+            o, n = eng.sec[name]
+            e = relerr(total[o:o + n], Es[r].grad[o:o + n])
+            print(f'rank {r} dE {name}: {e:.3e}')
+            assert e <= 1e-2, (r, name, e)
