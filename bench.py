@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--records-per-gpu', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
     args = ap.parse_args()
 
     import numpy as np
@@ -100,14 +101,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(nsteps):
+    def run(nsteps, graph=True):
         plan = trainer.plan(batches[0])
         for i in range(nsteps):
             b = batches[i % 2]
-            trainer.train_step(b, plan=plan)
+            if graph and use_graph:
+                trainer.train_step_graph(b, plan)
+            else:
+                trainer.train_step(b, plan=plan)
             if i + 1 < nsteps:
                 plan = trainer.plan(batches[(i + 1) % 2])     # host-side planning overlaps the GPU's step
 
+    use_graph = not args.no_graph
+    run(1, graph=False)                                        # eager step: allocates every buffer
+    if use_graph:
+        trainer.capture(batches[0])
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -123,7 +131,7 @@ def main():
     roof = None
     if not args.no_roofline:
         ops.GEMM_PROFILE = []
-        run(min(args.steps, 3))
+        run(min(args.steps, 3), graph=False)
         torch.cuda.synchronize()
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ops.GEMM_PROFILE)
         fl = sum(f for _, _, f in ops.GEMM_PROFILE)

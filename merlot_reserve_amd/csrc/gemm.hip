@@ -12,6 +12,7 @@
 // weight or activation is ever materialised in HBM.
 // Epilogue: bias / "rotary" diagonal scale / activation in the MFMA layout, then the tile goes
 // through LDS so that residual / gelu' operands are read and C is written as 16-byte row segments.
+#include <stdlib.h>
 #include "mr_common.h"
 
 namespace {
@@ -282,7 +283,25 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
     }
 }
 
+void launch_splitk_reduce(const mr_gemm_args* a, int64_t splits, hipStream_t s) {
+    const int64_t n4 = a->M * a->N / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(a->workspace),
+                       (int)splits, a->M, a->N, static_cast<const __bf16*>(a->bias), a->C, a->ldc, (int)a->c_dtype);
+}
+
 }  // namespace
+
+// gemm256.hip
+bool mr_gemm256_eligible(const mr_gemm_args* a);
+int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const mr_gemm_args*, int64_t, hipStream_t));
+
+static int use_gemm256() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MR_GEMM_V1_ONLY"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v;
+}
 
 extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(a != nullptr, "mr_gemm: null args");
@@ -305,6 +324,11 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
                      "mr_gemm: fp32 output supports bias only");
     }
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
+    if (use_gemm256() && mr_gemm256_eligible(a)) {
+        mr_gemm256_launch(a, static_cast<hipStream_t>(stream), launch_splitk_reduce);
+        MR_CHECK_LAUNCH("mr_gemm (256-row kernel)");
+        return MR_OK;
+    }
     const int64_t tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
     MR_CHECK_ARG(tm * tn < (1LL << 30), "mr_gemm: grid too large");
     // split-K: problems with few output tiles and a long contraction (every wgrad) cannot fill 256 CUs otherwise
@@ -327,13 +351,7 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
     else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
-    if (splits > 1) {
-        const int64_t n4 = a->M * a->N / 4;
-        int64_t blocks = (n4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(a->workspace),
-                           (int)splits, a->M, a->N, static_cast<const __bf16*>(a->bias), a->C, a->ldc, (int)a->c_dtype);
-    }
+    if (splits > 1) launch_splitk_reduce(a, splits, s);
     MR_CHECK_LAUNCH("mr_gemm");
     return MR_OK;
 }

@@ -1,0 +1,379 @@
+// Second-generation bf16 MFMA GEMM for gfx950: 256 x {128,96} x 64 tiles, 8 waves (4 x 2), one workgroup per CU,
+// operands streamed global -> LDS with LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction), a 3-stage
+// ring kept TWO k-tiles ahead behind a counted s_waitcnt vmcnt(6) and ONE raw s_barrier per k-tile (never vmcnt(0)
+// inside the loop).  LDS images are lane-linear per 1-KiB piece (an LDS-DMA constraint), so the bank-conflict
+// swizzles live on the per-lane SOURCE address and are undone by the matching XOR on the fragment reads:
+//   K-contiguous tile  [rows][64 k]  (128-B rows):  chunk ^= (row >> 1) & 7         -> conflict-free ds_read_b128
+//   K-strided   tile   [64 k][W]     (W = 256|128): chunk ^= 2*((k&3) + 4*((k>>3)&1)) -> conflict-free ds_read_b64_tr_b16
+// Out-of-range rows / columns are fetched with an out-of-range buffer offset, which the hardware zero-fills.
+// Same contract and epilogue as gemm.hip (mr_gemm dispatches here for large problems).
+#include <stdlib.h>
+#include "mr_common.h"
+
+namespace g256 {
+
+constexpr int BM = 256, BK = 64;
+constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
+constexpr int STAGE_B = 128 * BK * 2;       // 16 KiB (B is always staged 128 wide)
+constexpr int STAGE = STAGE_A + STAGE_B;    // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr unsigned OOB = 0x80000000u;      // >= any operand extent (< 2^31 B, checked on the host); + soffset cannot wrap
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_ks(int k) { return 2 * ((k & 3) + 4 * ((k >> 3) & 1)); }
+
+// byte offset (into the operand's buffer, for k-tile 0) of the 16-byte chunk that lane `lane` of piece `p` fetches.
+// The k-tile advance is a wave-uniform scalar offset (128 B per k-tile for K-contiguous, 64 rows for K-strided), and
+// k-rows past K fall beyond the operand's extent, so validity does not depend on the k-tile.
+template <bool TR, int W>
+__device__ __forceinline__ unsigned piece_src(int p, int lane, int64_t ld, int64_t own0, int64_t own_n) {
+    if (!TR) {
+        const int row = p * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz_kc(row);
+        const int64_t grow = own0 + row;
+        if (grow >= own_n) return OOB;
+        return (unsigned)((grow * ld + chunk * 8) * 2);
+    } else {
+        constexpr int C = W / 8;                 // chunks per k-row
+        const int krow = p * (64 / C) + lane / C;
+        const int chunk = (lane % C) ^ swz_ks(krow);
+        const int64_t gcol = own0 + chunk * 8;
+        if (gcol >= own_n) return OOB;
+        return (unsigned)((krow * ld + gcol) * 2);
+    }
+}
+
+template <bool TR, int W>
+__device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!TR) {
+        const int row = own0 + i;
+        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((kk * 4 + g) ^ swz_kc(row)) << 4));
+    } else {
+        const int q = i >> 2, p = i & 3;
+        const int k0 = kk * 32 + g * 8 + q;                 // rows k0 and k0 + 4 share swz bits except (k & 3)
+        const int chunk = (own0 >> 3) + (p >> 1);
+        // rows k0 and k0 + 4 have the same swizzle (bits 0-1 and bit 3 of k are equal), so one address + an immediate.
+        // Inline asm on purpose: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr builtin while LDS-DMA is in
+        // flight (it cannot disambiguate it from the DMA's LDS writes), which would drain the prefetch ring every
+        // k-tile.  The caller waits with an explicit lgkmcnt(0) + sched_barrier before the MFMAs (guide 5.7 form iii).
+        const unsigned a0 = (unsigned)(uintptr_t)MR_LDS_PTR(const char, tile + k0 * (W * 2) + ((chunk ^ swz_ks(k0)) << 4) + (p & 1) * 8);
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "i"(4 * W * 2));
+        s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    }
+}
+
+// One unit of work: an output tile (and, under split-K, one K range of it).
+struct Item {
+    int m0, n0, kt0, nkt, split;
+    bool valid;
+};
+
+__device__ __forceinline__ Item make_item(int w, int nwork, int splits, int tiles_n, int kt_per_split, int nk_all, int bn) {
+    Item it;
+    it.valid = w < nwork;
+    const int tile = w / splits;
+    it.split = w - tile * splits;
+    it.m0 = (tile / tiles_n) * BM;
+    it.n0 = (tile % tiles_n) * bn;
+    it.kt0 = it.split * kt_per_split;
+    const int kt1 = (it.kt0 + kt_per_split < nk_all) ? it.kt0 + kt_per_split : nk_all;
+    it.nkt = kt1 - it.kt0;
+    return it;
+}
+
+template <int BN, bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const mr_gemm_args p, int tiles_n, int kt_per_split, int splits, int nwork) {
+    constexpr int NJ = BN / 32;                  // 16-col MFMA tiles per wave (wave tile = 64 x BN/2)
+    constexpr int LDC = BN + 8;
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: LDS-DMA bases stay scalar
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    // PERSISTENT workgroups: block b handles work items b', b' + G, ... where b' is the XCD-aware permutation of b
+    // (blocks sharing an XCD's L2 get neighbouring tiles).  Round r of the grid covers items [rG, rG + G).
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
+    const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+    const int nk_all = (int)((p.K + BK - 1) / BK);
+
+#define GET_ITEM(w) make_item((w), nwork, splits, tiles_n, kt_per_split, nk_all, BN)
+
+    const int64_t a_rows = TA ? p.K : p.M, a_cols = TA ? p.M : p.K;
+    const int64_t b_rows = TB ? p.N : p.K, b_cols = TB ? p.K : p.N;
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((a_rows - 1) * p.lda + a_cols) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((b_rows - 1) * p.ldb + b_cols) * 2), 0x00020000);
+    const unsigned a_step = TA ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);       // bytes per k-tile
+    const unsigned b_step = TB ? (unsigned)(BK * 2) : (unsigned)(BK * p.ldb * 2);
+
+    // ---- issue cursor: runs two k-tiles ahead of the compute cursor, across item boundaries ----
+    int iw = bperm, ik = 0, istage = 0;
+    Item ii = GET_ITEM(iw);
+    unsigned ao0, ao1, ao2, ao3, bo0, bo1;
+#define SET_OFFSETS()                                                                   \
+    do {                                                                                \
+        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, p.lda, ii.m0, p.M);                \
+        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, p.lda, ii.m0, p.M);                \
+        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, p.lda, ii.m0, p.M);                \
+        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, p.lda, ii.m0, p.M);                \
+        bo0 = piece_src<!TB, 128>(wave * 2 + 0, lane, p.ldb, ii.n0, p.N);               \
+        bo1 = piece_src<!TB, 128>(wave * 2 + 1, lane, p.ldb, ii.n0, p.N);               \
+    } while (0)
+    // the 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any); `issued` tells the caller
+#define ISSUE_NEXT(issued)                                                                                              \
+    do {                                                                                                                \
+        (issued) = ii.valid;                                                                                            \
+        if (ii.valid) {                                                                                                 \
+            char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
+            char* sb_ = smem + istage * STAGE + STAGE_A + wave * 2048;                                                  \
+            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step, sb = (unsigned)(ii.kt0 + ik) * b_step;                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);              \
+            istage = (istage == NSTAGE - 1) ? 0 : istage + 1;                                                           \
+            if (++ik == ii.nkt) {                                                                                       \
+                iw += G;                                                                                                \
+                ik = 0;                                                                                                 \
+                ii = GET_ITEM(iw);                                                                                      \
+                if (ii.valid) SET_OFFSETS();                                                                            \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+
+    if (ii.valid) SET_OFFSETS();
+    int cw = bperm, cstage = 0;
+    Item ci = GET_ITEM(cw);
+    if (!ci.valid) return;
+    bool issued;
+    ISSUE_NEXT(issued);
+    ISSUE_NEXT(issued);
+    if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    while (ci.valid) {
+        // accumulators are kept TRANSPOSED (mfma(B-frag, A-frag)): lane holds C[m = .. + li][n = .. + 4g + r], i.e. 4
+        // consecutive columns of one row, so the epilogue moves 8-byte packed bf16 instead of single elements
+        f32x4 acc[4][NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < ci.nkt; ++t) {
+            // the stage being refilled was last read one step ago, behind that step's barrier
+            ISSUE_NEXT(issued);
+            const char* As = smem + cstage * STAGE;
+            const char* Bs = As + STAGE_A;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[NJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag<TA, 256>(As, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bfr[j] = frag<!TB, 128>(Bs, wn * (BN / 2) + j * 16, kk, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            // k-tile cseq+1 must have landed before anyone reads it: everything but this step's 6 pieces (this also
+            // retires the previous item's epilogue stores, which were issued before them)
+            if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
+        }
+
+        const int64_t m0 = ci.m0, n0 = ci.n0;
+        const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
+        if (splits > 1) {   // split-K partial: raw fp32 accumulators (N % 4 == 0 checked on the host)
+            float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = wrow0 + i * 16 + li;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int64_t n = wcol0 + j * 16 + g * 4;
+                    if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(Wp + m * p.N + n) = acc[i][j];
+                }
+            }
+        } else {
+            // ---------------- epilogue (same semantics as gemm.hip) ----------------
+            // bias / "rotary" scale are applied on the fly, (i, j) block by block, to keep register pressure flat
+            const __bf16* bias = static_cast<const __bf16*>(p.bias);
+            auto finish = [&](int i, int j, bool do_act) -> f32x4 {
+                const int64_t n = wcol0 + j * 16 + g * 4;
+                const int64_t m = wrow0 + i * 16 + li;
+                f32x4 v = acc[i][j];
+                if (bias != nullptr && n < p.N) {
+                    const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                }
+                if ((p.rot_tab != nullptr) && (n < p.rot_cols) && ((n & 63) < 32) && m < p.M)
+                    v *= *reinterpret_cast<const f32x4*>(p.rot_tab + (m % p.rot_rows) * 32 + (n & 63));
+                if (do_act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu1702(v[r]);
+                }
+                return v;
+            };
+            if (p.c_dtype == MR_DT_F32) {
+                float* C = static_cast<float*>(p.C);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = wrow0 + i * 16 + li;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const f32x4 v = finish(i, j, false);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t n = wcol0 + j * 16 + g * 4 + r;
+                            if (m < p.M && n < p.N) C[m * p.ldc + n] = v[r];
+                        }
+                    }
+                }
+            } else {
+                // the ring stage consumed last is free (the two others hold the next item's first k-tiles, in flight):
+                // stage the tile through it in two 128-row halves; raw barriers only, so the LDS-DMA stays in flight
+                __bf16* Cs = reinterpret_cast<__bf16*>(smem + (cstage == 0 ? NSTAGE - 1 : cstage - 1) * STAGE);
+                const int npass = (p.c2 != nullptr) ? 2 : 1;
+                for (int pass = 0; pass < npass; ++pass) {
+                    const bool final_pass = (pass == npass - 1);
+                    const bool do_act = final_pass && (p.act == MR_ACT_GELU1702);
+                    __bf16* Cout = static_cast<__bf16*>(final_pass ? p.C : p.c2);
+                    const __bf16* R = final_pass ? static_cast<const __bf16*>(p.residual) : nullptr;
+                    const __bf16* X = final_pass ? static_cast<const __bf16*>(p.aux) : nullptr;
+                    for (int half = 0; half < 2; ++half) {
+                        if ((wm >> 1) == half) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j) {
+                                    const f32x4 x = finish(i, j, do_act);
+                                    bf16x4 v;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] = (__bf16)x[r];
+                                    *reinterpret_cast<bf16x4*>(Cs + ((wm & 1) * 64 + i * 16 + li) * LDC + wn * (BN / 2) + j * 16 + g * 4) = v;
+                                }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+#pragma unroll 1
+                        for (int it = 0; it < (128 * CPR) / 512; ++it) {
+                            const int c = tid + 512 * it;
+                            const int row = c / CPR, ch = c % CPR;
+                            const int64_t gm = m0 + half * 128 + row, gn = n0 + 8 * ch;
+                            if (gm < p.M && gn < p.N) {
+                                u32x4 raw = *reinterpret_cast<const u32x4*>(Cs + row * LDC + 8 * ch);
+                                int64_t orow = gm;
+                                if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
+                                if (R != nullptr || X != nullptr) {
+                                    float f[8];
+                                    unpack8(raw, f);
+                                    if (R != nullptr) {
+                                        float rr[8];
+                                        unpack8(*reinterpret_cast<const u32x4*>(R + orow * p.ldr + gn), rr);
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+                                    }
+                                    if (X != nullptr) {
+                                        float xx[8];
+                                        unpack8(*reinterpret_cast<const u32x4*>(X + orow * p.ldaux + gn), xx);
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) f[e] = (float)(__bf16)f[e] * gelu1702_grad(xx[e]);
+                                    }
+                                    raw = pack8(f);
+                                }
+                                *reinterpret_cast<u32x4*>(Cout + orow * p.ldc + gn) = raw;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                }
+            }
+        }
+        cw += G;
+        ci = GET_ITEM(cw);
+    }
+}
+
+template <int BN>
+static void launch(const mr_gemm_args* a, dim3 grid, hipStream_t s, int tn, int kps, int splits, int nwork) {
+    dim3 block(512);
+    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, false, false>), grid, block, 0, s, *a, tn, kps, splits, nwork);
+    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, false, true>), grid, block, 0, s, *a, tn, kps, splits, nwork);
+    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, true, false>), grid, block, 0, s, *a, tn, kps, splits, nwork);
+    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true>), grid, block, 0, s, *a, tn, kps, splits, nwork);
+}
+
+}  // namespace g256
+
+constexpr int64_t NUM_CU = 256;    // MI355X
+
+// Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
+bool mr_gemm256_eligible(const mr_gemm_args* a) {
+    if (a->M < 512 || a->N < 96) return false;
+    if (!a->transA && a->K % 64 != 0) return false;       // K-contiguous operands are fetched in whole 128-B rows
+    if (a->transB && a->K % 64 != 0) return false;
+    const int64_t a_rows = a->transA ? a->K : a->M, b_rows = a->transB ? a->N : a->K;
+    if (a_rows * a->lda * 2 >= (1LL << 31) || b_rows * a->ldb * 2 >= (1LL << 31)) return false;   // 32-bit buffer offsets
+    return true;
+}
+
+int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const mr_gemm_args*, int64_t, hipStream_t)) {
+    const int64_t tm = (a->M + g256::BM - 1) / g256::BM;
+    // tile width: the one that wastes the fewest CU-rounds (256 workgroups per round, one per CU)
+    int bn = 128;
+    {
+        const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96);
+        // measured: a 96-wide tile costs ~0.91 of a 128-wide one (the A side and the LDS-DMA issue do not shrink)
+        const int64_t c128 = ((t128 + 255) / 256) * 100, c96 = ((t96 + 255) / 256) * 91;
+        if (c96 < c128) bn = 96;
+    }
+    static int force_bn = -1, grid_mode = -1;
+    if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
+    if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
+    if (force_bn == 96 || force_bn == 128) bn = force_bn;
+    const int64_t tn = (a->N + bn - 1) / bn;
+    const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
+    int64_t splits = 1;
+    const bool plain = !a->rot_tab && !a->c2 && a->act == MR_ACT_NONE && !a->residual && !a->aux && a->out_grp == 0;
+    if (a->workspace && plain && a->N % 4 == 0 && tm * tn < 192 && nk >= 16) {
+        splits = (512 + tm * tn - 1) / (tm * tn);
+        if (splits > nk / 6) splits = nk / 6;
+        if (splits > 64) splits = 64;
+        const int64_t fit = a->workspace_bytes / (a->M * a->N * (int64_t)sizeof(float));
+        if (splits > fit) splits = fit;
+        if (splits < 2) splits = 1;
+    }
+    int64_t kps = (nk + splits - 1) / splits;
+    splits = (nk + kps - 1) / kps;
+    const int64_t nwork = tm * tn * splits;
+    int64_t gsz = nwork < NUM_CU ? nwork : NUM_CU;               // persistent: one workgroup per CU
+    if (grid_mode == 1) gsz = nwork;                             // (experiment) one item per workgroup
+    else if (grid_mode > 1) gsz = nwork < grid_mode ? nwork : grid_mode;
+    dim3 grid((unsigned)gsz);
+    if (bn == 128) g256::launch<128>(a, grid, s, (int)tn, (int)kps, (int)splits, (int)nwork);
+    else g256::launch<96>(a, grid, s, (int)tn, (int)kps, (int)splits, (int)nwork);
+    if (splits > 1) reduce(a, splits, s);
+    return 0;
+}

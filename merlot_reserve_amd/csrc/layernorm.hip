@@ -6,7 +6,7 @@
 namespace {
 
 constexpr int MAXC = 4;           // 16-byte chunks per lane (template MC <= MAXC): H <= 64 * 8 * 4 = 2048
-constexpr int PART_ROWS = 128;    // rows of the fp32 partial-sum workspace
+constexpr int PART_ROWS = 1024;   // ln_bwd grid: 4 blocks per CU    // rows of the fp32 partial-sum workspace
 
 template <int MC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ x, int64_t ldx, const __bf16* __restrict__ gamma,
@@ -127,19 +127,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 }
 
 // out[c] = bf16(sum_p partials[p, c]);  columns [0, split) go to out0, [split, ncols) to out1.
-// Block = 64 columns x 4 row groups (coalesced 256-B row segments), LDS reduce over the 4 groups.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int ncols, int split,
-                                                              __bf16* __restrict__ out0, __bf16* __restrict__ out1) {
-    __shared__ float red[4][64];
+// Block = 64 columns x 16 row groups (coalesced 256-B row segments), LDS reduce over the groups.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int ncols, int split,
+                                                               __bf16* __restrict__ out0, __bf16* __restrict__ out1) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < ncols)
-        for (int p = grp; p < nparts; p += 4) s += partials[(int64_t)p * ncols + c];
+        for (int p = grp; p < nparts; p += 16) s += partials[(int64_t)p * ncols + c];
     red[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < ncols) {
-        s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][lane];
         if (c < split) out0[c] = (__bf16)s;
         else out1[c - split] = (__bf16)s;
     }
@@ -200,14 +202,14 @@ extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                        static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
                        static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, (int)add_to_dx,
                        static_cast<float*>(partials), rows, (int)H);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((2 * H + 63) / 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((2 * H + 63) / 64)), dim3(1024), 0, s,
                        static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H, static_cast<__bf16*>(dgamma),
                        static_cast<__bf16*>(dbeta));
     MR_CHECK_LAUNCH("mr_layernorm_bwd");
     return MR_OK;
 }
 
-constexpr int COLSUM_STRIPS = 64;
+constexpr int COLSUM_STRIPS = 128;
 extern "C" int64_t mr_colsum_workspace(int64_t N) { return (int64_t)COLSUM_STRIPS * N * sizeof(float); }
 
 extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream) {
@@ -219,7 +221,7 @@ extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, vo
     dim3 grid((unsigned)((N / 8 + 63) / 64), (unsigned)strips);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(x), ldx, rows, (int)N,
                        static_cast<float*>(partials));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s,
                        static_cast<const float*>(partials), (int)strips, (int)N, (int)N, static_cast<__bf16*>(out),
                        static_cast<__bf16*>(out));
     MR_CHECK_LAUNCH("mr_colsum");

@@ -123,6 +123,7 @@ class PretrainEngine:
         self.plan_dev = {}
         self._plan_caps = {}
         self._plan_views = {}
+        self.plan_frozen = False
 
     def _unpad_csr(self, nseq, S):
         rows = (np.arange(nseq)[:, None] * S + 1 + np.arange(S - 1)[None]).reshape(-1).astype(np.int32)
@@ -138,7 +139,10 @@ class PretrainEngine:
             t = torch.from_numpy(np.ascontiguousarray(v))
             cap = self._plan_caps.get(k, 0)
             if k not in self.plan_dev or t.numel() > cap:
-                newcap = max(int(t.numel() * 1.25) + 16, 16)
+                assert not self.plan_frozen, f'plan buffer {k} would be reallocated after graph capture'
+                # index lists are bounded by the number of joint + span positions; everything else has a fixed size
+                newcap = (self.tj.M + self.ts.M + 64) if k.endswith('_idx') else t.numel()
+                newcap = max(newcap, t.numel())
                 self.plan_dev[k] = torch.zeros(newcap, dtype=t.dtype, device=self.dev)
                 self._plan_caps[k] = newcap
             self.plan_dev[k][:t.numel()].copy_(t.reshape(-1), non_blocking=True)
@@ -255,6 +259,12 @@ class PretrainEngine:
             splits, z = draws if draws is not None else make_draws(self.config, d.B, seed=int(batch['audio2text/text_ptr'].astype(np.uint32).sum() % (2 ** 31)))
             plan = build_plan(batch, d, splits, z)
         self.set_plan(plan)
+        return self.forward_device(batch['images'], batch['audio_clips'])
+
+    def forward_device(self, images, audio_clips):
+        """Device part of forward(): the plan is already in its device buffers."""
+        d, W, H = self.d, self.p.w, self.d.H
+        batch = {'images': images, 'audio_clips': audio_clips}
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
 
         # vision tower (modeling.py:379-430)

@@ -78,6 +78,47 @@ class Trainer:
             draws = make_draws(self.config, self.B, seed=seed)
         return build_plan(batch, self.engine.d, draws[0], draws[1])
 
+    # ---- hipGraph path: the step is a fixed launch sequence over fixed buffers; capture it once, replay per step ----
+    def capture(self, batch):
+        """Capture forward / loss / backward into hipGraphs (split at the collectives when world > 1, which stay eager).
+        Call after at least one eager train_step (buffers and plan capacities exist)."""
+        eng, d = self.engine, self.engine.d
+        self.images_in = torch.zeros_like(batch['images'])
+        self.audio_in = torch.zeros_like(batch['audio_clips'])
+        eng.plan_frozen = True
+        torch.cuda.synchronize()
+        self.graphs = []
+        segs = [lambda: eng.forward_device(self.images_in, self.audio_in)]
+        if self.world > 1:
+            segs += [lambda: eng.loss_and_grad_outputs(self.E_all, self.dE_all),
+                     lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward(), ops.nan_to_num_(self.params.grad))]
+        else:
+            segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), eng.backward())]
+        pool = None
+        for fn in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            pool = g.pool()
+            self.graphs.append(g)
+
+    def train_step_graph(self, batch, plan):
+        eng = self.engine
+        self.images_in.copy_(batch['images'], non_blocking=True)
+        self.audio_in.copy_(batch['audio_clips'], non_blocking=True)
+        eng.set_plan(plan)
+        if self.world > 1:
+            self.graphs[0].replay()
+            self.comm.gather_embeddings(eng.E, self.E_all)
+            self.graphs[1].replay()
+            self.comm.scatter_grad(self.dE_all, self.dE_red)
+            self.graphs[2].replay()
+            self.comm.allreduce_mean(self.params.grad)
+        else:
+            self.graphs[0].replay()
+        self.state.apply_gradients()
+        return eng.loss_acc
+
     def train_step(self, batch, plan=None, draws=None):
         eng = self.engine
         if plan is None:

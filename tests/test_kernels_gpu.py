@@ -397,3 +397,68 @@ def test_adam_bf16(dev):
         assert torch.equal(fin, torch.isfinite(dec_got))
         assert relerr(dec_got[fin], dec_ref[fin]) < 2e-3
         assert torch.equal(work[sl].cpu(), d_master[sl].cpu().to(BF16))
+
+
+GEMM256_CASES = [
+    # shapes that dispatch to the 256-row LDS-DMA kernel (M >= 512): ragged M, both tile widths, all layouts, split-K
+    (15424 // 4, 768, 768, False, False),
+    (1000, 2304, 768, False, False),
+    (1000, 3072, 768, False, False),
+    (777, 768, 3072, False, True),
+    (520, 200, 128, False, True),       # N not a multiple of the tile
+    (768, 3072, 1500, True, False),     # wgrad: split-K, ragged K
+    (3072, 768, 1500, True, False),
+    (768, 768, 5000, True, False),
+    (640, 264, 704, True, True),
+]
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', GEMM256_CASES)
+def test_gemm256(dev, M, N, K, ta, tb):
+    from merlot_reserve_amd import ops
+    ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+    a = rnd((K, M) if ta else (M, K), dev, seed=1)
+    b = rnd((N, K) if tb else (K, N), dev, seed=2)
+    out = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
+    ops.gemm(a, b, out, transA=ta, transB=tb)
+    A = a.float().T if ta else a.float()
+    B = b.float().T if tb else b.float()
+    assert_close(out, A @ B, 3e-3, f'gemm256 {M}x{N}x{K} ta={ta} tb={tb}')
+
+
+def test_gemm256_epilogues(dev):
+    from merlot_reserve_amd import ops
+    M, N, K = 241 * 4, 384, 128
+    a, w = rnd((M, K), dev, seed=6), rnd((K, N), dev, scale=0.1, seed=7)
+    bias = rnd((N,), dev, seed=8)
+    tab = torch.rand(241, 32, device=dev) * 2 - 1
+    out = torch.zeros(M, N, dtype=BF16, device=dev)
+    ops.gemm(a, w, out, bias=bias, rot_tab=tab, rot_cols=256)
+    ref = a.float() @ w.float() + bias.float()
+    scale = torch.ones(M, N, device=dev)
+    rows = torch.arange(M, device=dev) % 241
+    for h in range(4):
+        scale[:, h * 64:h * 64 + 32] = tab[rows]
+    assert_close(out, ref * scale, 3e-3, 'rot epilogue')
+    pre = torch.zeros(M, N, dtype=BF16, device=dev)
+    ops.gemm(a, w, out, bias=bias, act=ops.ACT_GELU, c2=pre)
+    assert_close(pre, ref, 3e-3, 'c2')
+    assert_close(out, ref * torch.sigmoid(1.702 * ref), 4e-3, 'gelu')
+    res = rnd((M, N), dev, seed=9)
+    buf = res.clone()
+    ops.gemm(a, w, buf, residual=buf)
+    assert_close(buf, (a.float() @ w.float()).to(BF16).float() + res.float(), 3e-3, 'residual in place')
+    aux = rnd((M, N), dev, seed=10)
+    ops.gemm(a, w, out, aux=aux)
+    s = torch.sigmoid(1.702 * aux.float())
+    assert_close(out, (a.float() @ w.float()).to(BF16).float() * (s + 1.702 * aux.float() * s * (1 - s)), 4e-3, 'gelu grad')
+    M2 = 240 * 4
+    a2 = rnd((M2, K), dev, seed=11)
+    big = torch.zeros(4 * 241, N, dtype=BF16, device=dev)
+    ops.gemm(a2, w, big, bias=bias, row_map=(240, 241, 1))
+    got = big.reshape(4, 241, N)
+    assert torch.all(got[:, 0] == 0)
+    assert_close(got[:, 1:].reshape(M2, N), a2.float() @ w.float() + bias.float(), 3e-3, 'row map')
+    o32 = torch.zeros(M, N, dtype=F32, device=dev)
+    ops.gemm(a, w, o32, bias=bias)
+    assert relerr(o32, ref) < 1e-5
