@@ -74,15 +74,19 @@ typedef struct {
     void* workspace; int64_t workspace_bytes; /* optional fp32 scratch: enables split-K for few-tile / long-K problems */
 } mr_gemm_args;
 int mr_gemm(const mr_gemm_args* args, void* stream);
+/* count independent GEMMs (same transA/transB, epilogue limited to bias).  When they qualify (<= 4 problems, large M,
+ * N % 128 == 0) they run as ONE persistent launch sharing the 256 CUs -- the four weight gradients of a transformer
+ * layer -- with no split-K; otherwise this is count calls of mr_gemm.  Results are identical either way. */
+int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream);
 
 /* ---- LayerNorm (flax nn.LayerNorm eps=1e-5, fp32 stats, var = E[x^2]-E[x]^2: M:272,277,360,366) ---- */
 int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                      float* mean, float* rstd, int64_t rows, int64_t H, float eps, void* stream);
-/* dx = LN backward; dgamma/dbeta are reduced over rows into bf16 [H] each.
- * partials: fp32 workspace of mr_layernorm_bwd_workspace(H) bytes. If add_to_dx != 0, dx += result. */
+/* dx = LN backward (+ dx_add when not NULL: the other gradient path of the residual stream; dx_add may alias dx);
+ * dgamma/dbeta are reduced over rows into bf16 [H] each.  partials: fp32 workspace of mr_layernorm_bwd_workspace(H) bytes. */
 int64_t mr_layernorm_bwd_workspace(int64_t H);
 int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
-                     const float* mean, const float* rstd, void* dx, int64_t lddx, int32_t add_to_dx,
+                     const float* mean, const float* rstd, void* dx, int64_t lddx, const void* dx_add, int64_t ldadd,
                      void* dgamma, void* dbeta, void* partials, int64_t rows, int64_t H, void* stream);
 
 /* ---- column sum: out[n] = bf16(sum_m x[m,n])  (bias gradients) ---- */

@@ -29,9 +29,10 @@ PROTOTYPES = {
     'mr_version': (i32, []),
     'mr_last_error': (C.c_char_p, []),
     'mr_gemm': (i32, [C.POINTER(GemmArgs), vp]),
+    'mr_gemm_grouped': (i32, [C.POINTER(GemmArgs), i32, vp]),
     'mr_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, vp]),
     'mr_layernorm_bwd_workspace': (i64, [i64]),
-    'mr_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, vp]),
+    'mr_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp]),
     'mr_colsum_workspace': (i64, [i64]),
     'mr_colsum': (i32, [vp, i64, i64, i64, vp, vp, vp]),
     'mr_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),

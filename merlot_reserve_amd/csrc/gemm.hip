@@ -297,6 +297,8 @@ void launch_splitk_reduce(const mr_gemm_args* a, int64_t splits, hipStream_t s) 
 bool mr_gemm256_eligible(const mr_gemm_args* a);
 int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const mr_gemm_args*, int64_t, hipStream_t));
 
+bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s);
+
 static int use_gemm256() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MR_GEMM_V1_ONLY"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -353,5 +355,21 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
     if (splits > 1) launch_splitk_reduce(a, splits, s);
     MR_CHECK_LAUNCH("mr_gemm");
+    return MR_OK;
+}
+
+extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream) {
+    MR_CHECK_ARG(list != nullptr && count >= 1, "mr_gemm_grouped: empty list");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bool all_big = use_gemm256() && count > 1 && count <= 4;
+    for (int k = 0; all_big && k < count; ++k) all_big = list[k].M > 0 && list[k].N % 128 == 0;
+    if (all_big && mr_gemm256_grouped(list, count, s)) {
+        MR_CHECK_LAUNCH("mr_gemm_grouped");
+        return MR_OK;
+    }
+    for (int k = 0; k < count; ++k) {          // not groupable: one launch per problem (identical results)
+        const int rc = mr_gemm(&list[k], stream);
+        if (rc != MR_OK) return rc;
+    }
     return MR_OK;
 }

@@ -8,6 +8,7 @@
 // Out-of-range rows / columns are fetched with an out-of-range buffer offset, which the hardware zero-fills.
 // Same contract and epilogue as gemm.hip (mr_gemm dispatches here for large problems).
 #include <stdlib.h>
+#include <string.h>
 #include "mr_common.h"
 
 namespace g256 {
@@ -70,25 +71,37 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int l
 
 // One unit of work: an output tile (and, under split-K, one K range of it).
 struct Item {
-    int m0, n0, kt0, nkt, split;
+    int pi, m0, n0, kt0, nkt, split;
     bool valid;
 };
 
-__device__ __forceinline__ Item make_item(int w, int nwork, int splits, int tiles_n, int kt_per_split, int nk_all, int bn) {
+constexpr int MAXG = 4;
+// One launch = up to MAXG independent problems (same layouts and tile width) sharing the persistent grid: the four
+// weight gradients of a transformer layer fill the 256 CUs together, with no split-K traffic.
+struct G256Args {
+    int count, nwork, splits, kt_per_split;
+    int tiles_n[MAXG], tile_start[MAXG + 1];
+    mr_gemm_args p[MAXG];
+};
+
+__device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
     Item it;
-    it.valid = w < nwork;
-    const int tile = w / splits;
-    it.split = w - tile * splits;
-    it.m0 = (tile / tiles_n) * BM;
-    it.n0 = (tile % tiles_n) * bn;
-    it.kt0 = it.split * kt_per_split;
-    const int kt1 = (it.kt0 + kt_per_split < nk_all) ? it.kt0 + kt_per_split : nk_all;
+    it.valid = w < ga.nwork;
+    const int tile = w / ga.splits;
+    it.split = w - tile * ga.splits;
+    it.pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
+    const int lt = tile - ga.tile_start[it.pi], tn = ga.tiles_n[it.pi];
+    it.m0 = (lt / tn) * BM;
+    it.n0 = (lt % tn) * bn;
+    const int nk_all = (int)((ga.p[it.pi].K + BK - 1) / BK);
+    it.kt0 = it.split * ga.kt_per_split;
+    const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
     it.nkt = kt1 - it.kt0;
     return it;
 }
 
 template <int BN, bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const mr_gemm_args p, int tiles_n, int kt_per_split, int splits, int nwork) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     constexpr int NJ = BN / 32;                  // 16-col MFMA tiles per wave (wave tile = 64 x BN/2)
     constexpr int LDC = BN + 8;
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
@@ -103,29 +116,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const mr_gemm_args p, i
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
-    const int nk_all = (int)((p.K + BK - 1) / BK);
-
-#define GET_ITEM(w) make_item((w), nwork, splits, tiles_n, kt_per_split, nk_all, BN)
-
-    const int64_t a_rows = TA ? p.K : p.M, a_cols = TA ? p.M : p.K;
-    const int64_t b_rows = TB ? p.N : p.K, b_cols = TB ? p.K : p.N;
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((a_rows - 1) * p.lda + a_cols) * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(((b_rows - 1) * p.ldb + b_cols) * 2), 0x00020000);
-    const unsigned a_step = TA ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);       // bytes per k-tile
-    const unsigned b_step = TB ? (unsigned)(BK * 2) : (unsigned)(BK * p.ldb * 2);
+    const int splits = ga.splits;
+#define GET_ITEM(w) make_item(ga, (w), BN)
 
     // ---- issue cursor: runs two k-tiles ahead of the compute cursor, across item boundaries ----
     int iw = bperm, ik = 0, istage = 0;
     Item ii = GET_ITEM(iw);
-    unsigned ao0, ao1, ao2, ao3, bo0, bo1;
-#define SET_OFFSETS()                                                                   \
-    do {                                                                                \
-        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, p.lda, ii.m0, p.M);                \
-        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, p.lda, ii.m0, p.M);                \
-        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, p.lda, ii.m0, p.M);                \
-        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, p.lda, ii.m0, p.M);                \
-        bo0 = piece_src<!TB, 128>(wave * 2 + 0, lane, p.ldb, ii.n0, p.N);               \
-        bo1 = piece_src<!TB, 128>(wave * 2 + 1, lane, p.ldb, ii.n0, p.N);               \
+    unsigned ao0, ao1, ao2, ao3, bo0, bo1, a_step = 0, b_step = 0;
+    __amdgpu_buffer_rsrc_t ra, rb;      // wave-uniform descriptors of the issue cursor's problem (zero-fill beyond the extent)
+#define SET_OFFSETS()                                                                                                   \
+    do {                                                                                                                \
+        const mr_gemm_args& q_ = ga.p[ii.pi];                                                                           \
+        const int64_t lda_ = q_.lda, ldb_ = q_.ldb, M_ = q_.M, N_ = q_.N, K_ = q_.K;                                    \
+        const int64_t a_rows = TA ? K_ : M_, a_cols = TA ? M_ : K_, b_rows = TB ? N_ : K_, b_cols = TB ? K_ : N_;      \
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.A), 0, (int)(((a_rows - 1) * lda_ + a_cols) * 2), 0x00020000); \
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.B), 0, (int)(((b_rows - 1) * ldb_ + b_cols) * 2), 0x00020000); \
+        a_step = TA ? (unsigned)(BK * lda_ * 2) : (unsigned)(BK * 2);                                                   \
+        b_step = TB ? (unsigned)(BK * 2) : (unsigned)(BK * ldb_ * 2);                                                   \
+        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, lda_, ii.m0, M_);                                                  \
+        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ii.m0, M_);                                                  \
+        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ii.m0, M_);                                                  \
+        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ii.m0, M_);                                                  \
+        bo0 = piece_src<!TB, 128>(wave * 2 + 0, lane, ldb_, ii.n0, N_);                                                 \
+        bo1 = piece_src<!TB, 128>(wave * 2 + 1, lane, ldb_, ii.n0, N_);                                                 \
     } while (0)
     // the 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any); `issued` tells the caller
 #define ISSUE_NEXT(issued)                                                                                              \
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const mr_gemm_args p, i
             cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
         }
 
+        const mr_gemm_args& p = ga.p[ci.pi];          // (kernarg memory, uniform index: scalar loads)
         const int64_t m0 = ci.m0, n0 = ci.n0;
         const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
         if (splits > 1) {   // split-K partial: raw fp32 accumulators (N % 4 == 0 checked on the host)
@@ -317,12 +331,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const mr_gemm_args p, i
 }
 
 template <int BN>
-static void launch(const mr_gemm_args* a, dim3 grid, hipStream_t s, int tn, int kps, int splits, int nwork) {
+static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
     dim3 block(512);
-    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, false, false>), grid, block, 0, s, *a, tn, kps, splits, nwork);
-    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, false, true>), grid, block, 0, s, *a, tn, kps, splits, nwork);
-    else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm256_kernel<BN, true, false>), grid, block, 0, s, *a, tn, kps, splits, nwork);
-    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true>), grid, block, 0, s, *a, tn, kps, splits, nwork);
+    const bool ta = ga.p[0].transA, tb = ga.p[0].transB;
+    if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, false>), grid, block, 0, s, ga);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, true>), grid, block, 0, s, ga);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, true, false>), grid, block, 0, s, ga);
+    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true>), grid, block, 0, s, ga);
 }
 
 }  // namespace g256
@@ -372,8 +387,42 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     if (grid_mode == 1) gsz = nwork;                             // (experiment) one item per workgroup
     else if (grid_mode > 1) gsz = nwork < grid_mode ? nwork : grid_mode;
     dim3 grid((unsigned)gsz);
-    if (bn == 128) g256::launch<128>(a, grid, s, (int)tn, (int)kps, (int)splits, (int)nwork);
-    else g256::launch<96>(a, grid, s, (int)tn, (int)kps, (int)splits, (int)nwork);
+    g256::G256Args ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.count = 1; ga.nwork = (int)nwork; ga.splits = (int)splits; ga.kt_per_split = (int)kps;
+    ga.tiles_n[0] = (int)tn;
+    ga.tile_start[0] = 0;
+    for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
+    ga.p[0] = *a;
+    if (bn == 128) g256::launch<128>(ga, grid, s);
+    else g256::launch<96>(ga, grid, s);
     if (splits > 1) reduce(a, splits, s);
     return 0;
+}
+
+// Grouped launch: count <= 4 problems with identical transA/transB, each eligible for the 256-row kernel, epilogue
+// limited to bias; 128-wide tiles, no split-K.  Returns false if the group does not qualify (caller falls back).
+bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
+    if (count < 1 || count > g256::MAXG) return false;
+    g256::G256Args ga;
+    memset(&ga, 0, sizeof(ga));
+    int64_t tiles = 0;
+    for (int k = 0; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
+    int64_t nk_max = 0;
+    for (int k = 0; k < count; ++k) {
+        const mr_gemm_args* a = &list[k];
+        if (!mr_gemm256_eligible(a) || a->transA != list[0].transA || a->transB != list[0].transB) return false;
+        if (a->rot_tab || a->c2 || a->act != MR_ACT_NONE || a->residual || a->aux || a->out_grp != 0) return false;
+        const int64_t tm = (a->M + g256::BM - 1) / g256::BM, tn = (a->N + 127) / 128;
+        ga.tiles_n[k] = (int)tn;
+        ga.tile_start[k] = (int)tiles;
+        tiles += tm * tn;
+        ga.p[k] = *a;
+        const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
+        if (nk > nk_max) nk_max = nk;
+    }
+    ga.count = count; ga.nwork = (int)tiles; ga.splits = 1; ga.kt_per_split = (int)nk_max;
+    dim3 grid((unsigned)(tiles < NUM_CU ? tiles : NUM_CU));
+    g256::launch<128>(ga, grid, s);
+    return true;
 }

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ 
 template <int MC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, int64_t lddy, const __bf16* __restrict__ x,
                                                      int64_t ldx, const __bf16* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, __bf16* __restrict__ dx, int64_t lddx,
-                                                     int add_to_dx, float* __restrict__ partials, int64_t rows, int H) {
+                                                     const float* __restrict__ rstd, __bf16* dx, int64_t lddx,
+                                                     const __bf16* dx_add, int64_t ldadd, float* __restrict__ partials,
+                                                     int64_t rows, int H) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][2H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = H >> 3;
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rs * (gg[k][e] - s1 - xh[k][e] * s2);
-                if (add_to_dx) {
+                if (dx_add != nullptr) {
                     float old[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(dx + row * lddx + 8 * c), old);
+                    unpack8(*reinterpret_cast<const u32x4*>(dx_add + row * ldadd + 8 * c), old);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += old[e];
                 }
@@ -189,19 +190,19 @@ extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
 extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)PART_ROWS * 2 * H * sizeof(float); }
 
 extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* mean,
-                                const float* rstd, void* dx, int64_t lddx, int32_t add_to_dx, void* dgamma, void* dbeta,
-                                void* partials, int64_t rows, int64_t H, void* stream) {
+                                const float* rstd, void* dx, int64_t lddx, const void* dx_add, int64_t ldadd, void* dgamma,
+                                void* dbeta, void* partials, int64_t rows, int64_t H, void* stream) {
     MR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partials, "mr_layernorm_bwd: null pointer");
     MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_bwd: H=%ld unsupported", (long)H);
-    MR_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0, "mr_layernorm_bwd: leading dims must be multiples of 8");
+    MR_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "mr_layernorm_bwd: leading dims must be multiples of 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t nblk = (rows + 3) / 4;
     if (nblk > PART_ROWS) nblk = PART_ROWS;
     auto kern = (H <= 1024) ? ln_bwd_kernel<2> : ln_bwd_kernel<MAXC>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), (size_t)(8 * H * sizeof(float)), s,
                        static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
-                       static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, (int)add_to_dx,
-                       static_cast<float*>(partials), rows, (int)H);
+                       static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
+                       ldadd, static_cast<float*>(partials), rows, (int)H);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((2 * H + 63) / 64)), dim3(1024), 0, s,
                        static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H, static_cast<__bf16*>(dgamma),
                        static_cast<__bf16*>(dbeta));

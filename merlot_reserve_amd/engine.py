@@ -101,6 +101,7 @@ class PretrainEngine:
         self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
         self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
         self.T_a = z(Mmax, H)
+        self.T_d1, self.T_d2 = z(Mmax, H), z(Mmax, H)
         self.T_q = z(Mmax, 3 * H)
         self.T_h = z(Mmax, 4 * H)
         self.delta = f(max(t.nseq * t.S for t in (self.tv, self.ta, self.tj, self.ts)) * d.nh)
@@ -178,31 +179,36 @@ class PretrainEngine:
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
     def encoder_backward(self, st, prefix, rot, code, D):
-        """D [M,H]: gradient wrt st.xf on entry, wrt st.xin on exit.  Weight gradients go to the flat grad buffer."""
+        """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (one of D / two scratch
+        buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
+        gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K)."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
         T_a, T_q, T_h = self.T_a[:M], self.T_q[:M], self.T_h[:M]
+        Dcur, Dmid, Dnext = D, self.T_d1[:M], self.T_d2[:M]
         k = 2 * st.L + 1
-        ops.layernorm_bwd(D, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], D,
+        ops.layernorm_bwd(Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
                           G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.ln_ws)
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
-            ops.gemm(D, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                       # d hpre
-            ops.gemm(st.hact[l], D, G[n['w2']], transA=True)
-            ops.colsum(T_h, G[n['bb1']], self.cs_ws)
-            ops.gemm(st.ln2[l], T_h, G[n['w1']], transA=True)
+            ops.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
             ops.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
-            ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], D,
-                              G[n['g2']], G[n['b2']], self.ln_ws, add_to_dx=True)            # D = d xmid
-            ops.gemm(D, W[n['wo']], T_a, transB=True)                                      # d att
-            ops.gemm(st.att[l], D, G[n['wo']], transA=True)
+            ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
+                              G[n['g2']], G[n['b2']], self.ln_ws, dx_add=Dcur)               # Dmid = d xmid
+            ops.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
             ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.delta, T_q, rot, st.nseq, st.S, nh)
+            ops.colsum(T_h, G[n['bb1']], self.cs_ws)
             ops.colsum(T_q, G[n['bqkv']], self.cs_ws)
-            ops.gemm(st.ln1[l], T_q, G[n['wqkv']], transA=True)
             ops.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
-            ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], D,
-                              G[n['g1']], G[n['b1']], self.ln_ws, add_to_dx=True)            # D = d X[l]
-        ops.layernorm_bwd(D, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], D,
+            ops.gemm_grouped([ops.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
+                              ops.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
+                              ops.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
+                              ops.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
+            ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
+                              G[n['g1']], G[n['b1']], self.ln_ws, dx_add=Dmid)               # Dnext = d X[l]
+            Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
+        ops.layernorm_bwd(Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
                           G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.ln_ws)
+        return Dcur
 
     # ------------------------------------------------------------------------------------------ CLS tower head + pool
     def _cls_view(self, t, nseq, S):
@@ -246,7 +252,7 @@ class PretrainEngine:
         ops.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
         Dc = self._cls_view(D, st.nseq, st.S)
         ops.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
-        self.encoder_backward(st, prefix_t, rot, None, D)
+        D = self.encoder_backward(st, prefix_t, rot, None, D)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
 
@@ -379,8 +385,11 @@ class PretrainEngine:
         ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cs_ws)
         ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
         ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
-        self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
+        Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
         ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
+        if Ds.data_ptr() != self.Ds.data_ptr():            # the joint tower reuses the rotating scratch: keep a copy
+            self.Ds.copy_(Ds)
+            Ds = self.Ds
 
         # joint tower
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
@@ -388,9 +397,9 @@ class PretrainEngine:
         ops.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
         Dj = self.Dj
         ops.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
-        self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
+        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
-        ops.segment_sum([Dj, self.Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
+        ops.segment_sum([Dj, Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
         ops.segment_sum([Dj], self._pl('audT_indptr'), self._pl('audT_idx'), self.d_audio_seq)
         ops.segment_sum([Dj], self._pl('visT_indptr'), self._pl('visT_idx'), self.d_imgs_seq)
         ops.segment_sum([self.d_acls_g], self._pl('aclsT_indptr'), self._pl('aclsT_idx'), self.d_a_cls)

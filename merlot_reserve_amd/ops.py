@@ -33,11 +33,9 @@ GEMM_PROFILE = None
 GEMM_WORKSPACE = None
 
 
-def gemm(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
-         residual=None, aux=None, row_map=None):
-    """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
-    (or [N,K] if transB).  row_map = (grp, grp_stride, grp_off) remaps output rows (out must be big enough)."""
-    lib = _lib.load()
+def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
+              residual=None, aux=None, row_map=None):
+    """Builds the mr_gemm_args of out[M,N] = op(a) @ op(b) (see gemm())."""
     M, K = (a.shape[1], a.shape[0]) if transA else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if transB else (b.shape[0], b.shape[1])
     assert K == Kb, f'gemm: K mismatch {K} vs {Kb}'
@@ -70,15 +68,37 @@ def gemm(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_col
         g.workspace, g.workspace_bytes = GEMM_WORKSPACE.data_ptr(), GEMM_WORKSPACE.numel() * 4
     else:
         g.workspace, g.workspace_bytes = None, 0
+    return g
+
+
+def gemm(a, b, out, **kw):
+    """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
+    (or [N,K] if transB).  row_map = (grp, grp_stride, grp_off) remaps output rows (out must be big enough)."""
+    lib = _lib.load()
+    g = gemm_args(a, b, out, **kw)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K))
+        GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K))
         return out
     check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
     return out
+
+
+def gemm_grouped(arg_list):
+    """Several independent GEMMs (built with gemm_args) in one persistent launch when they qualify."""
+    lib = _lib.load()
+    arr = (GemmArgs * len(arg_list))(*arg_list)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list)))
+        return
+    check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 
 
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
@@ -92,11 +112,15 @@ def layernorm_bwd_workspace(H, device):
     return torch.empty(_lib.load().mr_layernorm_bwd_workspace(H) // 4, dtype=F32, device=device)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False, dx_add=None):
+    """dx = LN backward (+ dx_add; add_to_dx=True is shorthand for dx_add=dx)."""
     rows, H = x.shape
+    if add_to_dx:
+        dx_add = dx
     check(_lib.load().mr_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), mean.data_ptr(),
-                                       rstd.data_ptr(), dx.data_ptr(), _ld(dx), int(add_to_dx), dgamma.data_ptr(),
-                                       dbeta.data_ptr(), partials.data_ptr(), rows, H, _stream()), 'mr_layernorm_bwd')
+                                       rstd.data_ptr(), dx.data_ptr(), _ld(dx), _ptr(dx_add), 0 if dx_add is None else _ld(dx_add),
+                                       dgamma.data_ptr(), dbeta.data_ptr(), partials.data_ptr(), rows, H, _stream()),
+          'mr_layernorm_bwd')
     return dx
 
 

@@ -1,6 +1,6 @@
 """GEMM micro-benchmark on the shapes of the base / large pretraining step (random bf16 data, interleaved rounds)."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
 ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)

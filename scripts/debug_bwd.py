@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import *
 from merlot_reserve_amd.config import Dims
 from merlot_reserve_amd.engine import PretrainEngine

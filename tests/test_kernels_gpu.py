@@ -462,3 +462,23 @@ def test_gemm256_epilogues(dev):
     o32 = torch.zeros(M, N, dtype=F32, device=dev)
     ops.gemm(a, w, o32, bias=bias)
     assert relerr(o32, ref) < 1e-5
+
+
+def test_gemm_grouped(dev):
+    """Four wgrad-shaped problems in one persistent launch == four separate GEMMs."""
+    from merlot_reserve_amd import ops
+    ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+    Mtok, H = 1500, 512
+    xs = [rnd((Mtok, 4 * H), dev, seed=1), rnd((Mtok, H), dev, seed=2), rnd((Mtok, H), dev, seed=3), rnd((Mtok, H), dev, seed=4)]
+    ds = [rnd((Mtok, H), dev, seed=5), rnd((Mtok, 4 * H), dev, seed=6), rnd((Mtok, H), dev, seed=7), rnd((Mtok, 3 * H), dev, seed=8)]
+    outs = [torch.full((x.shape[1], d.shape[1]), float('nan'), dtype=BF16, device=dev) for x, d in zip(xs, ds)]
+    ops.gemm_grouped([ops.gemm_args(x, d, o, transA=True) for x, d, o in zip(xs, ds, outs)])
+    for x, d, o in zip(xs, ds, outs):
+        assert_close(o, x.float().T @ d.float(), 3e-3, f'grouped {tuple(o.shape)}')
+    # a group that does not qualify (small M) falls back to separate launches with the same results
+    small = [rnd((300, 128), dev, seed=9), rnd((300, 256), dev, seed=10)]
+    so = [torch.zeros(128, 128, dtype=BF16, device=dev), torch.zeros(256, 128, dtype=BF16, device=dev)]
+    dd = rnd((300, 128), dev, seed=11)
+    ops.gemm_grouped([ops.gemm_args(x, dd, o, transA=True) for x, o in zip(small, so)])
+    for x, o in zip(small, so):
+        assert_close(o, x.float().T @ dd.float(), 3e-3, 'grouped fallback')
