@@ -140,17 +140,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         bo0 = piece_src<!TB, 128>(wave * 2 + 0, lane, ldb_, ii.n0, N_);                                                 \
         bo1 = piece_src<!TB, 128>(wave * 2 + 1, lane, ldb_, ii.n0, N_);                                                 \
     } while (0)
-    // the 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any); `issued` tells the caller
-#define ISSUE_NEXT(issued)                                                                                              \
+    // The 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any), issued in two halves so that they can
+    // sit between the two MFMA batches of a k-tile instead of stalling the wave right after the barrier.
+#define ISSUE_A(issued)                                                                                                 \
     do {                                                                                                                \
         (issued) = ii.valid;                                                                                            \
         if (ii.valid) {                                                                                                 \
             char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
-            char* sb_ = smem + istage * STAGE + STAGE_A + wave * 2048;                                                  \
-            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step, sb = (unsigned)(ii.kt0 + ik) * b_step;                \
+            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step;                                                       \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
+        }                                                                                                               \
+    } while (0)
+#define ISSUE_B()                                                                                                       \
+    do {                                                                                                                \
+        if (ii.valid) {                                                                                                 \
+            char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
+            char* sb_ = smem + istage * STAGE + STAGE_A + wave * 2048;                                                  \
+            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step, sb = (unsigned)(ii.kt0 + ik) * b_step;                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);              \
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             }                                                                                                           \
         }                                                                                                               \
     } while (0)
+#define ISSUE_NEXT(issued) do { ISSUE_A(issued); ISSUE_B(); } while (0)
 
     if (ii.valid) SET_OFFSETS();
     int cw = bperm, cstage = 0;
@@ -186,7 +195,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
 
         for (int t = 0; t < ci.nkt; ++t) {
             // the stage being refilled was last read one step ago, behind that step's barrier
-            ISSUE_NEXT(issued);
             const char* As = smem + cstage * STAGE;
             const char* Bs = As + STAGE_A;
 #pragma unroll
@@ -196,6 +204,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 for (int i = 0; i < 4; ++i) af[i] = frag<TA, 256>(As, wm * 64 + i * 16, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) bfr[j] = frag<!TB, 128>(Bs, wn * (BN / 2) + j * 16, kk, lane);
+                // the DMA issue rides in the shadow of the fragment reads' latency / the other half's MFMAs
+                if (kk == 0) ISSUE_A(issued); else ISSUE_B();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
