@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmreserve_hip.so')
+LIB_PATH = os.environ.get('MR_LIB', os.path.join(HERE, 'libmreserve_hip.so'))    # MR_LIB: A/B a kernel variant in one run
 
 i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 

@@ -11,6 +11,12 @@
 #include <string.h>
 #include "mr_common.h"
 
+#ifdef MR_DIAG_SAMEK
+#define MR_DIAG_K(k) 0u     /* timing-only build: wrong results */
+#else
+#define MR_DIAG_K(k) (unsigned)(k)
+#endif
+
 namespace g256 {
 
 constexpr int BM = 256, BK = 64;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         (issued) = ii.valid;                                                                                            \
         if (ii.valid) {                                                                                                 \
             char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
-            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step;                                                       \
+            const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step;                                                        \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         if (ii.valid) {                                                                                                 \
             char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
             char* sb_ = smem + istage * STAGE + STAGE_A + wave * 2048;                                                  \
-            const unsigned sa = (unsigned)(ii.kt0 + ik) * a_step, sb = (unsigned)(ii.kt0 + ik) * b_step;                \
+            const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step, sb = MR_DIAG_K(ii.kt0 + ik) * b_step;                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);              \
@@ -274,63 +280,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     }
                 }
             } else {
-                // the ring stage consumed last is free (the two others hold the next item's first k-tiles, in flight):
-                // stage the tile through it in two 128-row halves; raw barriers only, so the LDS-DMA stays in flight
-                __bf16* Cs = reinterpret_cast<__bf16*>(smem + (cstage == 0 ? NSTAGE - 1 : cstage - 1) * STAGE);
-                const int npass = (p.c2 != nullptr) ? 2 : 1;
-                for (int pass = 0; pass < npass; ++pass) {
-                    const bool final_pass = (pass == npass - 1);
-                    const bool do_act = final_pass && (p.act == MR_ACT_GELU1702);
-                    __bf16* Cout = static_cast<__bf16*>(final_pass ? p.C : p.c2);
-                    const __bf16* R = final_pass ? static_cast<const __bf16*>(p.residual) : nullptr;
-                    const __bf16* X = final_pass ? static_cast<const __bf16*>(p.aux) : nullptr;
-                    for (int half = 0; half < 2; ++half) {
-                        if ((wm >> 1) == half) {
+                // Direct epilogue: with the transposed accumulators a lane owns 4 consecutive columns of a row, so every
+                // (i, j) block is one 8-byte store per lane (four lanes = one 32-B sector, four j = one 128-B line).
+                // No LDS staging and no workgroup barrier: each wave streams its 64 x BN/2 sub-tile on its own while the
+                // next item's k-tiles are already landing in the ring.
+                __bf16* Cout = static_cast<__bf16*>(p.C);
+                __bf16* C2 = static_cast<__bf16*>(p.c2);
+                const __bf16* R = static_cast<const __bf16*>(p.residual);
+                const __bf16* X = static_cast<const __bf16*>(p.aux);
+                const bool do_act = (p.act == MR_ACT_GELU1702);
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t gm = wrow0 + i * 16 + li;
+                    int64_t orow = gm;
+                    if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
 #pragma unroll
-                                for (int j = 0; j < NJ; ++j) {
-                                    const f32x4 x = finish(i, j, do_act);
-                                    bf16x4 v;
+                    for (int j = 0; j < NJ; ++j) {
+                        const int64_t gn = wcol0 + j * 16 + g * 4;
+                        if (gm < p.M && gn < p.N) {
+                            f32x4 v = finish(i, j, false);
+                            bf16x4 o;
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = (__bf16)x[r];
-                                    *reinterpret_cast<bf16x4*>(Cs + ((wm & 1) * 64 + i * 16 + li) * LDC + wn * (BN / 2) + j * 16 + g * 4) = v;
-                                }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
-#pragma unroll 1
-                        for (int it = 0; it < (128 * CPR) / 512; ++it) {
-                            const int c = tid + 512 * it;
-                            const int row = c / CPR, ch = c % CPR;
-                            const int64_t gm = m0 + half * 128 + row, gn = n0 + 8 * ch;
-                            if (gm < p.M && gn < p.N) {
-                                u32x4 raw = *reinterpret_cast<const u32x4*>(Cs + row * LDC + 8 * ch);
-                                int64_t orow = gm;
-                                if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
-                                if (R != nullptr || X != nullptr) {
-                                    float f[8];
-                                    unpack8(raw, f);
-                                    if (R != nullptr) {
-                                        float rr[8];
-                                        unpack8(*reinterpret_cast<const u32x4*>(R + orow * p.ldr + gn), rr);
+                            for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                            if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + orow * p.ldc + gn) = o;
+                            if (do_act) {
 #pragma unroll
-                                        for (int e = 0; e < 8; ++e) f[e] += rr[e];
-                                    }
-                                    if (X != nullptr) {
-                                        float xx[8];
-                                        unpack8(*reinterpret_cast<const u32x4*>(X + orow * p.ldaux + gn), xx);
-#pragma unroll
-                                        for (int e = 0; e < 8; ++e) f[e] = (float)(__bf16)f[e] * gelu1702_grad(xx[e]);
-                                    }
-                                    raw = pack8(f);
-                                }
-                                *reinterpret_cast<u32x4*>(Cout + orow * p.ldc + gn) = raw;
+                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)gelu1702(v[r]);
                             }
+                            if (R != nullptr) {
+                                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(R + orow * p.ldr + gn);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)((float)o[r] + (float)rr[r]);
+                            }
+                            if (X != nullptr) {
+                                const bf16x4 xx = *reinterpret_cast<const bf16x4*>(X + orow * p.ldaux + gn);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)((float)o[r] * gelu1702_grad((float)xx[r]));
+                            }
+                            *reinterpret_cast<bf16x4*>(Cout + orow * p.ldc + gn) = o;
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
                     }
                 }
             }

@@ -127,24 +127,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
         partials[(int64_t)blockIdx.x * 2 * H + c] = red[c] + red[2 * H + c] + red[4 * H + c] + red[6 * H + c];
 }
 
-// out[c] = bf16(sum_p partials[p, c]);  columns [0, split) go to out0, [split, ncols) to out1.
+// Column reduction of fp32 partial rows, two deterministic levels:
+//   level 1 (grid.y = RED_Y): block (x, y) sums rows y, y + RED_Y, ... of its 64 columns into mid[y, c]
+//   level 2 (grid.y = 1, nparts = RED_Y): sums mid and writes bf16; columns [0, split) -> out0, [split, ncols) -> out1.
 // Block = 64 columns x 16 row groups (coalesced 256-B row segments), LDS reduce over the groups.
+constexpr int RED_Y = 8;
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int ncols, int split,
-                                                               __bf16* __restrict__ out0, __bf16* __restrict__ out1) {
+                                                               float* __restrict__ mid, __bf16* __restrict__ out0,
+                                                               __bf16* __restrict__ out1) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < ncols)
-        for (int p = grp; p < nparts; p += 16) s += partials[(int64_t)p * ncols + c];
+        for (int p = blockIdx.y + gridDim.y * grp; p < nparts; p += gridDim.y * 16) s += partials[(int64_t)p * ncols + c];
     red[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < ncols) {
         s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][lane];
-        if (c < split) out0[c] = (__bf16)s;
+        if (mid != nullptr) mid[(int64_t)blockIdx.y * ncols + c] = s;
+        else if (c < split) out0[c] = (__bf16)s;
         else out1[c - split] = (__bf16)s;
+    }
+}
+
+static void launch_reduce(const float* partials, int nparts, int ncols, int split, float* mid, __bf16* out0, __bf16* out1, hipStream_t s) {
+    const unsigned gx = (unsigned)((ncols + 63) / 64);
+    if (nparts > 64) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, RED_Y), dim3(1024), 0, s, partials, nparts, ncols, split, mid, out0, out1);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(1024), 0, s, mid, RED_Y, ncols, split, (float*)nullptr, out0, out1);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(1024), 0, s, partials, nparts, ncols, split, (float*)nullptr, out0, out1);
     }
 }
 
@@ -187,7 +202,7 @@ extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
     return MR_OK;
 }
 
-extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)PART_ROWS * 2 * H * sizeof(float); }
+extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)(PART_ROWS + RED_Y) * 2 * H * sizeof(float); }
 
 extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* mean,
                                 const float* rstd, void* dx, int64_t lddx, const void* dx_add, int64_t ldadd, void* dgamma,
@@ -203,15 +218,14 @@ extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                        static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
                        static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
                        ldadd, static_cast<float*>(partials), rows, (int)H);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((2 * H + 63) / 64)), dim3(1024), 0, s,
-                       static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H, static_cast<__bf16*>(dgamma),
-                       static_cast<__bf16*>(dbeta));
+    launch_reduce(static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H,
+                  static_cast<float*>(partials) + (int64_t)PART_ROWS * 2 * H, static_cast<__bf16*>(dgamma), static_cast<__bf16*>(dbeta), s);
     MR_CHECK_LAUNCH("mr_layernorm_bwd");
     return MR_OK;
 }
 
 constexpr int COLSUM_STRIPS = 128;
-extern "C" int64_t mr_colsum_workspace(int64_t N) { return (int64_t)COLSUM_STRIPS * N * sizeof(float); }
+extern "C" int64_t mr_colsum_workspace(int64_t N) { return (int64_t)(COLSUM_STRIPS + RED_Y) * N * sizeof(float); }
 
 extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream) {
     MR_CHECK_ARG(x && out && partials, "mr_colsum: null pointer");
@@ -222,9 +236,8 @@ extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, vo
     dim3 grid((unsigned)((N / 8 + 63) / 64), (unsigned)strips);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(x), ldx, rows, (int)N,
                        static_cast<float*>(partials));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s,
-                       static_cast<const float*>(partials), (int)strips, (int)N, (int)N, static_cast<__bf16*>(out),
-                       static_cast<__bf16*>(out));
+    launch_reduce(static_cast<const float*>(partials), (int)strips, (int)N, (int)N,
+                  static_cast<float*>(partials) + (int64_t)COLSUM_STRIPS * N, static_cast<__bf16*>(out), static_cast<__bf16*>(out), s);
     MR_CHECK_LAUNCH("mr_colsum");
     return MR_OK;
 }
