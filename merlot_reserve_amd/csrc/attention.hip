@@ -12,17 +12,26 @@
 //     key(g, j) = 32 t + 16 (j >> 2) + 4 g + (j & 3)        (g = lane >> 4, j = 0..7, t = k-step)
 // and the other operand (V^T, K^T, dO^T, Q^T) is read with ds_read_b64_tr_b16 from a row-major LDS tile.
 // Softmax statistics are then per lane (no shuffles except a 4-lane max/sum) and nothing goes through LDS twice.
+//
+// Pipeline: a wave owns 16*QB queries (keys in the dK/dV kernel); the K/V (Q/dO) tiles of the inner loop are double
+// buffered in LDS: the next tile's global loads are issued into registers before the current tile is multiplied and
+// written to the other buffer afterwards -- one barrier per tile, global latency under the MFMAs.  Softmax runs in the
+// exp2 domain (scores pre-multiplied by log2 e); the additive -1e10 bias and tile tails are folded into a staged
+// per-key code tile (-2 = beyond the sequence).
 #include "mr_common.h"
 
 namespace {
 
-constexpr int TQ = 64;        // queries (or keys) per block: 4 waves x 16
-constexpr int TK = 64;        // keys (or queries) per inner tile
+constexpr int TK = 64;        // inner tile (keys in fwd / dQ, queries in dK/dV)
 constexpr int LDR = 72;       // row-read-only tile stride (elements): 144 B
 constexpr int LDV = 80;       // tiles that are tr-read: 160 B rows (8 rows x 32 B tile the 64 banks)
-constexpr float NEG_BIG = -1e10f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float SCALE2 = 0.125f * LOG2E;           // 1/sqrt(64) in the exp2 domain
+constexpr float NEG_BIG2 = -1e10f * LOG2E;         // the reference's -1e10 bias, exp2 domain
+constexpr int CODE_NONE = -2;                      // key / query beyond the sequence
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, int col0, int lane) {
     // rows row0 + 4g + {0..3} and row0 + 16 + 4g + {0..3}; 16 columns from col0; lane receives column (lane & 15)
@@ -46,125 +55,170 @@ __device__ __forceinline__ bf16x8 pack_acc_pair(const f32x4& a, const f32x4& b) 
     return r;
 }
 
-// cooperative load of a [64 rows][64 cols] bf16 tile (rows row0.., zero beyond nrows) from a matrix with leading dim ld
-__device__ __forceinline__ void load_tile64(const __bf16* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows,
-                                            __bf16* tile, int tld, int tid) {
+// register-staged copy of a [64 rows][64 cols] bf16 tile: 2 x 16 B per thread (256 threads)
+struct TileRegs { u32x4 v[2]; };
+__device__ __forceinline__ void tile_load(const __bf16* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int tid, TileRegs& r) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
+        const int c = tid + 256 * it, rr = c >> 3, ch = c & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + r < nrows) v = *reinterpret_cast<const u32x4*>(src + (row0 + r) * ld + 8 * ch);
-        *reinterpret_cast<u32x4*>(tile + r * tld + 8 * ch) = v;
+        if (row0 + rr < nrows) v = *reinterpret_cast<const u32x4*>(src + (row0 + rr) * ld + 8 * ch);
+        r.v[it] = v;
+    }
+}
+__device__ __forceinline__ void tile_store(__bf16* tile, int tld, int tid, const TileRegs& r) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it, rr = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(tile + rr * tld + 8 * ch) = r.v[it];
     }
 }
 
-// score for (query-side code cq, key index kidx): bias semantics of modeling.py:353-356
-__device__ __forceinline__ float biased(float raw, bool exists, bool has_code, int cq, int ck) {
-    if (!exists) return -INFINITY;
-    float s = raw * 0.125f;
-    if (has_code && !(cq == ck && cq >= 0)) s += NEG_BIG;
-    return s;
+// exp2-domain score with the bias semantics of modeling.py:353-356; ck == CODE_NONE: key does not exist
+template <bool MASKED>
+__device__ __forceinline__ float biased2(float raw, int cq, int ck) {
+    float s = raw * SCALE2;
+    if (MASKED && !(cq == ck && cq >= 0)) s += NEG_BIG2;
+    return (ck == CODE_NONE) ? -INFINITY : s;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+template <int QB, bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                           __bf16* __restrict__ out, float* __restrict__ lse,
                                                           int64_t S, int64_t nh) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[TK * LDR];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[TK * LDV];
-    __shared__ int32_t Cs[TK];
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDR];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDV];
+    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * TQ;
+    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
-    const int64_t qi = q0 + wave * 16 + i;
-    const bool has_code = code != nullptr;
 
-    bf16x8 qf[2];
+    bf16x8 qf[QB][2];
+    int64_t qi[QB];
+    int cq[QB];
 #pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (qi < S) v = *reinterpret_cast<const u32x4*>(base + qi * ld + h * 64 + dd * 32 + g * 8);
-        qf[dd] = __builtin_bit_cast(bf16x8, v);
+    for (int qb = 0; qb < QB; ++qb) {
+        qi[qb] = q0 + (wave * QB + qb) * 16 + i;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (qi[qb] < S) v = *reinterpret_cast<const u32x4*>(base + qi[qb] * ld + h * 64 + dd * 32 + g * 8);
+            qf[qb][dd] = __builtin_bit_cast(bf16x8, v);
+        }
+        cq[qb] = (MASKED && qi[qb] < S) ? code[seq * S + qi[qb]] : 0;
     }
-    const int cq = (has_code && qi < S) ? code[seq * S + qi] : 0;
 
-    float m = -INFINITY, l = 0.f;
-    f32x4 ot[4];
+    float m[QB], l[QB];
+    f32x4 ot[QB][4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) ot[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = -INFINITY; l[qb] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) ot[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    for (int64_t k0 = 0; k0 < S; k0 += TK) {
-        __syncthreads();
-        load_tile64(base + H + h * 64, ld, k0, S, Ks, LDR, tid);
-        load_tile64(base + 2 * H + h * 64, ld, k0, S, Vs, LDV, tid);
-        if (has_code && tid < TK) Cs[tid] = (k0 + tid < S) ? code[seq * S + k0 + tid] : -1;
-        __syncthreads();
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Vg = base + 2 * H + h * 64;
+    auto key_code = [&](int64_t k) -> int { return (k < S) ? (MASKED ? code[seq * S + k] : 0) : CODE_NONE; };
 
-        f32x4 st[4];
+    TileRegs kr, vr;
+    int cr = 0;
+    tile_load(Kg, ld, 0, S, tid, kr);
+    tile_load(Vg, ld, 0, S, tid, vr);
+    if (tid < TK) cr = key_code(tid);
+    tile_store(Ks[0], LDR, tid, kr);
+    tile_store(Vs[0], LDV, tid, vr);
+    if (tid < TK) Cs[0][tid] = cr;
+    __syncthreads();
+
+    const int nt = (int)((S + TK - 1) / TK);
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        if (t + 1 < nt) {      // next tile: global -> registers, in flight during this tile's MFMAs
+            tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
+            tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
+            if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
+        }
+        f32x4 st[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8 k0 = row_frag(Ks[b], LDR, kb * 16, 0, lane), k1 = row_frag(Ks[b], LDR, kb * 16, 1, lane);
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd)
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, LDR, kb * 16, dd, lane), qf[dd], st[kb], 0, 0, 0);
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kl = kb * 16 + g * 4 + r;
-                const float s = biased(st[kb][r], k0 + kl < S, has_code, cq, has_code ? Cs[kl] : 0);
-                st[kb][r] = s;
-                tmax = fmaxf(tmax, s);
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m, tmax);
-        const float alpha = __expf(m - mn);      // m = -inf on the first tile -> 0
-        m = mn;
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(st[kb][r] - mn);
-                st[kb][r] = pv;
-                psum += pv;
-            }
-        l = l * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) ot[db] *= alpha;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = pack_acc_pair(st[2 * t], st[2 * t + 1]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-                ot[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, LDV, 32 * t, 16 * db, lane), pf, ot[db], 0, 0, 0);
         }
+        i32x4 ck[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) ck[kb] = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+        bf16x8 pf[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = biased2<MASKED>(st[qb][kb][r], cq[qb], ck[kb][r]);
+                    st[qb][kb][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mn = fmaxf(m[qb], tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);      // m = -inf on the first tile -> 0
+            m[qb] = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(st[qb][kb][r] - mn);
+                    st[qb][kb][r] = pv;
+                    psum += pv;
+                }
+            l[qb] = l[qb] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
+            pf[qb][0] = pack_acc_pair(st[qb][0], st[qb][1]);
+            pf[qb][1] = pack_acc_pair(st[qb][2], st[qb][3]);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16x8 vf = tr_frag(Vs[b], LDV, 32 * t2, 16 * db, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][t2], ot[qb][db], 0, 0, 0);
+            }
+        if (t + 1 < nt) {      // the other buffer was last read one iteration ago, behind that iteration's barrier
+            tile_store(Ks[b ^ 1], LDR, tid, kr);
+            tile_store(Vs[b ^ 1], LDV, tid, vr);
+            if (tid < TK) Cs[b ^ 1][tid] = cr;
+        }
+        __syncthreads();
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (g == 0 && qi < S) lse[(seq * nh + h) * S + qi] = m + __logf(l);
-
-    __syncthreads();
-    __bf16* Os = Ks;  // [64 queries][LDR]
+    // lane holds O^T[d = 16 db + 4 g + r][query i]: 4 consecutive d of one row -> one 8-byte store per (qb, db)
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        bf16x4 v;
+    for (int qb = 0; qb < QB; ++qb) {
+        float lt = l[qb];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        if (qi[qb] < S) {
+            if (g == 0) lse[(seq * nh + h) * S + qi[qb]] = (m[qb] + log2f(lt)) * LN2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(ot[db][r] * inv);
-        *reinterpret_cast<bf16x4*>(Os + (wave * 16 + i) * LDR + db * 16 + g * 4) = v;
-    }
-    __syncthreads();
+            for (int db = 0; db < 4; ++db) {
+                bf16x4 v;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
-        if (q0 + r < S)
-            *reinterpret_cast<u32x4*>(out + (seq * S + q0 + r) * H + h * 64 + 8 * ch) =
-                *reinterpret_cast<const u32x4*>(Os + r * LDR + 8 * ch);
+                for (int r = 0; r < 4; ++r) v[r] = (__bf16)(ot[qb][db][r] * inv);
+                *reinterpret_cast<bf16x4*>(out + (seq * S + qi[qb]) * H + h * 64 + db * 16 + g * 4) = v;
+            }
+        }
     }
 }
 
@@ -190,197 +244,267 @@ __global__ void attn_delta_kernel(const __bf16* __restrict__ o, const __bf16* __
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+template <int QB, bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                              const __bf16* __restrict__ dout, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, __bf16* __restrict__ dqkv,
                                                              const float* __restrict__ rot_tab, int64_t rot_rows,
                                                              int64_t S, int64_t nh) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[TK * LDV];   // row reads (S^T) and tr reads (dQ^T)
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[TK * LDR];   // row reads (dP^T)
-    __shared__ int32_t Cs[TK];
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDV];   // row reads (S^T) and tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDR];   // row reads (dP^T)
+    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * TQ;
+    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
-    const int64_t qi = q0 + wave * 16 + i;
-    const bool has_code = code != nullptr;
 
-    bf16x8 qf[2], dof[2];
+    bf16x8 qf[QB][2], dof[QB][2];
+    int64_t qi[QB];
+    int cq[QB];
+    float lse2[QB], del[QB];
 #pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-        u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
-        if (qi < S) {
-            v = *reinterpret_cast<const u32x4*>(base + qi * ld + h * 64 + dd * 32 + g * 8);
-            w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi) * H + h * 64 + dd * 32 + g * 8);
+    for (int qb = 0; qb < QB; ++qb) {
+        qi[qb] = q0 + (wave * QB + qb) * 16 + i;
+        const bool ok = qi[qb] < S;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+            if (ok) {
+                v = *reinterpret_cast<const u32x4*>(base + qi[qb] * ld + h * 64 + dd * 32 + g * 8);
+                w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
+            }
+            qf[qb][dd] = __builtin_bit_cast(bf16x8, v);
+            dof[qb][dd] = __builtin_bit_cast(bf16x8, w);
         }
-        qf[dd] = __builtin_bit_cast(bf16x8, v);
-        dof[dd] = __builtin_bit_cast(bf16x8, w);
+        cq[qb] = (MASKED && ok) ? code[seq * S + qi[qb]] : 0;
+        lse2[qb] = ok ? lse[(seq * nh + h) * S + qi[qb]] * LOG2E : 0.f;
+        del[qb] = ok ? delta[(seq * nh + h) * S + qi[qb]] : 0.f;
     }
-    const int cq = (has_code && qi < S) ? code[seq * S + qi] : 0;
-    const float lse_q = (qi < S) ? lse[(seq * nh + h) * S + qi] : 0.f;
-    const float del_q = (qi < S) ? delta[(seq * nh + h) * S + qi] : 0.f;
-
-    f32x4 dq[4];
+    f32x4 dq[QB][4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t k0 = 0; k0 < S; k0 += TK) {
-        __syncthreads();
-        load_tile64(base + H + h * 64, ld, k0, S, Ks, LDV, tid);
-        load_tile64(base + 2 * H + h * 64, ld, k0, S, Vs, LDR, tid);
-        if (has_code && tid < TK) Cs[tid] = (k0 + tid < S) ? code[seq * S + k0 + tid] : -1;
-        __syncthreads();
-        f32x4 ds[4];
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Vg = base + 2 * H + h * 64;
+    auto key_code = [&](int64_t k) -> int { return (k < S) ? (MASKED ? code[seq * S + k] : 0) : CODE_NONE; };
+    TileRegs kr, vr;
+    int cr = 0;
+    tile_load(Kg, ld, 0, S, tid, kr);
+    tile_load(Vg, ld, 0, S, tid, vr);
+    if (tid < TK) cr = key_code(tid);
+    tile_store(Ks[0], LDV, tid, kr);
+    tile_store(Vs[0], LDR, tid, vr);
+    if (tid < TK) Cs[0][tid] = cr;
+    __syncthreads();
+
+    const int nt = (int)((S + TK - 1) / TK);
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        if (t + 1 < nt) {
+            tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
+            tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
+            if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
+        }
+        f32x4 ds[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 k0 = row_frag(Ks[b], LDV, kb * 16, 0, lane), k1 = row_frag(Ks[b], LDV, kb * 16, 1, lane);
+            const bf16x8 v0 = row_frag(Vs[b], LDR, kb * 16, 0, lane), v1 = row_frag(Vs[b], LDR, kb * 16, 1, lane);
+            const i32x4 ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, LDV, kb * 16, dd, lane), qf[dd], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, LDR, kb * 16, dd, lane), dof[dd], dp, 0, 0, 0);
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], st, 0, 0, 0);
+                f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(biased2<MASKED>(st[r], cq[qb], ck[r]) - lse2[qb]);
+                    ds[qb][kb][r] = pv * (dp[r] - del[qb]);
+                }
             }
+        }
+        bf16x8 dsf[QB][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kl = kb * 16 + g * 4 + r;
-                const float s = biased(st[r], k0 + kl < S, has_code, cq, has_code ? Cs[kl] : 0);
-                const float pv = __expf(s - lse_q);
-                ds[kb][r] = pv * (dp[r] - del_q);
+        for (int qb = 0; qb < QB; ++qb) {
+            dsf[qb][0] = pack_acc_pair(ds[qb][0], ds[qb][1]);
+            dsf[qb][1] = pack_acc_pair(ds[qb][2], ds[qb][3]);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16x8 kt = tr_frag(Ks[b], LDV, 32 * t2, 16 * db, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][t2], dq[qb][db], 0, 0, 0);
+            }
+        if (t + 1 < nt) {
+            tile_store(Ks[b ^ 1], LDV, tid, kr);
+            tile_store(Vs[b ^ 1], LDR, tid, vr);
+            if (tid < TK) Cs[b ^ 1][tid] = cr;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        if (qi[qb] < S) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int d = db * 16 + g * 4;
+                f32x4 x = dq[qb][db] * 0.125f;
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + qi[qb]) % rot_rows) * 32 + d);
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (__bf16)x[r];
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + qi[qb]) * ld + h * 64 + d) = v;
             }
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 dsf = pack_acc_pair(ds[2 * t], ds[2 * t + 1]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-                dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, LDV, 32 * t, 16 * db, lane), dsf, dq[db], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    __bf16* Os = Ks;   // [64][LDV]
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int d = db * 16 + g * 4 + r;
-            float x = dq[db][r] * 0.125f;
-            if (rot_tab != nullptr && d < 32 && qi < S) x *= rot_tab[((seq * S + qi) % rot_rows) * 32 + d];
-            v[r] = (__bf16)x;
-        }
-        *reinterpret_cast<bf16x4*>(Os + (wave * 16 + i) * LDV + db * 16 + g * 4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
-        if (q0 + r < S)
-            *reinterpret_cast<u32x4*>(dqkv + (seq * S + q0 + r) * ld + h * 64 + 8 * ch) =
-                *reinterpret_cast<const u32x4*>(Os + r * LDV + 8 * ch);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-// Block owns 64 keys (wave: 16).  Here scores are NOT transposed (S = Q . K^T: column = key on the lane, 4 queries per
-// 16-query block in the registers), so P and dS are the B operands of dV^T = dO^T . P and dK^T = Q^T . dS.
+// Block owns 64*KB keys (wave: 16*KB).  Here scores are NOT transposed (S = Q . K^T: column = key on the lane, 4 queries
+// per 16-query block in the registers), so P and dS are the B operands of dV^T = dO^T . P and dK^T = Q^T . dS.
+template <int KB, bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                               const __bf16* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, __bf16* __restrict__ dqkv,
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
                                                               int64_t S, int64_t nh) {
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[TK * LDV];    // row reads (S) and tr reads (dK^T)
-    __shared__ __attribute__((aligned(16))) __bf16 Ds[TK * LDV];    // dO: row reads (dP) and tr reads (dV^T)
-    __shared__ float Ls[TK], Dl[TK];
-    __shared__ int32_t Cs[TK];
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TK * LDV];    // row reads (S) and tr reads (dK^T)
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TK * LDV];    // dO: row reads (dP) and tr reads (dV^T)
+    __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK];
+    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, kbase = (int64_t)blockIdx.x * TQ;
+    const int64_t seq = blockIdx.z, h = blockIdx.y, kbase = (int64_t)blockIdx.x * (64 * KB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
-    const int64_t ki = kbase + wave * 16 + i;
-    const bool has_code = code != nullptr;
 
-    bf16x8 kf[2], vf[2];
+    bf16x8 kf[KB][2], vf[KB][2];
+    int64_t ki[KB];
+    int ck[KB];
 #pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-        u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
-        if (ki < S) {
-            v = *reinterpret_cast<const u32x4*>(base + ki * ld + H + h * 64 + dd * 32 + g * 8);
-            w = *reinterpret_cast<const u32x4*>(base + ki * ld + 2 * H + h * 64 + dd * 32 + g * 8);
+    for (int kb = 0; kb < KB; ++kb) {
+        ki[kb] = kbase + (wave * KB + kb) * 16 + i;
+        const bool ok = ki[kb] < S;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+            if (ok) {
+                v = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
+                w = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
+            }
+            kf[kb][dd] = __builtin_bit_cast(bf16x8, v);
+            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
         }
-        kf[dd] = __builtin_bit_cast(bf16x8, v);
-        vf[dd] = __builtin_bit_cast(bf16x8, w);
+        ck[kb] = ok ? (MASKED ? code[seq * S + ki[kb]] : 0) : CODE_NONE;
     }
-    const int ck = (has_code && ki < S) ? code[seq * S + ki] : -1;
-
-    f32x4 dk[4], dv[4];
+    f32x4 dk[KB][4], dv[KB][4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { dk[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    for (int64_t q0 = 0; q0 < S; q0 += TK) {
-        __syncthreads();
-        load_tile64(base + h * 64, ld, q0, S, Qs, LDV, tid);
-        load_tile64(dout + seq * S * H + h * 64, H, q0, S, Ds, LDV, tid);
+    const __bf16* Qg = base + h * 64;
+    const __bf16* Dg = dout + seq * S * H + h * 64;
+    const float* Lg = lse + (seq * nh + h) * S;
+    const float* Eg = delta + (seq * nh + h) * S;
+    TileRegs qr, dr;
+    float lr = 0.f, er = 0.f;
+    int cr = 0;
+    auto side_load = [&](int64_t q0) {
         if (tid < TK) {
             const bool ok = q0 + tid < S;
-            Ls[tid] = ok ? lse[(seq * nh + h) * S + q0 + tid] : 0.f;
-            Dl[tid] = ok ? delta[(seq * nh + h) * S + q0 + tid] : 0.f;
-            Cs[tid] = (ok && has_code) ? code[seq * S + q0 + tid] : -1;
+            lr = ok ? Lg[q0 + tid] * LOG2E : 0.f;
+            er = ok ? Eg[q0 + tid] : 0.f;
+            cr = ok ? (MASKED ? code[seq * S + q0 + tid] : 0) : CODE_NONE;
         }
-        __syncthreads();
-        f32x4 pp[4], ds[4];
+    };
+    tile_load(Qg, ld, 0, S, tid, qr);
+    tile_load(Dg, H, 0, S, tid, dr);
+    side_load(0);
+    tile_store(Qs[0], LDV, tid, qr);
+    tile_store(Ds[0], LDV, tid, dr);
+    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; }
+    __syncthreads();
+
+    const int nt = (int)((S + TK - 1) / TK);
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        if (t + 1 < nt) {
+            tile_load(Qg, ld, (int64_t)(t + 1) * TK, S, tid, qr);
+            tile_load(Dg, H, (int64_t)(t + 1) * TK, S, tid, dr);
+            side_load((int64_t)(t + 1) * TK);
+        }
+        f32x4 pp[KB][4], ds[KB][4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 q0f = row_frag(Qs[b], LDV, qb * 16, 0, lane), q1f = row_frag(Qs[b], LDV, qb * 16, 1, lane);
+            const bf16x8 d0f = row_frag(Ds[b], LDV, qb * 16, 0, lane), d1f = row_frag(Ds[b], LDV, qb * 16, 1, lane);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
+            const i32x4 c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs, LDV, qb * 16, dd, lane), kf[dd], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ds, LDV, qb * 16, dd, lane), vf[dd], dp, 0, 0, 0);
-            }
+            for (int kb = 0; kb < KB; ++kb) {
+                f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
+                f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qb * 16 + g * 4 + r;
-                const bool qok = q0 + ql < S;
-                const float s = biased(st[r], ki < S, has_code, has_code ? Cs[ql] : 0, ck);
-                const float pv = qok ? __expf(s - Ls[ql]) : 0.f;
-                pp[qb][r] = pv;
-                ds[qb][r] = pv * (dp[r] - Dl[ql]);
+                for (int r = 0; r < 4; ++r) {
+                    // query side code c4[r] (CODE_NONE: query beyond S -> p = 0), key side ck[kb]
+                    float s = st[r] * SCALE2;
+                    if (MASKED && !(c4[r] == ck[kb] && ck[kb] >= 0)) s += NEG_BIG2;
+                    const float pv = (c4[r] == CODE_NONE || ck[kb] == CODE_NONE) ? 0.f : __builtin_amdgcn_exp2f(s - l4[r]);
+                    pp[kb][qb][r] = pv;
+                    ds[kb][qb][r] = pv * (dp[r] - e4[r]);
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 pf = pack_acc_pair(pp[2 * t], pp[2 * t + 1]);
-            const bf16x8 dsf = pack_acc_pair(ds[2 * t], ds[2 * t + 1]);
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ds, LDV, 32 * t, 16 * db, lane), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qs, LDV, 32 * t, 16 * db, lane), dsf, dk[db], 0, 0, 0);
+                const bf16x8 dot = tr_frag(Ds[b], LDV, 32 * t2, 16 * db, lane);
+                const bf16x8 qt = tr_frag(Qs[b], LDV, 32 * t2, 16 * db, lane);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pack_acc_pair(pp[kb][2 * t2], pp[kb][2 * t2 + 1]), dv[kb][db], 0, 0, 0);
+                    dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pack_acc_pair(ds[kb][2 * t2], ds[kb][2 * t2 + 1]), dk[kb][db], 0, 0, 0);
+                }
+            }
+        if (t + 1 < nt) {
+            tile_store(Qs[b ^ 1], LDV, tid, qr);
+            tile_store(Ds[b ^ 1], LDV, tid, dr);
+            if (tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; }
+        }
+        __syncthreads();
+    }
+    // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (ki[kb] < S) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int d = db * 16 + g * 4;
+                f32x4 x = dk[kb][db] * 0.125f;
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + ki[kb]) % rot_rows) * 32 + d);
+                bf16x4 a, c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r]; }
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + H + h * 64 + d) = a;
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + 2 * H + h * 64 + d) = c;
             }
         }
     }
-    // store dK (scaled, "rotary"-scaled) and dV through LDS as 16-byte row segments
-    for (int which = 0; which < 2; ++which) {
-        __syncthreads();
-        __bf16* Os = Qs;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = db * 16 + g * 4 + r;
-                float x = (which == 0) ? dk[db][r] * 0.125f : dv[db][r];
-                if (which == 0 && rot_tab != nullptr && d < 32 && ki < S) x *= rot_tab[((seq * S + ki) % rot_rows) * 32 + d];
-                v[r] = (__bf16)x;
-            }
-            *reinterpret_cast<bf16x4*>(Os + (wave * 16 + i) * LDV + db * 16 + g * 4) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
-            if (kbase + r < S)
-                *reinterpret_cast<u32x4*>(dqkv + (seq * S + kbase + r) * ld + (which + 1) * H + h * 64 + 8 * ch) =
-                    *reinterpret_cast<const u32x4*>(Os + r * LDV + 8 * ch);
-        }
-    }
+}
+
+template <int QB>
+static dim3 attn_grid(int64_t S, int64_t nh, int64_t nseq) {
+    return dim3((unsigned)((S + 64 * QB - 1) / (64 * QB)), (unsigned)nh, (unsigned)nseq);
 }
 
 }  // namespace
@@ -390,9 +514,14 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     MR_CHECK_ARG(qkv && out && lse, "mr_attention_fwd: null pointer");
     MR_CHECK_ARG(nseq > 0 && S > 0 && nh > 0, "mr_attention_fwd: bad shape nseq=%ld S=%ld nh=%ld", (long)nseq, (long)S, (long)nh);
     MR_CHECK_ARG(nseq <= 65535 && nh <= 65535, "mr_attention_fwd: nseq / nh exceed grid limits");
-    dim3 grid((unsigned)((S + TQ - 1) / TQ), (unsigned)nh, (unsigned)nseq);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const __bf16*>(qkv), code, static_cast<__bf16*>(out), lse, S, nh);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const __bf16* q = static_cast<const __bf16*>(qkv);
+    __bf16* o = static_cast<__bf16*>(out);
+    const bool two = S > 64;        // short sequences (audio 31, span 16): one 16-query block per wave
+    if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
+    else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
+    else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
     MR_CHECK_LAUNCH("mr_attention_fwd");
     return MR_OK;
 }
@@ -406,13 +535,24 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     MR_CHECK_ARG(!rot_tab || rot_rows > 0, "mr_attention_bwd: rot_rows must be > 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = nseq * S;
+    const __bf16* q = static_cast<const __bf16*>(qkv);
+    const __bf16* d = static_cast<const __bf16*>(dout);
+    __bf16* g = static_cast<__bf16*>(dqkv);
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                       static_cast<const __bf16*>(out), static_cast<const __bf16*>(dout), delta, rows, S, nh);
-    dim3 grid((unsigned)((S + TQ - 1) / TQ), (unsigned)nh, (unsigned)nseq);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(qkv), code,
-                       static_cast<const __bf16*>(dout), lse, delta, static_cast<__bf16*>(dqkv), rot_tab, rot_rows, S, nh);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(qkv), code,
-                       static_cast<const __bf16*>(dout), lse, delta, static_cast<__bf16*>(dqkv), rot_tab, rot_rows, S, nh);
+                       static_cast<const __bf16*>(out), d, delta, rows, S, nh);
+    const bool two = S > 64;
+#define MR_LAUNCH_BWD(QB, M)                                                                                                  \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
+                           rot_tab, rot_rows, S, nh);                                                                         \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
+                           rot_tab, rot_rows, S, nh);                                                                         \
+    } while (0)
+    if (two && code) MR_LAUNCH_BWD(2, true);
+    else if (two) MR_LAUNCH_BWD(2, false);
+    else if (code) MR_LAUNCH_BWD(1, true);
+    else MR_LAUNCH_BWD(1, false);
+#undef MR_LAUNCH_BWD
     MR_CHECK_LAUNCH("mr_attention_bwd");
     return MR_OK;
 }
