@@ -133,8 +133,8 @@ def main():
         ops.GEMM_PROFILE = []
         run(min(args.steps, 3), graph=False)
         torch.cuda.synchronize()
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ops.GEMM_PROFILE)
-        fl = sum(f for _, _, f in ops.GEMM_PROFILE)
+        ms = sum(r[0].elapsed_time(r[1]) for r in ops.GEMM_PROFILE)
+        fl = sum(r[2] for r in ops.GEMM_PROFILE)
         n = len(ops.GEMM_PROFILE)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12

@@ -49,10 +49,10 @@ const char* mr_last_error(void);
  *   v = acc + bias[n]                                  (bias bf16 [N])
  *   v *= rot_tab[(m % rot_rows)*32 + (n & 63)]          for n < rot_cols and (n & 63) < 32
  *        (the reference's "rotary": a per-position diagonal scaling, M:116-144; rot_tab fp32)
- *   if c2: c2[m,n] = bf16(v)                           (pre-activation copy, same ldc / row map)
+ *   if c2: c2[m,n] = bf16(act'(v))  (= bf16(v) when act is NONE)   (saved for backward, same ldc / row map)
  *   v = act(v)
  *   v = bf16(v) + residual[m,n]                        (residual bf16, ld = ldr)
- *   v = bf16(v) * gelu1702'(aux[m,n])                  (aux bf16 pre-activation, ld = ldaux)
+ *   v = bf16(v) * aux[m,n]                             (aux bf16 = the act'(v) saved by the forward GEMM, ld = ldaux)
  * Output row map: row m is stored at row (m / out_grp) * out_grp_stride + out_grp_off + m % out_grp
  * when out_grp > 0 (used to leave room for the CLS row, M:311-320), else at row m.
  * c_dtype = MR_DT_F32 supports bias only (used for the contrastive logits, P:293).

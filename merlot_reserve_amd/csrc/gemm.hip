@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
     for (int pass = 0; pass < npass; ++pass) {
         const bool final_pass = (pass == npass - 1);
         const bool do_act = final_pass && (p.act == MR_ACT_GELU1702);
+        const bool do_dact = !final_pass && (p.act == MR_ACT_GELU1702);     // c2 pass under GELU stores gelu'(v)
         // stage the tile as bf16
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r];
                     if (do_act) v = gelu1702(v);
+                    if (do_dact) v = gelu1702_grad(v);
                     Cs[(wm * 64 + i * 16 + g * 4 + r) * LDC + wn * 64 + j * 16 + li] = (__bf16)v;
                 }
         __syncthreads();
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
                         float xx[8];
                         unpack8(*reinterpret_cast<const u32x4*>(X + orow * p.ldaux + gn), xx);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = (float)(__bf16)f[e] * gelu1702_grad(xx[e]);
+                        for (int e = 0; e < 8; ++e) f[e] = (float)(__bf16)f[e] * xx[e];
                     }
                     raw = pack8(f);
                 }

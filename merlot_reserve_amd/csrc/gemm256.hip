@@ -52,6 +52,14 @@ __device__ __forceinline__ unsigned piece_src(int p, int lane, int64_t ld, int64
     }
 }
 
+// Epilogue operands are fetched EARLY (top of the item's last k-tile) with ordinary loads.  With LDS-DMA in flight hipcc
+// turns the first use of an ordinary load into s_waitcnt vmcnt(0); issued a whole k-tile before that first use (in the
+// epilogue), the wait finds them -- and the ring's pieces issued during the last k-tile -- already landed.
+// (Inline-asm loads retired by the loop's counted vmcnt were tried: the register allocator may split the live range of
+// an asm result, i.e. copy the register before the data lands -- wrong values, no fault.  Not used.)
+#define PRE_LOAD_B64(dst, ptr) (dst) = *reinterpret_cast<const u32x2*>(ptr)
+__device__ __forceinline__ void reg_fence(u32x2& v) { asm volatile("" : "+v"(v)); }
+
 template <bool TR, int W>
 __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int lane) {
     const int g = lane >> 4, i = lane & 15;
@@ -199,7 +207,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int t = 0; t < ci.nkt; ++t) {
+        // Everything the epilogue reads from global memory (bias, and ONE of: residual / act' factor / "rotary" scales) is
+        // fetched at the top of the item's LAST k-tile with asm loads: older than that step's LDS-DMA pieces, so the
+        // step's own vmcnt(6) retires them under the MFMAs and the epilogue runs on registers only.
+        const mr_gemm_args& pc = ga.p[ci.pi];
+        const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
+        const __bf16* pre_src = static_cast<const __bf16*>(pc.residual ? pc.residual : pc.aux);
+        const int64_t pre_ld = pc.residual ? pc.ldr : pc.ldaux;
+        const bool pre_rot = epi_bf16 && pre_src == nullptr && pc.rot_tab != nullptr && BN == 128;
+        u32x2 pbias[NJ];
+        u32x2 pre2[4 * NJ];     // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
+        // k-loop with the LAST k-tile peeled: the prefetch registers are written (asm) and consumed in straight-line code,
+        // so no loop-carried copy of a register whose load is still in flight can be generated.
+        auto kstep = [&]() {
             // the stage being refilled was last read one step ago, behind that step's barrier
             const char* As = smem + cstage * STAGE;
             const char* Bs = As + STAGE_A;
@@ -227,8 +247,48 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
+        };
+        for (int t = 0; t + 1 < ci.nkt; ++t) kstep();
+        {
+            if (epi_bf16) {
+                const __bf16* bias_ = static_cast<const __bf16*>(pc.bias);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int64_t gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
+                    const void* src_ = (bias_ != nullptr && gn < pc.N) ? (const void*)(bias_ + gn) : pc.A;
+                    PRE_LOAD_B64(pbias[j], src_);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t gm = ci.m0 + wm * 64 + i * 16 + li;
+                    const bool mok = gm < pc.M;
+                    if (pre_src != nullptr) {
+                        int64_t orow = gm;
+                        if (pc.out_grp > 0) orow = (gm / pc.out_grp) * pc.out_grp_stride + pc.out_grp_off + gm % pc.out_grp;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int64_t gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
+                            const void* src_ = (mok && gn < pc.N) ? (const void*)(pre_src + orow * pre_ld + gn) : pc.A;
+                            PRE_LOAD_B64(pre2[i * NJ + j], src_);
+                        }
+                    } else if (pre_rot) {
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {  // BN = 128: the wave's 64 columns are one head; dims < 32 are j = 0, 1
+                            const void* src_ = mok ? (const void*)(pc.rot_tab + (gm % pc.rot_rows) * 32 + (j2 >> 1) * 16 + g * 4 + (j2 & 1) * 2) : pc.A;
+                            PRE_LOAD_B64(pre2[(i * 4 + j2) % (4 * NJ)], src_);
+                        }
+                    }
+                }
+            }
+            kstep();
         }
 
+        if (epi_bf16) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) reg_fence(pbias[j]);
+#pragma unroll
+            for (int k = 0; k < 4 * NJ; ++k) reg_fence(pre2[k]);
+        }
         const mr_gemm_args& p = ga.p[ci.pi];          // (kernarg memory, uniform index: scalar loads)
         const int64_t m0 = ci.m0, n0 = ci.n0;
         const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
@@ -247,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             // ---------------- epilogue (same semantics as gemm.hip) ----------------
             // bias / "rotary" scale are applied on the fly, (i, j) block by block, to keep register pressure flat
             const __bf16* bias = static_cast<const __bf16*>(p.bias);
-            auto finish = [&](int i, int j, bool do_act) -> f32x4 {
+            auto finish = [&](int i, int j, bool do_act) -> f32x4 {          // fp32-output path: direct loads
                 const int64_t n = wcol0 + j * 16 + g * 4;
                 const int64_t m = wrow0 + i * 16 + li;
                 f32x4 v = acc[i][j];
@@ -258,9 +318,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 }
                 if ((p.rot_tab != nullptr) && (n < p.rot_cols) && ((n & 63) < 32) && m < p.M)
                     v *= *reinterpret_cast<const f32x4*>(p.rot_tab + (m % p.rot_rows) * 32 + (n & 63));
-                if (do_act) {
+                (void)do_act;
+                return v;
+            };
+            auto finish_pre = [&](int i, int j) -> f32x4 {                   // bf16 path: prefetched registers only
+                const int64_t n = wcol0 + j * 16 + g * 4;
+                const int64_t m = wrow0 + i * 16 + li;
+                f32x4 v = acc[i][j];
+                if (bias != nullptr) {
+                    const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu1702(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                }
+                if (pre_rot && (n < p.rot_cols) && ((n & 63) < 32) && m < p.M) {   // host guarantees BN = 128 with rot_tab
+                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % (4 * NJ)], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % (4 * NJ)];
+                    v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
                 }
                 return v;
             };
@@ -286,38 +358,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 // next item's k-tiles are already landing in the ring.
                 __bf16* Cout = static_cast<__bf16*>(p.C);
                 __bf16* C2 = static_cast<__bf16*>(p.c2);
-                const __bf16* R = static_cast<const __bf16*>(p.residual);
-                const __bf16* X = static_cast<const __bf16*>(p.aux);
+                const bool has_res = p.residual != nullptr, has_aux = p.aux != nullptr;   // never both (host check)
                 const bool do_act = (p.act == MR_ACT_GELU1702);
+                const int64_t ldc = p.ldc;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t gm = wrow0 + i * 16 + li;
                     int64_t orow = gm;
                     if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
+                    const int64_t roff = orow * ldc + wcol0 + g * 4;       // element offset of this lane's first column
+                    const bool mok = gm < p.M;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int64_t gn = wcol0 + j * 16 + g * 4;
-                        if (gm < p.M && gn < p.N) {
-                            f32x4 v = finish(i, j, false);
+                        if (mok && wcol0 + j * 16 + g * 4 < p.N) {
+                            f32x4 v = finish_pre(i, j);
                             bf16x4 o;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                            if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + orow * p.ldc + gn) = o;
                             if (do_act) {
+                                bf16x4 d;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)gelu1702(v[r]);
+                                for (int r = 0; r < 4; ++r) {
+                                    const float sg = 1.0f / (1.0f + __expf(-1.702f * v[r]));
+                                    o[r] = (__bf16)(v[r] * sg);
+                                    d[r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
+                                }
+                                if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + roff + j * 16) = d;
+                            } else if (C2 != nullptr) {
+                                *reinterpret_cast<bf16x4*>(C2 + roff + j * 16) = o;
                             }
-                            if (R != nullptr) {
-                                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(R + orow * p.ldr + gn);
+                            if (has_res || has_aux) {
+                                const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)((float)o[r] + (float)rr[r]);
+                                for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
+                                    o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
                             }
-                            if (X != nullptr) {
-                                const bf16x4 xx = *reinterpret_cast<const bf16x4*>(X + orow * p.ldaux + gn);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] = (__bf16)((float)o[r] * gelu1702_grad((float)xx[r]));
-                            }
-                            *reinterpret_cast<bf16x4*>(Cout + orow * p.ldc + gn) = o;
+                            *reinterpret_cast<bf16x4*>(Cout + roff + j * 16) = o;
                         }
                     }
                 }
@@ -345,6 +421,7 @@ constexpr int64_t NUM_CU = 256;    // MI355X
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
     if (a->M < 512 || a->N < 96) return false;
+    if (a->residual && a->aux) return false;              // the epilogue prefetches ONE bf16 operand
     if (!a->transA && a->K % 64 != 0) return false;       // K-contiguous operands are fetched in whole 128-B rows
     if (a->transB && a->K % 64 != 0) return false;
     const int64_t a_rows = a->transA ? a->K : a->M, b_rows = a->transB ? a->N : a->K;
@@ -366,6 +443,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
     if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
     if (force_bn == 96 || force_bn == 128) bn = force_bn;
+    if (a->rot_tab) bn = 128;                               // the prefetched "rotary" scales assume one head per wave
     const int64_t tn = (a->N + bn - 1) / bn;
     const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
     int64_t splits = 1;

@@ -81,7 +81,7 @@ def gemm(a, b, out, **kw):
         e0.record()
         check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K))
+        GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K, (g.M, g.N, g.K, g.transA, g.transB, bool(g.bias), bool(g.rot_tab), bool(g.c2), g.act, bool(g.residual), bool(g.aux))))
         return out
     check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
     return out
@@ -96,7 +96,7 @@ def gemm_grouped(arg_list):
         e0.record()
         check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list)))
+        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list), ('grouped', len(arg_list), arg_list[0].K)))
         return
     check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 

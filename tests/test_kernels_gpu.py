@@ -99,8 +99,9 @@ def test_gemm_epilogues(dev):
     # mlp-in style: bias + gelu, pre-activation copy
     pre = torch.zeros(M, N, dtype=BF16, device=dev)
     ops.gemm(a, w, out, bias=bias, act=ops.ACT_GELU, c2=pre)
-    assert_close(pre, ref, 3e-3, 'c2')
-    assert_close(out, ref * torch.sigmoid(1.702 * ref), 4e-3, 'gelu')
+    sg = torch.sigmoid(1.702 * ref)
+    assert_close(pre, sg + 1.702 * ref * sg * (1 - sg), 4e-3, 'c2 = gelu grad')
+    assert_close(out, ref * sg, 4e-3, 'gelu')
     # residual
     res = rnd((M, N), dev, seed=9)
     ops.gemm(a, w, out, residual=res)
@@ -112,9 +113,9 @@ def test_gemm_epilogues(dev):
     # gelu' multiply
     aux = rnd((M, N), dev, seed=10)
     ops.gemm(a, w, out, aux=aux)
-    s = torch.sigmoid(1.702 * aux.float())
-    gp = s + 1.702 * aux.float() * s * (1 - s)
-    assert_close(out, (a.float() @ w.float()).to(BF16).float() * gp, 4e-3, 'gelu grad')
+    assert_close(out, (a.float() @ w.float()).to(BF16).float() * aux.float(), 4e-3, 'aux multiply')
+    ops.gemm(a, w, pre, bias=bias, c2=out)
+    assert_close(out, ref, 3e-3, 'c2 without activation')
     # row map: groups of 240 rows land after a CLS row
     M2 = 480
     a2 = rnd((M2, K), dev, seed=11)
@@ -442,16 +443,16 @@ def test_gemm256_epilogues(dev):
     assert_close(out, ref * scale, 3e-3, 'rot epilogue')
     pre = torch.zeros(M, N, dtype=BF16, device=dev)
     ops.gemm(a, w, out, bias=bias, act=ops.ACT_GELU, c2=pre)
-    assert_close(pre, ref, 3e-3, 'c2')
-    assert_close(out, ref * torch.sigmoid(1.702 * ref), 4e-3, 'gelu')
+    sg = torch.sigmoid(1.702 * ref)
+    assert_close(pre, sg + 1.702 * ref * sg * (1 - sg), 4e-3, 'c2 = gelu grad')
+    assert_close(out, ref * sg, 4e-3, 'gelu')
     res = rnd((M, N), dev, seed=9)
     buf = res.clone()
     ops.gemm(a, w, buf, residual=buf)
     assert_close(buf, (a.float() @ w.float()).to(BF16).float() + res.float(), 3e-3, 'residual in place')
     aux = rnd((M, N), dev, seed=10)
     ops.gemm(a, w, out, aux=aux)
-    s = torch.sigmoid(1.702 * aux.float())
-    assert_close(out, (a.float() @ w.float()).to(BF16).float() * (s + 1.702 * aux.float() * s * (1 - s)), 4e-3, 'gelu grad')
+    assert_close(out, (a.float() @ w.float()).to(BF16).float() * aux.float(), 4e-3, 'aux multiply')
     M2 = 240 * 4
     a2 = rnd((M2, K), dev, seed=11)
     big = torch.zeros(4 * 241, N, dtype=BF16, device=dev)
