@@ -38,3 +38,11 @@ class Comm:
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_((tmp / self.world).to(flat.dtype))
         return flat
+
+    def allreduce_mean_async(self, flat):
+        """Non-blocking form for gradient buckets: returns a handle with .wait() (nccl: runs on RCCL's stream after the
+        producing kernels, overlapping the compute stream), or None when the backend completed it synchronously."""
+        if self.backend == 'nccl':
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        self.allreduce_mean(flat)
+        return None

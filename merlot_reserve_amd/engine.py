@@ -366,7 +366,14 @@ class PretrainEngine:
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self):
-        """Backward of forward() given self.dE; fills self.p.grad (bf16, per rank, un-reduced)."""
+        """Backward of forward() given self.dE; fills self.p.grad (bf16, per rank, un-reduced).
+        Three stages, in the order the flat gradient buffer is laid out (params.py), so that a data-parallel caller can
+        all-reduce each finished range while the next stage runs: [scales, head, span, joint, token] -> audio -> vision."""
+        self.backward_stage_joint()
+        self.backward_stage_audio()
+        self.backward_stage_vision()
+
+    def backward_stage_joint(self):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
         self.dls.zero_()
@@ -404,7 +411,9 @@ class PretrainEngine:
         ops.segment_sum([Dj], self._pl('visT_indptr'), self._pl('visT_idx'), self.d_imgs_seq)
         ops.segment_sum([self.d_acls_g], self._pl('aclsT_indptr'), self._pl('aclsT_idx'), self.d_a_cls)
 
-        # audio tower
+    def backward_stage_audio(self):
+        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        ta = self.ta
         Da = self._tower_with_pool_backward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                             self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
                                             self.a_probs, self.d_audio_seq, self.d_a_cls, self.Da)
@@ -412,7 +421,9 @@ class PretrainEngine:
         ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
         ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cs_ws)
         ops.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
-        # vision tower
+    def backward_stage_vision(self):
+        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        tv = self.tv
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                             self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                             self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv)

@@ -71,6 +71,13 @@ class Trainer:
             R, H = self.engine.R, self.engine.d.H
             z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)
             self.E_all, self.dE_all, self.dE_red = z(world, R, H), z(world, R, H), z(R, H)
+            # gradient buckets = the three backward stages' ranges of the flat buffer (params.py lays towers out in
+            # the order backward finishes them)
+            tr = self.params.tower_ranges
+            a0, a1 = tr['audio_encoder']
+            v0, v1 = tr['vision_encoder']
+            assert a1 == v0 and v1 == self.params.total
+            self.buckets = [self.params.grad[:a0], self.params.grad[a0:a1], self.params.grad[v0:v1]]
 
     def plan(self, batch, draws=None):
         if draws is None:
@@ -90,8 +97,11 @@ class Trainer:
         self.graphs = []
         segs = [lambda: eng.forward_device(self.images_in, self.audio_in)]
         if self.world > 1:
+            b = self.buckets
             segs += [lambda: eng.loss_and_grad_outputs(self.E_all, self.dE_all),
-                     lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward(), ops.nan_to_num_(self.params.grad))]
+                     lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward_stage_joint(), ops.nan_to_num_(b[0])),
+                     lambda: (eng.backward_stage_audio(), ops.nan_to_num_(b[1])),
+                     lambda: (eng.backward_stage_vision(), ops.nan_to_num_(b[2]))]
         else:
             segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), eng.backward())]
         pool = None
@@ -112,8 +122,13 @@ class Trainer:
             self.comm.gather_embeddings(eng.E, self.E_all)
             self.graphs[1].replay()
             self.comm.scatter_grad(self.dE_all, self.dE_red)
-            self.graphs[2].replay()
-            self.comm.allreduce_mean(self.params.grad)
+            works = []
+            for k in range(3):       # bucket k is all-reduced (pretrain_model.py:329) while stage k+1 runs
+                self.graphs[2 + k].replay()
+                works.append(self.comm.allreduce_mean_async(self.buckets[k]))
+            for w in works:
+                if w is not None:
+                    w.wait()
         else:
             self.graphs[0].replay()
         self.state.apply_gradients()
@@ -131,10 +146,17 @@ class Trainer:
             ops.add_(eng.dE.view(-1), self.dE_red.view(-1))
         else:
             eng.loss_and_grad_outputs()
-        eng.backward()
         if self.world > 1:
-            ops.nan_to_num_(self.params.grad)                               # pretrain_model.py:328, before the pmean
-            self.comm.allreduce_mean(self.params.grad)                      # :329 (bf16, like the reference)
+            works = []
+            for k, stage in enumerate((eng.backward_stage_joint, eng.backward_stage_audio, eng.backward_stage_vision)):
+                stage()
+                ops.nan_to_num_(self.buckets[k])                            # pretrain_model.py:328, before the pmean
+                works.append(self.comm.allreduce_mean_async(self.buckets[k]))   # :329 (bf16, like the reference)
+            for w in works:
+                if w is not None:
+                    w.wait()
+        else:
+            eng.backward()
         self.state.apply_gradients()
         return eng.loss_acc
 
