@@ -361,39 +361,60 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 const bool has_res = p.residual != nullptr, has_aux = p.aux != nullptr;   // never both (host check)
                 const bool do_act = (p.act == MR_ACT_GELU1702);
                 const int64_t ldc = p.ldc;
+                // Stores are widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 and 4g+4.. of the same row, so one
+                // v_permlane16_swap per dword between the registers of two adjacent 16-column blocks (rows 1,3 of the first
+                // <-> rows 0,2 of the second) leaves every lane with 8 contiguous columns: lane rows g = 0/2 own block 2jp
+                // (columns 0-7 / 8-15), g = 1/3 own block 2jp+1.  A wave instruction then writes 64 contiguous bytes per
+                // row instead of 32 (the 8-byte form was store-issue bound: ~6 us per tile).
+                auto store_pair = [&](__bf16* base, int64_t roff0, bool mok, int jp, bf16x4 va, bf16x4 vb) {
+                    u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    const int col = wn * (BN / 2) + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;     // within the tile
+                    if (mok && n0 + col < p.N)
+                        *reinterpret_cast<u32x4*>(base + roff0 + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                };
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t gm = wrow0 + i * 16 + li;
                     int64_t orow = gm;
                     if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
-                    const int64_t roff = orow * ldc + wcol0 + g * 4;       // element offset of this lane's first column
+                    const int64_t roff0 = orow * ldc + n0;                  // element offset of the tile's first column
                     const bool mok = gm < p.M;
+                    bf16x4 oc[NJ], od[NJ];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if (mok && wcol0 + j * 16 + g * 4 < p.N) {
-                            f32x4 v = finish_pre(i, j);
-                            bf16x4 o;
+                        f32x4 v = finish_pre(i, j);
+                        bf16x4 o;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                            if (do_act) {
-                                bf16x4 d;
+                        for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                        od[j] = o;
+                        if (do_act) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float sg = 1.0f / (1.0f + __expf(-1.702f * v[r]));
-                                    o[r] = (__bf16)(v[r] * sg);
-                                    d[r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
-                                }
-                                if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + roff + j * 16) = d;
-                            } else if (C2 != nullptr) {
-                                *reinterpret_cast<bf16x4*>(C2 + roff + j * 16) = o;
+                            for (int r = 0; r < 4; ++r) {
+                                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[r]));   // v_rcp / v_exp: ~1 ulp
+                                o[r] = (__bf16)(v[r] * sg);
+                                od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
                             }
-                            if (has_res || has_aux) {
-                                const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
+                        }
+                        if (has_res || has_aux) {
+                            const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
-                                    o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
-                            }
-                            *reinterpret_cast<bf16x4*>(Cout + roff + j * 16) = o;
+                            for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
+                                o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
+                        }
+                        oc[j] = o;
+                    }
+#pragma unroll
+                    for (int jp = 0; jp < NJ / 2; ++jp) {
+                        if (C2 != nullptr) store_pair(C2, roff0, mok, jp, od[2 * jp], od[2 * jp + 1]);
+                        store_pair(Cout, roff0, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
+                    }
+                    if (NJ & 1) {                                          // BN = 96: the odd block keeps 8-byte stores
+                        const int col = wn * (BN / 2) + (NJ - 1) * 16 + g * 4;
+                        if (mok && n0 + col < p.N) {
+                            if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + roff0 + col) = od[NJ - 1];
+                            *reinterpret_cast<bf16x4*>(Cout + roff0 + col) = oc[NJ - 1];
                         }
                     }
                 }

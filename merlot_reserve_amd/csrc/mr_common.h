@@ -61,8 +61,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu1702(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float sigmoid1702(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x)); }
+__device__ __forceinline__ float gelu1702(float x) { return x * sigmoid1702(x); }
 __device__ __forceinline__ float gelu1702_grad(float x) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    float s = sigmoid1702(x);
     return s + 1.702f * x * s * (1.0f - s);
 }
