@@ -17,6 +17,17 @@
 #define MR_DIAG_K(k) (unsigned)(k)
 #endif
 
+#ifdef MR_DIAG_STAMPS
+#define MR_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (tid == 0 && nstamp < 64) stamps[(blockIdx.x * 64 + nstamp) * 4 + (slot)] = t_;          \
+    } while (0)
+#else
+#define MR_STAMP(slot) do {} while (0)
+#endif
+
 namespace g256 {
 
 constexpr int BM = 256, BK = 64;
@@ -101,7 +112,7 @@ struct G256Args {
 __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
     Item it;
     it.valid = w < ga.nwork;
-    const int tile = w / ga.splits;
+    const int tile = (ga.splits == 1) ? w : w / ga.splits;
     it.split = w - tile * ga.splits;
     it.pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
     const int lt = tile - ga.tile_start[it.pi], tn = ga.tiles_n[it.pi];
@@ -189,6 +200,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
 
     if (ii.valid) SET_OFFSETS();
     int cw = bperm, cstage = 0;
+#ifdef MR_DIAG_STAMPS
+    unsigned long long* stamps = static_cast<unsigned long long*>(ga.p[0].workspace);
+    int nstamp = 0;
+#endif
     Item ci = GET_ITEM(cw);
     if (!ci.valid) return;
     bool issued;
@@ -210,11 +225,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         // Everything the epilogue reads from global memory (bias, and ONE of: residual / act' factor / "rotary" scales) is
         // fetched at the top of the item's LAST k-tile with asm loads: older than that step's LDS-DMA pieces, so the
         // step's own vmcnt(6) retires them under the MFMAs and the epilogue runs on registers only.
+        // Every field of the problem that the prefetch / epilogue needs is copied into registers ONCE per item: the
+        // k-loop's asm statements clobber "memory", so anything left in kernarg memory would be re-loaded (s_load +
+        // full lgkmcnt wait, ~200 cycles each) at every use.  32-bit index math; 64 bits only to form addresses.
         const mr_gemm_args& pc = ga.p[ci.pi];
+        const int eM = (int)pc.M, eN = (int)pc.N;
+        const int64_t e_ldc = pc.ldc;
+        __bf16* const eC = static_cast<__bf16*>(pc.C);
+        __bf16* const eC2 = static_cast<__bf16*>(pc.c2);
+        const __bf16* const e_bias = static_cast<const __bf16*>(pc.bias);
+        const bool has_res = pc.residual != nullptr, has_aux = pc.aux != nullptr;      // never both (host check)
+        const __bf16* const pre_src = static_cast<const __bf16*>(has_res ? pc.residual : pc.aux);
+        const int64_t pre_ld = has_res ? pc.ldr : pc.ldaux;
+        const float* const e_rot = pc.rot_tab;
+        const int e_rot_rows = (int)pc.rot_rows, e_rot_cols = (int)pc.rot_cols;
+        const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
+        const bool do_act = (pc.act == MR_ACT_GELU1702);
         const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
-        const __bf16* pre_src = static_cast<const __bf16*>(pc.residual ? pc.residual : pc.aux);
-        const int64_t pre_ld = pc.residual ? pc.ldr : pc.ldaux;
-        const bool pre_rot = epi_bf16 && pre_src == nullptr && pc.rot_tab != nullptr && BN == 128;
+        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN == 128;
+        const void* const dummy = pc.A;
+        auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
         u32x2 pre2[4 * NJ];     // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
         // k-loop with the LAST k-tile peeled: the prefetch registers are written (asm) and consumed in straight-line code,
@@ -248,33 +278,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             __builtin_amdgcn_s_barrier();
             cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
         };
+        MR_STAMP(0);
         for (int t = 0; t + 1 < ci.nkt; ++t) kstep();
+        MR_STAMP(1);
         {
             if (epi_bf16) {
-                const __bf16* bias_ = static_cast<const __bf16*>(pc.bias);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int64_t gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
-                    const void* src_ = (bias_ != nullptr && gn < pc.N) ? (const void*)(bias_ + gn) : pc.A;
+                    const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
+                    const void* src_ = (e_bias != nullptr && gn < eN) ? (const void*)(e_bias + gn) : dummy;
                     PRE_LOAD_B64(pbias[j], src_);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int64_t gm = ci.m0 + wm * 64 + i * 16 + li;
-                    const bool mok = gm < pc.M;
+                    const int gm = ci.m0 + wm * 64 + i * 16 + li;
+                    const bool mok = gm < eM;
                     if (pre_src != nullptr) {
-                        int64_t orow = gm;
-                        if (pc.out_grp > 0) orow = (gm / pc.out_grp) * pc.out_grp_stride + pc.out_grp_off + gm % pc.out_grp;
+                        const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const int64_t gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
-                            const void* src_ = (mok && gn < pc.N) ? (const void*)(pre_src + orow * pre_ld + gn) : pc.A;
+                            const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
+                            const void* src_ = (mok && gn < eN) ? (const void*)(rowp + gn) : dummy;
                             PRE_LOAD_B64(pre2[i * NJ + j], src_);
                         }
                     } else if (pre_rot) {
+                        const int rr = (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+                        const float* rowp = e_rot + (int64_t)rr * 32 + g * 4;
 #pragma unroll
                         for (int j2 = 0; j2 < 4; ++j2) {  // BN = 128: the wave's 64 columns are one head; dims < 32 are j = 0, 1
-                            const void* src_ = mok ? (const void*)(pc.rot_tab + (gm % pc.rot_rows) * 32 + (j2 >> 1) * 16 + g * 4 + (j2 & 1) * 2) : pc.A;
+                            const void* src_ = mok ? (const void*)(rowp + (j2 >> 1) * 16 + (j2 & 1) * 2) : dummy;
                             PRE_LOAD_B64(pre2[(i * 4 + j2) % (4 * NJ)], src_);
                         }
                     }
@@ -283,143 +315,127 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             kstep();
         }
 
+        MR_STAMP(2);
         if (epi_bf16) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) reg_fence(pbias[j]);
 #pragma unroll
             for (int k = 0; k < 4 * NJ; ++k) reg_fence(pre2[k]);
         }
-        const mr_gemm_args& p = ga.p[ci.pi];          // (kernarg memory, uniform index: scalar loads)
-        const int64_t m0 = ci.m0, n0 = ci.n0;
-        const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
-        if (splits > 1) {   // split-K partial: raw fp32 accumulators (N % 4 == 0 checked on the host)
-            float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
+        const int m0 = ci.m0, n0 = ci.n0;
+        const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
+        if (!epi_bf16) {
+            // split-K partials and fp32 outputs (contrastive logits): rare, small; direct loads / scalar stores
+            const mr_gemm_args& p = ga.p[ci.pi];
+            if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
+                float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = wrow0 + i * 16 + li;
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = wrow0 + i * 16 + li;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int64_t n = wcol0 + j * 16 + g * 4;
-                    if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(Wp + m * p.N + n) = acc[i][j];
+                    for (int j = 0; j < NJ; ++j) {
+                        const int64_t n = wcol0 + j * 16 + g * 4;
+                        if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(Wp + m * p.N + n) = acc[i][j];
+                    }
                 }
-            }
-        } else {
-            // ---------------- epilogue (same semantics as gemm.hip) ----------------
-            // bias / "rotary" scale are applied on the fly, (i, j) block by block, to keep register pressure flat
-            const __bf16* bias = static_cast<const __bf16*>(p.bias);
-            auto finish = [&](int i, int j, bool do_act) -> f32x4 {          // fp32-output path: direct loads
-                const int64_t n = wcol0 + j * 16 + g * 4;
-                const int64_t m = wrow0 + i * 16 + li;
-                f32x4 v = acc[i][j];
-                if (bias != nullptr && n < p.N) {
-                    const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
-                }
-                if ((p.rot_tab != nullptr) && (n < p.rot_cols) && ((n & 63) < 32) && m < p.M)
-                    v *= *reinterpret_cast<const f32x4*>(p.rot_tab + (m % p.rot_rows) * 32 + (n & 63));
-                (void)do_act;
-                return v;
-            };
-            auto finish_pre = [&](int i, int j) -> f32x4 {                   // bf16 path: prefetched registers only
-                const int64_t n = wcol0 + j * 16 + g * 4;
-                const int64_t m = wrow0 + i * 16 + li;
-                f32x4 v = acc[i][j];
-                if (bias != nullptr) {
-                    const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
-                }
-                if (pre_rot && (n < p.rot_cols) && ((n & 63) < 32) && m < p.M) {   // host guarantees BN = 128 with rot_tab
-                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % (4 * NJ)], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % (4 * NJ)];
-                    v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
-                }
-                return v;
-            };
-            if (p.c_dtype == MR_DT_F32) {
+            } else {
+                const __bf16* bias = static_cast<const __bf16*>(p.bias);
                 float* C = static_cast<float*>(p.C);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t m = wrow0 + i * 16 + li;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const f32x4 v = finish(i, j, false);
+                        const int64_t n = wcol0 + j * 16 + g * 4;
+                        f32x4 v = acc[i][j];
+                        if (bias != nullptr && n < p.N) {
+                            const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int64_t n = wcol0 + j * 16 + g * 4 + r;
-                            if (m < p.M && n < p.N) C[m * p.ldc + n] = v[r];
+                            for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
                         }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (m < p.M && n + r < p.N) C[m * p.ldc + n + r] = v[r];
                     }
                 }
-            } else {
-                // Direct epilogue: with the transposed accumulators a lane owns 4 consecutive columns of a row, so every
-                // (i, j) block is one 8-byte store per lane (four lanes = one 32-B sector, four j = one 128-B line).
-                // No LDS staging and no workgroup barrier: each wave streams its 64 x BN/2 sub-tile on its own while the
-                // next item's k-tiles are already landing in the ring.
-                __bf16* Cout = static_cast<__bf16*>(p.C);
-                __bf16* C2 = static_cast<__bf16*>(p.c2);
-                const bool has_res = p.residual != nullptr, has_aux = p.aux != nullptr;   // never both (host check)
-                const bool do_act = (p.act == MR_ACT_GELU1702);
-                const int64_t ldc = p.ldc;
-                // Stores are widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 and 4g+4.. of the same row, so one
-                // v_permlane16_swap per dword between the registers of two adjacent 16-column blocks (rows 1,3 of the first
-                // <-> rows 0,2 of the second) leaves every lane with 8 contiguous columns: lane rows g = 0/2 own block 2jp
-                // (columns 0-7 / 8-15), g = 1/3 own block 2jp+1.  A wave instruction then writes 64 contiguous bytes per
-                // row instead of 32 (the 8-byte form was store-issue bound: ~6 us per tile).
-                auto store_pair = [&](__bf16* base, int64_t roff0, bool mok, int jp, bf16x4 va, bf16x4 vb) {
-                    u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                    const int col = wn * (BN / 2) + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;     // within the tile
-                    if (mok && n0 + col < p.N)
-                        *reinterpret_cast<u32x4*>(base + roff0 + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                };
+            }
+        } else {
+            // ---------------- bf16 epilogue: registers only (operands were prefetched during the last k-tile) ----------------
+            auto finish_pre = [&](int i, int j) -> f32x4 {
+                f32x4 v = acc[i][j];
+                if (e_bias != nullptr) {
+                    const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t gm = wrow0 + i * 16 + li;
-                    int64_t orow = gm;
-                    if (p.out_grp > 0) orow = (gm / p.out_grp) * p.out_grp_stride + p.out_grp_off + gm % p.out_grp;
-                    const int64_t roff0 = orow * ldc + n0;                  // element offset of the tile's first column
-                    const bool mok = gm < p.M;
-                    bf16x4 oc[NJ], od[NJ];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                }
+                // "rotary" scale: host guarantees BN = 128, so the wave's 64 columns are one head and (n & 63) = 16 j + 4 g
+                if (pre_rot && j < 2 && wcol0 < e_rot_cols) {
+                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % (4 * NJ)], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % (4 * NJ)];
+                    v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                }
+                return v;
+            };
+            // Stores are widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 and 4g+4.. of the same row, so one
+            // v_permlane16_swap per dword between the registers of two adjacent 16-column blocks (rows 1,3 of the first
+            // <-> rows 0,2 of the second) leaves every lane with 8 contiguous columns: lane rows g = 0/2 own block 2jp
+            // (columns 0-7 / 8-15), g = 1/3 own block 2jp+1.  A wave instruction then writes 64 contiguous bytes per
+            // row instead of 32 (the 8-byte form was store-issue bound).
+            auto store_pair = [&](__bf16* rowp, bool mok, int jp, bf16x4 va, bf16x4 vb) {
+                u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                if (mok && col < eN) *reinterpret_cast<u32x4*>(rowp + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            };
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        f32x4 v = finish_pre(i, j);
-                        bf16x4 o;
+            for (int i = 0; i < 4; ++i) {
+                const int gm = wrow0 + i * 16 + li;
+                const bool mok = gm < eM;
+                const int64_t roff = (int64_t)out_row(gm) * e_ldc;
+                __bf16* const crow = eC + roff;
+                __bf16* const c2row = eC2 + roff;
+                bf16x4 oc[NJ], od[NJ];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                        od[j] = o;
-                        if (do_act) {
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = finish_pre(i, j);
+                    bf16x4 o;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[r]));   // v_rcp / v_exp: ~1 ulp
-                                o[r] = (__bf16)(v[r] * sg);
-                                od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
-                            }
+                    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                    od[j] = o;
+                    if (do_act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sg = sigmoid1702(v[r]);
+                            o[r] = (__bf16)(v[r] * sg);
+                            od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
                         }
-                        if (has_res || has_aux) {
-                            const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
-                                o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
-                        }
-                        oc[j] = o;
                     }
+                    if (has_res || has_aux) {
+                        const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
 #pragma unroll
-                    for (int jp = 0; jp < NJ / 2; ++jp) {
-                        if (C2 != nullptr) store_pair(C2, roff0, mok, jp, od[2 * jp], od[2 * jp + 1]);
-                        store_pair(Cout, roff0, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
+                        for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
+                            o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
                     }
-                    if (NJ & 1) {                                          // BN = 96: the odd block keeps 8-byte stores
-                        const int col = wn * (BN / 2) + (NJ - 1) * 16 + g * 4;
-                        if (mok && n0 + col < p.N) {
-                            if (C2 != nullptr) *reinterpret_cast<bf16x4*>(C2 + roff0 + col) = od[NJ - 1];
-                            *reinterpret_cast<bf16x4*>(Cout + roff0 + col) = oc[NJ - 1];
-                        }
+                    oc[j] = o;
+                }
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    if (eC2 != nullptr) store_pair(c2row, mok, jp, od[2 * jp], od[2 * jp + 1]);
+                    store_pair(crow, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
+                }
+                if (NJ & 1) {                                          // BN = 96: the odd block keeps 8-byte stores
+                    const int col = wcol0 + (NJ - 1) * 16 + g * 4;
+                    if (mok && col < eN) {
+                        if (eC2 != nullptr) *reinterpret_cast<bf16x4*>(c2row + col) = od[NJ - 1];
+                        *reinterpret_cast<bf16x4*>(crow + col) = oc[NJ - 1];
                     }
                 }
             }
         }
+        MR_STAMP(3);
+#ifdef MR_DIAG_STAMPS
+        ++nstamp;
+#endif
         cw += G;
         ci = GET_ITEM(cw);
     }
