@@ -9,6 +9,7 @@ Data layout in HBM (bf16 unless noted; M = sequences x positions of a tower):
   the [S,S] attention mask never exists (one int32 code per position); the "rotary" is a [positions, 32] fp32 table.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -100,22 +101,33 @@ class PretrainEngine:
         # backward scratch
         self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
         self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
-        self.T_a = z(Mmax, H)
-        self.T_d1, self.T_d2 = z(Mmax, H), z(Mmax, H)
-        self.T_q = z(Mmax, 3 * H)
-        self.T_h = z(Mmax, 4 * H)
-        self.delta = f(max(t.nseq * t.S for t in (self.tv, self.ta, self.tj, self.ts)) * d.nh)
-        if ops.GEMM_WORKSPACE is None or ops.GEMM_WORKSPACE.device != dev:
-            ops.GEMM_WORKSPACE = f(32 * 1024 * 1024)            # 128 MiB of fp32 split-K partials
-        self.ln_ws = ops.layernorm_bwd_workspace(H, dev)
-        self.cs_ws = ops.colsum_workspace(4 * H, dev)
+        # Two scratch sets: the audio tower runs on a side stream concurrently with the vision tower (forward and
+        # backward), so that one tower's kernels fill the CUs the other leaves idle (partial last rounds of the
+        # persistent GEMMs, small kernels).  `self.cur` is the set the ops being ISSUED right now may use.
+        class Scratch:
+            pass
+
+        def make_scratch(Ms, Gs, Ps):
+            sc = Scratch()
+            sc.T_a, sc.T_d1, sc.T_d2 = z(Ms, H), z(Ms, H), z(Ms, H)
+            sc.T_q, sc.T_h = z(Ms, 3 * H), z(Ms, 4 * H)
+            sc.delta = f(Ms * d.nh)
+            sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
+            sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
+            sc.cs_ws = ops.colsum_workspace(4 * H, dev)
+            sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
+            sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
+            sc.Dpatch = z(Ps, H)
+            return sc
+        self.sc_main = make_scratch(Mmax, max(self.Gv, self.Ga), max(d.Nv * d.hw, d.Na * d.a_len))   # also serves audio when issued in line
+        self.sc_side = make_scratch(self.ta.M, self.Ga, d.Na * d.a_len)
+        self.cur = self.sc_main
+        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
+        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.dXpool = z(self.n_pool, H)
         self.d_hj = z(self.tj.M, H)
         self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
         self.d_audio_seq, self.d_imgs_seq = z(self.Ga, H), z(self.Gv, H)
-        self.d_pool_q, self.d_pool_po, self.d_pool_qin = z(max(self.Gv, self.Ga), H), z(max(self.Gv, self.Ga), H), z(max(self.Gv, self.Ga), H)
-        self.d_k, self.d_v = z(max(self.tv.M, self.ta.M), H), z(max(self.tv.M, self.ta.M), H)   # CLS rows stay zero
-        self.Dpatch = z(max(d.Nv * d.hw, d.Na * d.a_len), H)
         # static gather lists: patch rows of a [nseq, S] grid without the CLS rows
         self.unpad_v = self._unpad_csr(d.Nv, d.Sv)
         self.unpad_a = self._unpad_csr(d.Na, d.Sa)
@@ -125,6 +137,18 @@ class PretrainEngine:
         self._plan_caps = {}
         self._plan_views = {}
         self.plan_frozen = False
+
+    def _on_side(self, fn):
+        """Issue fn()'s kernels on the side stream (forked from / joined to the current stream by the caller)."""
+        main_ws = ops.GEMM_WORKSPACE
+        self.cur, ops.GEMM_WORKSPACE = self.sc_side, self.sc_side.gemm_ws
+        try:
+            if os.environ.get('MR_NO_SIDE_STREAM') == '1':       # (A/B switch) same work, issued in line
+                return fn()
+            with torch.cuda.stream(self.side_stream):
+                return fn()
+        finally:
+            self.cur, ops.GEMM_WORKSPACE = self.sc_main, main_ws
 
     def _unpad_csr(self, nseq, S):
         rows = (np.arange(nseq)[:, None] * S + 1 + np.arange(S - 1)[None]).reshape(-1).astype(np.int32)
@@ -183,31 +207,31 @@ class PretrainEngine:
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
         gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K)."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
-        T_a, T_q, T_h = self.T_a[:M], self.T_q[:M], self.T_h[:M]
-        Dcur, Dmid, Dnext = D, self.T_d1[:M], self.T_d2[:M]
+        T_a, T_q, T_h = self.cur.T_a[:M], self.cur.T_q[:M], self.cur.T_h[:M]
+        Dcur, Dmid, Dnext = D, self.cur.T_d1[:M], self.cur.T_d2[:M]
         k = 2 * st.L + 1
         ops.layernorm_bwd(Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
-                          G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.ln_ws)
+                          G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.cur.ln_ws)
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
             ops.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
             ops.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
-                              G[n['g2']], G[n['b2']], self.ln_ws, dx_add=Dcur)               # Dmid = d xmid
+                              G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur)               # Dmid = d xmid
             ops.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
-            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.delta, T_q, rot, st.nseq, st.S, nh)
-            ops.colsum(T_h, G[n['bb1']], self.cs_ws)
-            ops.colsum(T_q, G[n['bqkv']], self.cs_ws)
+            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh)
+            ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws)
+            ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws)
             ops.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
             ops.gemm_grouped([ops.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
                               ops.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
                               ops.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
                               ops.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
             ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
-                              G[n['g1']], G[n['b1']], self.ln_ws, dx_add=Dmid)               # Dnext = d X[l]
+                              G[n['g1']], G[n['b1']], self.cur.ln_ws, dx_add=Dmid)               # Dnext = d X[l]
             Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
         ops.layernorm_bwd(Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
-                          G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.ln_ws)
+                          G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.cur.ln_ws)
         return Dcur
 
     # ------------------------------------------------------------------------------------------ CLS tower head + pool
@@ -230,25 +254,25 @@ class PretrainEngine:
         """d_seq: grad wrt the pooled sequence output; d_cls: grad wrt the cls output.  Returns D = grad wrt st.xin."""
         W, G, nh, M = self.p.w, self.p.g, st.H // 64, st.M
         Gn = qin.shape[0]
-        d_po, d_q, d_qin = self.d_pool_po[:Gn], self.d_pool_q[:Gn], self.d_pool_qin[:Gn]
-        d_k, d_v = self.d_k[:M], self.d_v[:M]
-        ops.colsum(d_seq, G[f'{prefix_pool}/out/bias'], self.cs_ws)
+        d_po, d_q, d_qin = self.cur.d_pool_po[:Gn], self.cur.d_pool_q[:Gn], self.cur.d_pool_qin[:Gn]
+        d_k, d_v = self.cur.d_k[:M], self.cur.d_v[:M]
+        ops.colsum(d_seq, G[f'{prefix_pool}/out/bias'], self.cur.cs_ws)
         ops.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
         ops.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
         ops.poolattn_bwd(q, k, v, pool_rows, probs, d_po, d_q, d_k, d_v, nh)
-        ops.colsum(d_q, G[f'{prefix_pool}/query/bias'], self.cs_ws)
+        ops.colsum(d_q, G[f'{prefix_pool}/query/bias'], self.cur.cs_ws)
         ops.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
         ops.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
-        ops.colsum(d_k, G[f'{prefix_pool}/key/bias'], self.cs_ws)
+        ops.colsum(d_k, G[f'{prefix_pool}/key/bias'], self.cur.cs_ws)
         ops.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
         ops.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
-        ops.colsum(d_v, G[f'{prefix_pool}/value/bias'], self.cs_ws)
+        ops.colsum(d_v, G[f'{prefix_pool}/value/bias'], self.cur.cs_ws)
         ops.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
         ops.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
         ops.rows_mean_bwd(d_qin, pool_rows, D)
         # cls head
         cls_in = self._cls_view(st.xf, st.nseq, st.S)
-        ops.colsum(d_cls, G[f'{prefix_t}/cls_proj/bias'], self.cs_ws)
+        ops.colsum(d_cls, G[f'{prefix_t}/cls_proj/bias'], self.cur.cs_ws)
         ops.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
         Dc = self._cls_view(D, st.nseq, st.S)
         ops.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
@@ -273,20 +297,26 @@ class PretrainEngine:
         batch = {'images': images, 'audio_clips': audio_clips}
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
 
+        # vision tower (main stream) and audio tower (side stream) are independent until the joint tower
+        def audio_fwd():
+            # audio tower (modeling.py:433-476): the stride-2 conv is a GEMM over 2 consecutive hops = 130 inputs
+            audio = batch['audio_clips'].reshape(d.Na * d.a_len, d.a_patch * 65)
+            ops.pad_cols(audio, self.a_in)
+            a_view = self.a_in[:, :d.a_patch * 65]
+            ops.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
+            self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
+                                          self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
+                                          self.a_probs, self.audio_seq, self.a_cls)
+        main = torch.cuda.current_stream()
+        self.side_stream.wait_stream(main)
+        self._on_side(audio_fwd)
         # vision tower (modeling.py:379-430)
         images = self._images2d = batch['images'].reshape(d.Nv * d.hw, d.pp3)
         ops.gemm(images, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                       self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                       self.v_probs, self.imgs_seq, self.v_cls)
-        # audio tower (modeling.py:433-476): the stride-2 conv is a GEMM over 2 consecutive hops = 130 inputs
-        audio = batch['audio_clips'].reshape(d.Na * d.a_len, d.a_patch * 65)
-        ops.pad_cols(audio, self.a_in)
-        a_view = self.a_in[:, :d.a_patch * 65]
-        ops.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
-        self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
-                                      self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
-                                      self.a_probs, self.audio_seq, self.a_cls)
+        main.wait_stream(self.side_stream)
         # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         emb = W['token_encoder/Embed_0/embedding']
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
@@ -370,8 +400,11 @@ class PretrainEngine:
         Three stages, in the order the flat gradient buffer is laid out (params.py), so that a data-parallel caller can
         all-reduce each finished range while the next stage runs: [scales, head, span, joint, token] -> audio -> vision."""
         self.backward_stage_joint()
-        self.backward_stage_audio()
+        main = torch.cuda.current_stream()
+        self.side_stream.wait_stream(main)
+        self._on_side(self.backward_stage_audio)
         self.backward_stage_vision()
+        main.wait_stream(self.side_stream)
 
     def backward_stage_joint(self):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
@@ -389,7 +422,7 @@ class PretrainEngine:
         Ds = self.Ds
         Ds.zero_()
         cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
-        ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cs_ws)
+        ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cur.cs_ws)
         ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
         ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
         Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
@@ -400,7 +433,7 @@ class PretrainEngine:
 
         # joint tower
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
-        ops.colsum(self.d_hj, G['head/bias'], self.cs_ws)
+        ops.colsum(self.d_hj, G['head/bias'], self.cur.cs_ws)
         ops.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
         Dj = self.Dj
         ops.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
@@ -417,9 +450,9 @@ class PretrainEngine:
         Da = self._tower_with_pool_backward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                             self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
                                             self.a_probs, self.d_audio_seq, self.d_a_cls, self.Da)
-        Dp = self.Dpatch[:d.Na * d.a_len]
+        Dp = self.cur.Dpatch[:d.Na * d.a_len]
         ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
-        ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cs_ws)
+        ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cur.cs_ws)
         ops.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
     def backward_stage_vision(self):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
@@ -427,9 +460,9 @@ class PretrainEngine:
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                             self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                             self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv)
-        Dp = self.Dpatch[:d.Nv * d.hw]
+        Dp = self.cur.Dpatch[:d.Nv * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
-        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cs_ws)
+        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
         ops.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
 
     def loss_info(self):
