@@ -317,19 +317,24 @@ class PretrainEngine:
                                       self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                       self.v_probs, self.imgs_seq, self.v_cls)
         main.wait_stream(self.side_stream)
-        # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         emb = W['token_encoder/Embed_0/embedding']
+
+        def span_fwd():       # needs only the token table and the plan: runs beside the joint tower
+            # span tower on the chosen spans (modeling.py:479-504)
+            ops.segment_sum([emb], self._pl('span_gather_indptr'), self._pl('span_gather_idx'), ts.xin)
+            ops.fill_rows(W['span_encoder/transformer/cls'], ts.xin, ts.nseq, ts.S, 0)
+            self.encoder_forward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'))
+            ops.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
+                     bias=W['span_encoder/transformer/cls_proj/bias'])
+        self.side_stream.wait_stream(main)
+        self._on_side(span_fwd)
+        # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
         self.encoder_forward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'))
         ops.gemm(tj.xf, W['head/kernel'], self.hj, bias=W['head/bias'])
         ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)
         ops.segment_sum([self.a_cls], self._pl('acls_indptr'), self._pl('acls_idx'), self.acls_g)
-        # span tower on the chosen spans (modeling.py:479-504)
-        ops.segment_sum([emb], self._pl('span_gather_indptr'), self._pl('span_gather_idx'), ts.xin)
-        ops.fill_rows(W['span_encoder/transformer/cls'], ts.xin, ts.nseq, ts.S, 0)
-        self.encoder_forward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'))
-        ops.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
-                 bias=W['span_encoder/transformer/cls_proj/bias'])
+        main.wait_stream(self.side_stream)
         # unit-normalise * temperature into the packed buffer E (pretrain_model.py:239-257)
         for src, names, si in self._norm_sections():
             o, n = self.sec[names[0]][0], sum(self.sec[k][1] for k in names)
@@ -418,19 +423,24 @@ class PretrainEngine:
                                     self.dls[si:si + 1])
         ops.cast_f32_to_bf16(self.dls, G['contrastive_scales'])
 
-        # span tower (only its cls output is used: gradient enters at the CLS rows)
-        Ds = self.Ds
-        Ds.zero_()
-        cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
-        ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cur.cs_ws)
-        ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
-        ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
-        Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
-        ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
-        if Ds.data_ptr() != self.Ds.data_ptr():            # the joint tower reuses the rotating scratch: keep a copy
-            self.Ds.copy_(Ds)
+        def span_bwd():
+            # span tower (only its cls output is used: gradient enters at the CLS rows)
             Ds = self.Ds
+            Ds.zero_()
+            cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
+            ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cur.cs_ws)
+            ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
+            ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
+            Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
+            ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
+            if Ds.data_ptr() != self.Ds.data_ptr():            # the joint tower reuses the rotating scratch: keep a copy
+                self.Ds.copy_(Ds)
+                Ds = self.Ds
 
+            return Ds
+        main = torch.cuda.current_stream()
+        self.side_stream.wait_stream(main)
+        Ds = self._on_side(span_bwd)
         # joint tower
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
         ops.colsum(self.d_hj, G['head/bias'], self.cur.cs_ws)
@@ -438,6 +448,7 @@ class PretrainEngine:
         Dj = self.Dj
         ops.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
         Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
+        main.wait_stream(self.side_stream)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
         ops.segment_sum([Dj, Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
         ops.segment_sum([Dj], self._pl('audT_indptr'), self._pl('audT_idx'), self.d_audio_seq)
