@@ -37,26 +37,37 @@ def algorithmic_flops_per_record(config, train=True):
     return fwd * (3 if train else 1)
 
 
-def cpu_baseline(config, seconds_hint=20):
-    """The oracle (torch CPU restatement of the reference's step, fp32) on ONE record: forward + backward."""
+def cpu_baseline(config, threads=None):
+    """The oracle (torch CPU restatement of the reference's step, fp32) timed on a BOUNDED sample of the bench workload:
+    forward + backward of ONE record with every tower truncated to a quarter of its depth (3/3/3/1 of 12/12/12/4
+    layers at base), the same widths, sequence lengths and batch structure; the time is scaled to the full depth by
+    the ratio of algorithmic FLOPs and reported in the metric's unit."""
+    import copy
     import torch
     from oracle import ref_torch as R
     from merlot_reserve_amd.params import ParamStore
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from tests.util import oracle_batch, oracle_draws
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    store = ParamStore(config, 'cpu', seed=0, with_optimizer=False)
+    threads = threads or min(os.cpu_count() or 1, 32)          # more threads than that only add fork/join overhead
+    torch.set_num_threads(threads)
+    small = copy.deepcopy(config)
+    m = small['model']
+    for k in ('vit_num_layers', 'audio_num_layers', 'joint_num_layers', 'span_num_layers'):
+        m[k] = max(1, m[k] // 4)
+    scale = algorithmic_flops_per_record(config) / algorithmic_flops_per_record(small)
+    store = ParamStore(small, 'cpu', seed=0, with_optimizer=False)
     params = store.master_tree()
-    batch = make_batch(config, 1, seed=1234, device='cpu', float_dtype=torch.float32)
-    splits, z = make_draws(config, 1, seed=1234)
+    batch = make_batch(small, 1, seed=1234, device='cpu', float_dtype=torch.float32)
+    splits, z = make_draws(small, 1, seed=1234)
     osp, oz = oracle_draws(splits, z)
     ob = oracle_batch(batch)
     t0 = time.time()
-    R.loss_and_grads(params, config, ob, osp, oz)
+    R.loss_and_grads(params, small, ob, osp, oz)
     dt = time.time() - t0
-    return {'value': 2.0 / dt, 'unit': 'video-segments/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 record (2 video-segment groups x 8 frames) forward+backward, fp32 torch-CPU oracle, {dt:.1f} s'}
+    return {'value': 2.0 / (dt * scale), 'unit': 'video-segments/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle (fp32 torch-CPU port) forward+backward of 1 record (2 video-segment groups x 8 frames) with each '
+                      f'tower at 1/4 depth ({m["vit_num_layers"]}/{m["audio_num_layers"]}/{m["joint_num_layers"]}/{m["span_num_layers"]} '
+                      f'layers): {dt:.1f} s measured, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
 def main():
@@ -138,8 +149,15 @@ def main():
         n = len(ops.GEMM_PROFILE)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': ach, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': None, 'launches': n,
+        traffic = None                # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')   # counters cannot be read from inside this process
+        if os.path.exists(pmc):
+            p = json.load(open(pmc))
+            if p['workload'] == {'model': args.model, 'records_per_gpu': B}:
+                g = [v for k, v in p['kernels'].items() if 'gemm' in k]
+                traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
+        roof = {'bound': 'mfma', 'kernel': 'g256::gemm256_kernel<*> (+ gemm_bf16_kernel for small shapes)', 'achieved': ach, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per GEMM launch (PMC, profiles/r01_pmc_hbm_traffic.json)', 'launches': n,
                 'avg_launch_us': ms * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
 
     if rank == 0:
