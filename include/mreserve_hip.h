@@ -39,6 +39,11 @@ extern "C" {
 
 int mr_version(void);
 const char* mr_last_error(void);
+/* Tuning / diagnostic knobs (process-wide, not thread-safe against concurrent launches).  Known names:
+ *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 256 : forces the output-tile width of the 256-row GEMM
+ *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
+ * Returns MR_EINVAL for an unknown name. */
+int mr_set_option(const char* name, int value);
 
 /* ---- GEMM with fused epilogue (flax Dense / DenseGeneral: M:228-236, 252-255, 371, 402, 453, 631;
  *      and their dgrad / wgrad) --------------------------------------------------------------
@@ -83,15 +88,30 @@ int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream);
 int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                      float* mean, float* rstd, int64_t rows, int64_t H, float eps, void* stream);
 /* dx = LN backward (+ dx_add when not NULL: the other gradient path of the residual stream; dx_add may alias dx);
- * dgamma/dbeta are reduced over rows into bf16 [H] each.  partials: fp32 workspace of mr_layernorm_bwd_workspace(H) bytes. */
+ * dgamma/dbeta are reduced over rows into bf16 [H] each.  partials: fp32 workspace of mr_layernorm_bwd_workspace(H) bytes.
+ * dgamma = dbeta = NULL defers that reduction: `partials` then holds mr_layernorm_bwd_nparts(rows) fp32 rows of
+ * [dgamma(H) | dbeta(H)] for a later mr_reduce_partials job {partials, nparts, 2H, split = H, dgamma, dbeta}. */
 int64_t mr_layernorm_bwd_workspace(int64_t H);
+int64_t mr_layernorm_bwd_nparts(int64_t rows);
 int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
                      const float* mean, const float* rstd, void* dx, int64_t lddx, const void* dx_add, int64_t ldadd,
                      void* dgamma, void* dbeta, void* partials, int64_t rows, int64_t H, void* stream);
 
-/* ---- column sum: out[n] = bf16(sum_m x[m,n])  (bias gradients) ---- */
+/* ---- column sum: out[n] = bf16(sum_m x[m,n])  (bias gradients) ----
+ * out = NULL defers the final reduction: `partials` holds mr_colsum_nparts(rows) fp32 rows of [N]. */
 int64_t mr_colsum_workspace(int64_t N);
+int64_t mr_colsum_nparts(int64_t rows);
 int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream);
+
+/* ---- several deferred column reductions in ONE launch (the 2 LayerNorm + 2 bias gradients of a transformer layer):
+ * out0[c] = bf16(sum_p partials[p, c]) for c < split, out1[c - split] for split <= c < ncols; fixed order. count <= 8. */
+typedef struct {
+    const float* partials;
+    int32_t nparts, ncols, split;
+    void* out0;
+    void* out1;
+} mr_reduce_job;
+int mr_reduce_partials(const mr_reduce_job* jobs, int32_t count, void* stream);
 
 /* ---- fused multi-head attention (M:188-200 + flax dot_product_attention_weights) ----
  * qkv: [nseq*S, 3*H] bf16 rows = [Q(H) | K(H) | V(H)], head h at columns h*64..h*64+63, q/k already

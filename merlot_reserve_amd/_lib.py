@@ -24,9 +24,15 @@ class GemmArgs(C.Structure):
                 ('workspace', vp), ('workspace_bytes', i64)]
 
 
+class ReduceJob(C.Structure):
+    """mirrors mr_reduce_job"""
+    _fields_ = [('partials', vp), ('nparts', i32), ('ncols', i32), ('split', i32), ('out0', vp), ('out1', vp)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/mreserve_hip.h
 PROTOTYPES = {
     'mr_version': (i32, []),
+    'mr_set_option': (i32, [C.c_char_p, i32]),
     'mr_last_error': (C.c_char_p, []),
     'mr_gemm': (i32, [C.POINTER(GemmArgs), vp]),
     'mr_gemm_grouped': (i32, [C.POINTER(GemmArgs), i32, vp]),
@@ -34,6 +40,9 @@ PROTOTYPES = {
     'mr_layernorm_bwd_workspace': (i64, [i64]),
     'mr_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp]),
     'mr_colsum_workspace': (i64, [i64]),
+    'mr_colsum_nparts': (i64, [i64]),
+    'mr_layernorm_bwd_nparts': (i64, [i64]),
+    'mr_reduce_partials': (i32, [C.POINTER(ReduceJob), i32, vp]),
     'mr_colsum': (i32, [vp, i64, i64, i64, vp, vp, vp]),
     'mr_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
     'mr_attention_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),

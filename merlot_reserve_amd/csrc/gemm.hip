@@ -301,10 +301,11 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
 
 bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s);
 
+extern int g_mr_opt_v1_only;        // mr_set_option("gemm_v1_only")
 static int use_gemm256() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MR_GEMM_V1_ONLY"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v;
+    return v && !g_mr_opt_v1_only;
 }
 
 extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {

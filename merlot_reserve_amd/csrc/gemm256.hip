@@ -17,6 +17,21 @@
 #define MR_DIAG_K(k) (unsigned)(k)
 #endif
 
+#if defined(MR_DIAG_NOFRAG) || defined(MR_DIAG_NOMFMA)   /* timing-only builds: no LDS fragment reads */
+#define MR_DIAG_FRAG(x) bf16x8{}
+#else
+#define MR_DIAG_FRAG(x) (x)
+#endif
+#ifdef MR_DIAG_NOMFMA
+#define MR_DIAG_MFMA(x) do {} while (0)
+#else
+#define MR_DIAG_MFMA(x) x
+#endif
+#ifdef MR_DIAG_NOLOAD      /* timing-only build (wrong results): no LDS-DMA at all, cursors still advance */
+#define MR_DMA(...) do {} while (0)
+#else
+#define MR_DMA(...) __builtin_amdgcn_raw_ptr_buffer_load_lds(__VA_ARGS__)
+#endif
 #ifdef MR_DIAG_STAMPS
 #define MR_STAMP(slot)                                                                              \
     do {                                                                                            \
@@ -32,9 +47,19 @@ namespace g256 {
 
 constexpr int BM = 256, BK = 64;
 constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
-constexpr int STAGE_B = 128 * BK * 2;       // 16 KiB (B is always staged 128 wide)
-constexpr int STAGE = STAGE_A + STAGE_B;    // 48 KiB
-constexpr int NSTAGE = 3;
+// B is staged 128 wide (BN = 128 | 96: 48-KiB stages, 3-stage ring, two k-tiles ahead) or 256 wide (BN = 256: 64-KiB
+// stages, 2-stage ring, one k-tile ahead).  The k-loop is bound by the LDS-DMA fill rate of a CU (~60-70 GB/s measured
+// with the MFMAs compiled out), so the 256 x 256 tile -- 2/3 of the bytes per FLOP -- is the fast one wherever the
+// problem has enough tiles for it.
+template <int BN> struct Geo {
+    static constexpr int BW = (BN == 256) ? 256 : 128;
+    static constexpr int STAGE_B = BW * BK * 2;
+    static constexpr int STAGE = STAGE_A + STAGE_B;
+    static constexpr int NSTAGE = (BN == 256) ? 2 : 3;
+    static constexpr int NBP = BW / 64;                    // 1-KiB B pieces per wave and k-tile
+    static constexpr int NPIECE = 4 + NBP;
+    static constexpr int WAITN = (NSTAGE - 2) * NPIECE;    // pieces that may stay in flight behind a k-tile's barrier
+};
 constexpr unsigned OOB = 0x80000000u;      // >= any operand extent (< 2^31 B, checked on the host); + soffset cannot wrap
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -128,7 +153,13 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
 template <int BN, bool TA, bool TB>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     constexpr int NJ = BN / 32;                  // 16-col MFMA tiles per wave (wave tile = 64 x BN/2)
-    constexpr int LDC = BN + 8;
+    constexpr int BW = Geo<BN>::BW, STAGE = Geo<BN>::STAGE, NSTAGE = Geo<BN>::NSTAGE, NBP = Geo<BN>::NBP;
+    constexpr int WAITN = Geo<BN>::WAITN;
+    // Epilogue operands: fetched EARLY (top of the last k-tile, see PRE_LOAD_B64) by the 3-stage variants; the 256-wide
+    // variant has no registers to park them in, and its 2-stage ring is drained (vmcnt(0)) behind every k-tile anyway, so
+    // it loads them in the epilogue itself, row block by row block.
+    constexpr bool EARLY = BN != 256;
+    constexpr int NPRE = EARLY ? 4 * NJ : 1;
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     // ---- issue cursor: runs two k-tiles ahead of the compute cursor, across item boundaries ----
     int iw = bperm, ik = 0, istage = 0;
     Item ii = GET_ITEM(iw);
-    unsigned ao0, ao1, ao2, ao3, bo0, bo1, a_step = 0, b_step = 0;
+    unsigned ao0, ao1, ao2, ao3, bo0, bo1, bo2 = 0, bo3 = 0, a_step = 0, b_step = 0;
     __amdgpu_buffer_rsrc_t ra, rb;      // wave-uniform descriptors of the issue cursor's problem (zero-fill beyond the extent)
 #define SET_OFFSETS()                                                                                                   \
     do {                                                                                                                \
@@ -162,8 +193,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ii.m0, M_);                                                  \
         ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ii.m0, M_);                                                  \
         ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ii.m0, M_);                                                  \
-        bo0 = piece_src<!TB, 128>(wave * 2 + 0, lane, ldb_, ii.n0, N_);                                                 \
-        bo1 = piece_src<!TB, 128>(wave * 2 + 1, lane, ldb_, ii.n0, N_);                                                 \
+        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ii.n0, N_);                                                \
+        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ii.n0, N_);                                                \
+        if (NBP == 4) {                                                                                                 \
+            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ii.n0, N_);                                            \
+            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ii.n0, N_);                                            \
+        }                                                                                                               \
     } while (0)
     // The 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any), issued in two halves so that they can
     // sit between the two MFMA batches of a k-tile instead of stalling the wave right after the barrier.
@@ -173,20 +208,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         if (ii.valid) {                                                                                                 \
             char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
             const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step;                                                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
+            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
+            if (NBP == 4) MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);                                  \
         }                                                                                                               \
     } while (0)
 #define ISSUE_B()                                                                                                       \
     do {                                                                                                                \
         if (ii.valid) {                                                                                                 \
             char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
-            char* sb_ = smem + istage * STAGE + STAGE_A + wave * 2048;                                                  \
+            char* sb_ = smem + istage * STAGE + STAGE_A + wave * (NBP * 1024);                                          \
             const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step, sb = MR_DIAG_K(ii.kt0 + ik) * b_step;                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);              \
+            if (NBP != 4) MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);                                  \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                                                       \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);                                                \
+            if (NBP == 4) {                                                                                             \
+                MR_DMA(rb, MR_LDS_PTR(void, sb_ + 2048), 16, bo2, sb, 0, 0);                                            \
+                MR_DMA(rb, MR_LDS_PTR(void, sb_ + 3072), 16, bo3, sb, 0, 0);                                            \
+            }                                                                                                           \
             istage = (istage == NSTAGE - 1) ? 0 : istage + 1;                                                           \
             if (++ik == ii.nkt) {                                                                                       \
                 iw += G;                                                                                                \
@@ -198,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     } while (0)
 #define ISSUE_NEXT(issued) do { ISSUE_A(issued); ISSUE_B(); } while (0)
 
+
     if (ii.valid) SET_OFFSETS();
     int cw = bperm, cstage = 0;
 #ifdef MR_DIAG_STAMPS
@@ -207,10 +248,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     Item ci = GET_ITEM(cw);
     if (!ci.valid) return;
     bool issued;
+    // all but the youngest WAITN pieces have landed (everything when nothing was issued this step: the stream is ending)
+#define RING_WAIT(issued)                                                                                               \
+    do {                                                                                                                \
+        if (WAITN == 6 && (issued)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    } while (0)
+    static_assert(WAITN == 6 || WAITN == 0, "RING_WAIT spells the counts out");
     ISSUE_NEXT(issued);
-    ISSUE_NEXT(issued);
-    if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NSTAGE == 3) ISSUE_NEXT(issued);
+    RING_WAIT(issued);
     __builtin_amdgcn_s_barrier();
 
     while (ci.valid) {
@@ -242,38 +289,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
         const bool do_act = (pc.act == MR_ACT_GELU1702);
         const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
-        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN == 128;
+        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;
         const void* const dummy = pc.A;
         auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
-        u32x2 pre2[4 * NJ];     // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
+        u32x2 pre2[NPRE];       // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
         // k-loop with the LAST k-tile peeled: the prefetch registers are written (asm) and consumed in straight-line code,
         // so no loop-carried copy of a register whose load is still in flight can be generated.
         auto kstep = [&]() {
             // the stage being refilled was last read one step ago, behind that step's barrier
             const char* As = smem + cstage * STAGE;
             const char* Bs = As + STAGE_A;
+            // Units of 16 MFMAs: (kk, half) with the wave's B columns taken JH 16-column blocks at a time (all of them when
+            // NJ <= 4), so the fragments in flight stay at A(kk) + 2 B halves even for the 128-column waves of BN = 256.
+            constexpr int NH = (NJ > 4) ? 2 : 1, JH = NJ / NH;
+            bf16x8 af[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[4], bfr[NJ];
+            for (int u = 0; u < 2 * NH; ++u) {
+                const int kk = u / NH, h = u % NH;
+                bf16x8 bfr[JH];
+                if (h == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = frag<TA, 256>(As, wm * 64 + i * 16, kk, lane);
+                    for (int i = 0; i < 4; ++i) af[i] = MR_DIAG_FRAG((frag<TA, 256>(As, wm * 64 + i * 16, kk, lane)));
+                }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bfr[j] = frag<!TB, 128>(Bs, wn * (BN / 2) + j * 16, kk, lane);
-                // the DMA issue rides in the shadow of the fragment reads' latency / the other half's MFMAs
-                if (kk == 0) ISSUE_A(issued); else ISSUE_B();
+                for (int j = 0; j < JH; ++j) bfr[j] = MR_DIAG_FRAG((frag<!TB, BW>(Bs, wn * (BN / 2) + (h * JH + j) * 16, kk, lane)));
+                // the DMA issue rides in the shadow of the fragment reads' latency / the previous unit's MFMAs
+                if (u == 0) ISSUE_A(issued);
+                if (u == NH) ISSUE_B();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < JH; ++j)
+                        MR_DIAG_MFMA(acc[i][h * JH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][h * JH + j], 0, 0, 0));
             }
             // k-tile cseq+1 must have landed before anyone reads it: everything but this step's 6 pieces (this also
             // retires the previous item's epilogue stores, which were issued before them)
-            if (issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RING_WAIT(issued);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
@@ -282,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         for (int t = 0; t + 1 < ci.nkt; ++t) kstep();
         MR_STAMP(1);
         {
-            if (epi_bf16) {
+            if (EARLY && epi_bf16) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
@@ -299,15 +353,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                         for (int j = 0; j < NJ; ++j) {
                             const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
                             const void* src_ = (mok && gn < eN) ? (const void*)(rowp + gn) : dummy;
-                            PRE_LOAD_B64(pre2[i * NJ + j], src_);
+                            PRE_LOAD_B64(pre2[(i * NJ + j) % NPRE], src_);
                         }
                     } else if (pre_rot) {
                         const int rr = (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
                         const float* rowp = e_rot + (int64_t)rr * 32 + g * 4;
 #pragma unroll
-                        for (int j2 = 0; j2 < 4; ++j2) {  // BN = 128: the wave's 64 columns are one head; dims < 32 are j = 0, 1
+                        for (int j2 = 0; j2 < 4; ++j2) {  // the wave's columns are whole heads (64); dims < 32 are j & 3 = 0, 1
                             const void* src_ = mok ? (const void*)(rowp + (j2 >> 1) * 16 + (j2 & 1) * 2) : dummy;
-                            PRE_LOAD_B64(pre2[(i * 4 + j2) % (4 * NJ)], src_);
+                            PRE_LOAD_B64(pre2[(i * 4 + j2) % NPRE], src_);
                         }
                     }
                 }
@@ -316,11 +370,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         }
 
         MR_STAMP(2);
-        if (epi_bf16) {
+        if (EARLY && epi_bf16) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) reg_fence(pbias[j]);
 #pragma unroll
-            for (int k = 0; k < 4 * NJ; ++k) reg_fence(pre2[k]);
+            for (int k = 0; k < NPRE; ++k) reg_fence(pre2[k]);
         }
         const int m0 = ci.m0, n0 = ci.n0;
         const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
@@ -361,16 +415,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             }
         } else {
             // ---------------- bf16 epilogue: registers only (operands were prefetched during the last k-tile) ----------------
+            if (!EARLY && e_bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int gn = wcol0 + j * 16 + g * 4;
+                    pbias[j] = *reinterpret_cast<const u32x2*>(gn < eN ? e_bias + gn : e_bias);
+                }
+            }
             auto finish_pre = [&](int i, int j) -> f32x4 {
                 f32x4 v = acc[i][j];
+                if (!EARLY) {
+                    if (e_bias != nullptr) {
+                        const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                    }
+                    if (pre_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
+                        const int gm = wrow0 + i * 16 + li;
+                        const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+                        v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (j & 1) * 16 + g * 4);
+                    }
+                    return v;
+                }
                 if (e_bias != nullptr) {
                     const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
                 }
-                // "rotary" scale: host guarantees BN = 128, so the wave's 64 columns are one head and (n & 63) = 16 j + 4 g
-                if (pre_rot && j < 2 && wcol0 < e_rot_cols) {
-                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % (4 * NJ)], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % (4 * NJ)];
+                // "rotary" scale: host guarantees BN >= 128, so the wave's columns are whole heads and (n & 63) = 16 (j & 3) + 4 g;
+                // the table depends on the row and the dim only, so one prefetched set serves both heads of a 128-wide wave
+                if (pre_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
+                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % NPRE], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % NPRE];
                     v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
                 }
                 return v;
@@ -411,7 +486,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                         }
                     }
                     if (has_res || has_aux) {
-                        const bf16x4 xx = __builtin_bit_cast(bf16x4, pre2[i * NJ + j]);
+                        bf16x4 xx;
+                        if (EARLY) xx = __builtin_bit_cast(bf16x4, pre2[(i * NJ + j) % NPRE]);
+                        else {
+                            const int gn = wcol0 + j * 16 + g * 4;
+                            xx = (mok && gn < eN) ? *reinterpret_cast<const bf16x4*>(pre_src + (int64_t)out_row(gm) * pre_ld + gn) : bf16x4{};
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
                             o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
@@ -454,6 +534,7 @@ static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
 }  // namespace g256
 
 constexpr int64_t NUM_CU = 256;    // MI355X
+extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -470,17 +551,22 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     const int64_t tm = (a->M + g256::BM - 1) / g256::BM;
     // tile width: the one that wastes the fewest CU-rounds (256 workgroups per round, one per CU)
     int bn = 128;
-    {
-        const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96);
-        // measured: a 96-wide tile costs ~0.91 of a 128-wide one (the A side and the LDS-DMA issue do not shrink)
-        const int64_t c128 = ((t128 + 255) / 256) * 100, c96 = ((t96 + 255) / 256) * 91;
-        if (c96 < c128) bn = 96;
-    }
-    static int force_bn = -1, grid_mode = -1;
+    static int force_bn = -1, grid_mode = -1, c256_cost = -1;
     if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
     if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
-    if (force_bn == 96 || force_bn == 128) bn = force_bn;
-    if (a->rot_tab) bn = 128;                               // the prefetched "rotary" scales assume one head per wave
+    if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 190; }
+    const bool can256 = a->N >= 256;
+    {
+        const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96), t256 = tm * ((a->N + 255) / 256);
+        // measured: a 96-wide tile costs ~0.91 of a 128-wide one (the A side and the LDS-DMA issue do not shrink); a
+        // 256-wide one ~1.9 (twice the FLOPs for 4/3 of the LDS-DMA bytes, but its 2-stage ring drains behind every k-tile)
+        const int64_t c128 = ((t128 + 255) / 256) * 100, c96 = ((t96 + 255) / 256) * 91, c256 = ((t256 + 255) / 256) * c256_cost;
+        int64_t best = c128;
+        if (c96 < best && !a->rot_tab) { bn = 96; best = c96; }       // the prefetched "rotary" scales assume whole heads per wave
+        if (can256 && c256 < best) { bn = 256; best = c256; }
+    }
+    { const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn; if (f == 96 || f == 128 || (f == 256 && can256)) bn = f; }
+    if (a->rot_tab && bn == 96) bn = 128;
     const int64_t tn = (a->N + bn - 1) / bn;
     const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
     int64_t splits = 1;
@@ -507,7 +593,8 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     ga.tile_start[0] = 0;
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
     ga.p[0] = *a;
-    if (bn == 128) g256::launch<128>(ga, grid, s);
+    if (bn == 256) g256::launch<256>(ga, grid, s);
+    else if (bn == 128) g256::launch<128>(ga, grid, s);
     else g256::launch<96>(ga, grid, s);
     if (splits > 1) reduce(a, splits, s);
     return 0;

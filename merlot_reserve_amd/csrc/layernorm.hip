@@ -1,6 +1,7 @@
 // LayerNorm forward / backward and column sums for gfx950 (HBM-bound: one wave per row, 16-byte vectors,
 // wavefront reductions).  Replaces flax nn.LayerNorm(epsilon=1e-5) as used at mreserve/modeling.py:272,277,360,366:
 // statistics in fp32 with var = E[x^2] - E[x]^2, y = (x - mean) * (rsqrt(var + eps) * scale) + bias.
+#include <string.h>
 #include "mr_common.h"
 
 namespace {
@@ -163,6 +164,36 @@ static void launch_reduce(const float* partials, int nparts, int ncols, int spli
     }
 }
 
+// Several independent reductions in ONE launch (the LayerNorm and bias gradients of a transformer layer): single level,
+// block = 64 columns of one job x 16 row groups, fixed summation order.
+constexpr int MAX_JOBS = 8;
+struct ReduceBatch {
+    int count;
+    int blk_start[MAX_JOBS + 1];
+    mr_reduce_job job[MAX_JOBS];
+};
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_JOBS; ++k) j += (k < rb.count && (int)blockIdx.x >= rb.blk_start[k]);
+    const mr_reduce_job& q = rb.job[j];
+    const int c = ((int)blockIdx.x - rb.blk_start[j]) * 64 + lane, ncols = q.ncols, nparts = q.nparts;
+    float s = 0.f;
+    if (c < ncols)
+        for (int p = grp; p < nparts; p += 16) s += q.partials[(int64_t)p * ncols + c];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < ncols) {
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][lane];
+        if (c < q.split) static_cast<__bf16*>(q.out0)[c] = (__bf16)s;
+        else static_cast<__bf16*>(q.out1)[c - q.split] = (__bf16)s;
+    }
+}
+
 // column sums: grid.x = 512-column groups, grid.y = row strips; partial[strip, N]
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ x, int64_t ldx, int64_t rows, int N,
                                                      float* __restrict__ partials) {
@@ -202,12 +233,14 @@ extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
     return MR_OK;
 }
 
+extern "C" int64_t mr_layernorm_bwd_nparts(int64_t rows) { const int64_t n = (rows + 3) / 4; return n > PART_ROWS ? PART_ROWS : n; }
 extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)(PART_ROWS + RED_Y) * 2 * H * sizeof(float); }
 
 extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* mean,
                                 const float* rstd, void* dx, int64_t lddx, const void* dx_add, int64_t ldadd, void* dgamma,
                                 void* dbeta, void* partials, int64_t rows, int64_t H, void* stream) {
-    MR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partials, "mr_layernorm_bwd: null pointer");
+    MR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials, "mr_layernorm_bwd: null pointer");
+    MR_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "mr_layernorm_bwd: dgamma and dbeta must both be given or both be NULL");
     MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_bwd: H=%ld unsupported", (long)H);
     MR_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "mr_layernorm_bwd: leading dims must be multiples of 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -218,17 +251,19 @@ extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                        static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
                        static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
                        ldadd, static_cast<float*>(partials), rows, (int)H);
-    launch_reduce(static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H,
-                  static_cast<float*>(partials) + (int64_t)PART_ROWS * 2 * H, static_cast<__bf16*>(dgamma), static_cast<__bf16*>(dbeta), s);
+    if (dgamma != nullptr)      // else: deferred, the caller reduces `partials` with mr_reduce_partials
+        launch_reduce(static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H,
+                      static_cast<float*>(partials) + (int64_t)PART_ROWS * 2 * H, static_cast<__bf16*>(dgamma), static_cast<__bf16*>(dbeta), s);
     MR_CHECK_LAUNCH("mr_layernorm_bwd");
     return MR_OK;
 }
 
 constexpr int COLSUM_STRIPS = 128;
+extern "C" int64_t mr_colsum_nparts(int64_t rows) { const int64_t n = (rows + 3) / 4; return n > COLSUM_STRIPS ? COLSUM_STRIPS : n; }
 extern "C" int64_t mr_colsum_workspace(int64_t N) { return (int64_t)(COLSUM_STRIPS + RED_Y) * N * sizeof(float); }
 
 extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream) {
-    MR_CHECK_ARG(x && out && partials, "mr_colsum: null pointer");
+    MR_CHECK_ARG(x && partials, "mr_colsum: null pointer");
     MR_CHECK_ARG(rows > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, "mr_colsum: N and ldx must be multiples of 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t strips = (rows + 3) / 4;
@@ -236,8 +271,29 @@ extern "C" int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, vo
     dim3 grid((unsigned)((N / 8 + 63) / 64), (unsigned)strips);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, static_cast<const __bf16*>(x), ldx, rows, (int)N,
                        static_cast<float*>(partials));
-    launch_reduce(static_cast<const float*>(partials), (int)strips, (int)N, (int)N,
-                  static_cast<float*>(partials) + (int64_t)COLSUM_STRIPS * N, static_cast<__bf16*>(out), static_cast<__bf16*>(out), s);
+    if (out != nullptr)         // else: deferred, the caller reduces `partials` with mr_reduce_partials
+        launch_reduce(static_cast<const float*>(partials), (int)strips, (int)N, (int)N,
+                      static_cast<float*>(partials) + (int64_t)COLSUM_STRIPS * N, static_cast<__bf16*>(out), static_cast<__bf16*>(out), s);
     MR_CHECK_LAUNCH("mr_colsum");
+    return MR_OK;
+}
+
+extern "C" int mr_reduce_partials(const mr_reduce_job* jobs, int32_t count, void* stream) {
+    MR_CHECK_ARG(jobs != nullptr && count >= 1 && count <= MAX_JOBS, "mr_reduce_partials: 1..%d jobs per call (got %d)", MAX_JOBS, (int)count);
+    ReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.count = count;
+    int blocks = 0;
+    for (int k = 0; k < count; ++k) {
+        const mr_reduce_job& q = jobs[k];
+        MR_CHECK_ARG(q.partials && q.out0 && (q.out1 || q.split >= q.ncols) && q.nparts > 0 && q.ncols > 0 && q.split >= 0,
+                     "mr_reduce_partials: bad job %d", k);
+        rb.blk_start[k] = blocks;
+        rb.job[k] = q;
+        blocks += (q.ncols + 63) / 64;
+    }
+    rb.blk_start[count] = blocks;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), rb);
+    MR_CHECK_LAUNCH("mr_reduce_partials");
     return MR_OK;
 }

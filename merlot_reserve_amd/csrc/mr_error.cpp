@@ -1,6 +1,7 @@
 // Thread-local error text for the C-ABI (include/mreserve_hip.h: mr_last_error).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/mreserve_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -14,3 +15,13 @@ void mr_set_error(const char* fmt, ...) {
 
 extern "C" const char* mr_last_error(void) { return g_err; }
 extern "C" int mr_version(void) { return 1; }
+
+// ---- process-wide knobs (include/mreserve_hip.h: mr_set_option) ----
+int g_mr_opt_tile_n = 0;
+int g_mr_opt_v1_only = 0;
+extern "C" int mr_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "gemm_tile_n")) { g_mr_opt_tile_n = value; return MR_OK; }
+    if (name && !strcmp(name, "gemm_v1_only")) { g_mr_opt_v1_only = value; return MR_OK; }
+    mr_set_error("mr_set_option: unknown option '%s'", name ? name : "(null)");
+    return MR_EINVAL;
+}

@@ -115,6 +115,10 @@ class PretrainEngine:
             sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
             sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
             sc.cs_ws = ops.colsum_workspace(4 * H, dev)
+            # a layer's four deferred reductions (2 LayerNorm, 2 bias) each keep their partial rows until the layer's
+            # single mr_reduce_partials launch
+            sc.ln_ws2 = ops.layernorm_bwd_workspace(H, dev)
+            sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
             sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
             sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
             sc.Dpatch = z(Ps, H)
@@ -212,23 +216,26 @@ class PretrainEngine:
         k = 2 * st.L + 1
         ops.layernorm_bwd(Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
                           G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.cur.ln_ws)
+        jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
             ops.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
             ops.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
-                              G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur)               # Dmid = d xmid
+                              G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
             ops.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
             ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh)
-            ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws)
-            ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws)
+            ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
+            ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
             ops.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
             ops.gemm_grouped([ops.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
                               ops.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
                               ops.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
                               ops.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
             ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
-                              G[n['g1']], G[n['b1']], self.cur.ln_ws, dx_add=Dmid)               # Dnext = d X[l]
+                              G[n['g1']], G[n['b1']], self.cur.ln_ws2, dx_add=Dmid, jobs=jobs)   # Dnext = d X[l]
+            if jobs is not None:
+                ops.reduce_partials(jobs)          # the layer's 2 LayerNorm + 2 bias gradients: one launch
             Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
         ops.layernorm_bwd(Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
                           G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.cur.ln_ws)

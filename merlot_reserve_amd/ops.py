@@ -112,15 +112,20 @@ def layernorm_bwd_workspace(H, device):
     return torch.empty(_lib.load().mr_layernorm_bwd_workspace(H) // 4, dtype=F32, device=device)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False, dx_add=None):
-    """dx = LN backward (+ dx_add; add_to_dx=True is shorthand for dx_add=dx)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False, dx_add=None, jobs=None):
+    """dx = LN backward (+ dx_add; add_to_dx=True is shorthand for dx_add=dx).  With `jobs` (a list) the dgamma/dbeta
+    reduction is deferred: a job is appended for reduce_partials() and `partials` must stay untouched until then."""
     rows, H = x.shape
     if add_to_dx:
         dx_add = dx
-    check(_lib.load().mr_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), mean.data_ptr(),
-                                       rstd.data_ptr(), dx.data_ptr(), _ld(dx), _ptr(dx_add), 0 if dx_add is None else _ld(dx_add),
-                                       dgamma.data_ptr(), dbeta.data_ptr(), partials.data_ptr(), rows, H, _stream()),
-          'mr_layernorm_bwd')
+    lib = _lib.load()
+    defer = jobs is not None
+    check(lib.mr_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), mean.data_ptr(),
+                               rstd.data_ptr(), dx.data_ptr(), _ld(dx), _ptr(dx_add), 0 if dx_add is None else _ld(dx_add),
+                               None if defer else dgamma.data_ptr(), None if defer else dbeta.data_ptr(), partials.data_ptr(),
+                               rows, H, _stream()), 'mr_layernorm_bwd')
+    if defer:
+        jobs.append(_lib.ReduceJob(partials.data_ptr(), lib.mr_layernorm_bwd_nparts(rows), 2 * H, H, dgamma.data_ptr(), dbeta.data_ptr()))
     return dx
 
 
@@ -128,10 +133,24 @@ def colsum_workspace(N, device):
     return torch.empty(_lib.load().mr_colsum_workspace(N) // 4, dtype=F32, device=device)
 
 
-def colsum(x, out, partials):
+def colsum(x, out, partials, jobs=None):
+    """out[n] = sum_m x[m, n]; with `jobs` the final reduction is deferred to reduce_partials() (see layernorm_bwd)."""
     rows, N = x.shape
-    check(_lib.load().mr_colsum(x.data_ptr(), _ld(x), rows, N, out.data_ptr(), partials.data_ptr(), _stream()), 'mr_colsum')
+    lib = _lib.load()
+    check(lib.mr_colsum(x.data_ptr(), _ld(x), rows, N, None if jobs is not None else out.data_ptr(), partials.data_ptr(), _stream()),
+          'mr_colsum')
+    if jobs is not None:
+        jobs.append(_lib.ReduceJob(partials.data_ptr(), lib.mr_colsum_nparts(rows), N, N, out.data_ptr(), out.data_ptr()))
     return out
+
+
+def reduce_partials(jobs):
+    """Runs the deferred column reductions (<= 8 per launch) and clears the list."""
+    while jobs:
+        chunk = jobs[:8]
+        del jobs[:8]
+        arr = (_lib.ReduceJob * len(chunk))(*chunk)
+        check(_lib.load().mr_reduce_partials(arr, len(chunk), _stream()), 'mr_reduce_partials')
 
 
 def attention_fwd(qkv, code, out, lse, nseq, S, nh):

@@ -65,8 +65,12 @@ class Trainer:
         self.state = construct_train_state(config['optimizer'], self.params)
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
         self.comm = comm
-        if world > 1:
-            assert comm is not None and comm.world == world and comm.rank == rank
+        # the collective path runs whenever a Comm is given -- also with a single rank, which is how the RCCL calls
+        # themselves are exercised on a 1-GPU box (tests/test_dist_gpu.py)
+        assert world == 1 or comm is not None
+        self.use_comm = comm is not None
+        if self.use_comm:
+            assert comm.world == world and comm.rank == rank
             assert (B * self.engine.d.ntrg) % 8 == 0, 'world > 1 needs 8-aligned contrastive blocks (even B for the stock configs)'
             R, H = self.engine.R, self.engine.d.H
             z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)
@@ -96,7 +100,7 @@ class Trainer:
         torch.cuda.synchronize()
         self.graphs = []
         segs = [lambda: eng.forward_device(self.images_in, self.audio_in)]
-        if self.world > 1:
+        if self.use_comm:
             b = self.buckets
             segs += [lambda: eng.loss_and_grad_outputs(self.E_all, self.dE_all),
                      lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward_stage_joint(), ops.nan_to_num_(b[0])),
@@ -117,7 +121,7 @@ class Trainer:
         self.images_in.copy_(batch['images'], non_blocking=True)
         self.audio_in.copy_(batch['audio_clips'], non_blocking=True)
         eng.set_plan(plan)
-        if self.world > 1:
+        if self.use_comm:
             self.graphs[0].replay()
             self.comm.gather_embeddings(eng.E, self.E_all)
             self.graphs[1].replay()
@@ -139,14 +143,14 @@ class Trainer:
         if plan is None:
             plan = self.plan(batch, draws)
         eng.forward(batch, plan=plan)
-        if self.world > 1:
+        if self.use_comm:
             self.comm.gather_embeddings(eng.E, self.E_all)                  # pretrain_model.py:290
             eng.loss_and_grad_outputs(self.E_all, self.dE_all)
             self.comm.scatter_grad(self.dE_all, self.dE_red)                # transpose of the all-gather
             ops.add_(eng.dE.view(-1), self.dE_red.view(-1))
         else:
             eng.loss_and_grad_outputs()
-        if self.world > 1:
+        if self.use_comm:
             works = []
             for k, stage in enumerate((eng.backward_stage_joint, eng.backward_stage_audio, eng.backward_stage_vision)):
                 stage()

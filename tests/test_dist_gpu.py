@@ -64,3 +64,52 @@ def test_two_rank_train_step_on_one_gpu(dev):
     assert r0['replicas_equal'] and r1['replicas_equal'], 'ranks diverged: gradient averaging is broken'
     assert r0['graph_equals_eager'] and r1['graph_equals_eager'], 'hipGraph replay differs from eager execution'
     assert r0['eager'] != r1['eager'], 'ranks saw different batches, so per-rank losses must differ'
+
+
+def _nccl_single_rank(_i, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    from merlot_reserve_amd.config import tiny_config
+    from merlot_reserve_amd.dist import Comm
+    from merlot_reserve_amd.synthetic import make_batch
+    from merlot_reserve_amd.trainer import Trainer
+    cfg = tiny_config(seq_len=80, lang_seq_len=40)
+    cfg['optimizer'].update(num_warmup_steps=1, learning_rate=1e-3)
+    B = 8
+    batches = [make_batch(cfg, B, seed=100 + 10 * i, device=dev) for i in range(3)]
+    res = {}
+    for name, comm, graph in (('plain', None, False), ('rccl_eager', Comm(), False), ('rccl_graph', Comm(), True)):
+        tr = Trainer(cfg, B, dev, rank=0, world=1, seed=0, comm=comm)
+        tr.train_step(batches[0], plan=tr.plan(batches[0]))
+        losses = [tr.loss_info()['loss']]
+        if graph:
+            tr.capture(batches[0])
+        for b in batches[1:]:
+            plan = tr.plan(b)
+            tr.train_step_graph(b, plan) if graph else tr.train_step(b, plan=plan)
+            losses.append(tr.loss_info()['loss'])
+        torch.cuda.synchronize()
+        res[name] = (losses, tr.params.master.detach().cpu())
+    ret['losses'] = {k: v[0] for k, v in res.items()}
+    ret['eager_equals_graph'] = bool(torch.equal(res['rccl_eager'][1], res['rccl_graph'][1]))
+    d = (res['plain'][1] - res['rccl_eager'][1]).abs().max().item()
+    ret['max_param_diff_vs_plain'] = d
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_single_rank(dev):
+    """The Trainer's collective path (all-gather of embeddings, reduce-scatter of their gradient, async bf16 AVG
+    all-reduce per gradient bucket, graph segments between them) on the REAL nccl/RCCL backend with one rank: the
+    transport calls, dtypes and stream ordering the multi-GPU bench uses, which gloo cannot cover."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_single_rank, args=(29700 + (os.getpid() % 1000), ret), nprocs=1, join=True)
+    print(dict(ret))
+    L = ret['losses']
+    assert all(v == v and abs(v) < 1e9 for k in L for v in L[k])
+    assert ret['eager_equals_graph'], 'graph-segmented RCCL step differs from the eager RCCL step'
+    # one rank: the gathered loss / averaged gradients equal the local ones up to the bf16 round trip of dE
+    assert abs(L['plain'][-1] - L['rccl_eager'][-1]) < 2e-2 * abs(L['plain'][-1])

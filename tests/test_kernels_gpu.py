@@ -171,6 +171,34 @@ def test_colsum(dev):
     assert_close(out, x.float().sum(0), 4e-3, 'colsum')
 
 
+def test_deferred_reductions_in_one_launch(dev):
+    """LayerNorm dgamma/dbeta and two column sums deferred into ONE mr_reduce_partials launch == the immediate forms."""
+    from merlot_reserve_amd import ops
+    rows, H = 5000, 256
+    x = rnd((rows, H), dev, scale=2.0, seed=1) + 0.5
+    gamma, dy = rnd((H,), dev, seed=2) + 1, rnd((rows, H), dev, seed=4)
+    y, mean, rstd = torch.zeros_like(x), torch.zeros(rows, device=dev), torch.zeros(rows, device=dev)
+    ops.layernorm_fwd(x, gamma, gamma, y, mean, rstd)
+    a, b = rnd((777, 776), dev, seed=5), rnd((130, 3072), dev, seed=6)
+    outs = []
+    for deferred in (False, True):
+        jobs = [] if deferred else None
+        dx, dg, db = torch.zeros_like(x), torch.zeros(H, dtype=BF16, device=dev), torch.zeros(H, dtype=BF16, device=dev)
+        ca, cb = torch.zeros(776, dtype=BF16, device=dev), torch.zeros(3072, dtype=BF16, device=dev)
+        ws = [ops.layernorm_bwd_workspace(H, dev), ops.colsum_workspace(776, dev), ops.colsum_workspace(3072, dev)]   # kept alive
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, ws[0], jobs=jobs)
+        ops.colsum(a, ca, ws[1], jobs=jobs)
+        ops.colsum(b, cb, ws[2], jobs=jobs)
+        if deferred:
+            assert len(jobs) == 3
+            ops.reduce_partials(jobs)
+            assert jobs == []
+        outs.append((dg, db, ca, cb))
+    assert_close(outs[1][2], a.float().sum(0), 4e-3, 'deferred colsum')
+    for u, v in zip(*outs):
+        assert relerr(u, v) < 4e-3      # same partial rows, different (both fixed) summation trees
+
+
 def ref_attention(qkv, code, nseq, S, nh):
     H = nh * 64
     q, k, v = qkv.float().reshape(nseq, S, 3, nh, 64).unbind(2)
@@ -414,8 +442,17 @@ GEMM256_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 96, 128, 256])
+def tile_n(request):
+    """Forces the output-tile width of the 256-row GEMM (0 = the library's own choice) for the duration of a test."""
+    from merlot_reserve_amd import _lib
+    _lib.check(_lib.load().mr_set_option(b'gemm_tile_n', request.param), 'mr_set_option')
+    yield request.param
+    _lib.load().mr_set_option(b'gemm_tile_n', 0)
+
+
 @pytest.mark.parametrize('M,N,K,ta,tb', GEMM256_CASES)
-def test_gemm256(dev, M, N, K, ta, tb):
+def test_gemm256(dev, tile_n, M, N, K, ta, tb):
     from merlot_reserve_amd import ops
     ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
     a = rnd((K, M) if ta else (M, K), dev, seed=1)
@@ -427,7 +464,7 @@ def test_gemm256(dev, M, N, K, ta, tb):
     assert_close(out, A @ B, 3e-3, f'gemm256 {M}x{N}x{K} ta={ta} tb={tb}')
 
 
-def test_gemm256_epilogues(dev):
+def test_gemm256_epilogues(dev, tile_n):
     from merlot_reserve_amd import ops
     M, N, K = 241 * 4, 384, 128
     a, w = rnd((M, K), dev, seed=6), rnd((K, N), dev, scale=0.1, seed=7)
