@@ -130,12 +130,38 @@ constexpr int MAXG = 4;
 // weight gradients of a transformer layer fill the 256 CUs together, with no split-K traffic.
 struct G256Args {
     int count, nwork, splits, kt_per_split;
+    // XCD-blocked tile order (xmode = 1; single problem, no split-K, grid = 256): the 8 XCDs own the cells of a px x py
+    // partition of the tile grid and walk their cell in panels of XPANEL tile columns, so that the 32 workgroups of an
+    // XCD -- which move through K in lockstep -- ask their L2 for few distinct operand strips at a time, and a cell's
+    // slice of B stays L2-resident while its A strips stream through.  (With the plain row-major order every XCD swept
+    // all of B once per round of 256 tiles: rocprofv3 FETCH_SIZE showed 6x the operand bytes leaving L2 per launch.)
+    int xmode, px, py, tm, tn;
     int tiles_n[MAXG], tile_start[MAXG + 1];
     mr_gemm_args p[MAXG];
 };
 
+constexpr int XPANEL = 8;
 __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
     Item it;
+    if (ga.xmode) {
+        const int r = w >> 8, bp = w & 255, x = bp >> 5, sl = bp & 31;     // w = bperm + r * 256, bperm = xcd * 32 + slot
+        const int xi = x / ga.py, xj = x - xi * ga.py;
+        const int m_lo = xi * ga.tm / ga.px, hm = (xi + 1) * ga.tm / ga.px - m_lo;
+        const int n_lo = xj * ga.tn / ga.py, hn = (xj + 1) * ga.tn / ga.py - n_lo;
+        const int q = r * 32 + sl;
+        it.valid = q < hm * hn;
+        const int gw = hn < XPANEL ? hn : XPANEL;
+        const int panel = q / (hm * gw), rem = q - panel * hm * gw;
+        const int left = hn - panel * gw, pw = left < gw ? left : gw;          // the last panel may be narrower
+        const int m = rem / (pw > 0 ? pw : 1), n = panel * gw + rem - m * pw;
+        it.pi = 0;
+        it.split = 0;
+        it.m0 = (m_lo + m) * BM;
+        it.n0 = (n_lo + n) * bn;
+        it.kt0 = 0;
+        it.nkt = (int)((ga.p[0].K + BK - 1) / BK);
+        return it;
+    }
     it.valid = w < ga.nwork;
     const int tile = (ga.splits == 1) ? w : w / ga.splits;
     it.split = w - tile * ga.splits;
@@ -554,7 +580,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     static int force_bn = -1, grid_mode = -1, c256_cost = -1;
     if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
     if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
-    if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 190; }
+    if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 180; }
     const bool can256 = a->N >= 256;
     {
         const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96), t256 = tm * ((a->N + 255) / 256);
@@ -589,6 +615,31 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     ga.count = 1; ga.nwork = (int)nwork; ga.splits = (int)splits; ga.kt_per_split = (int)kps;
+    static int xmode_env = -1;
+    if (xmode_env < 0) { const char* e = getenv("MR_G256_XMODE"); xmode_env = e ? atoi(e) : 1; }
+    if (xmode_env && splits == 1 && gsz == NUM_CU && nwork >= 2 * NUM_CU) {
+        // choose the XCD partition: fewest rounds first (the slowest XCD sets the time), then least traffic out of L2
+        const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
+        double best = 1e300;
+        for (int px = 1; px <= 8; px *= 2) {
+            const int py = 8 / px;
+            if (px > tm || py > tn) continue;
+            int64_t rounds = 0;
+            for (int xi = 0; xi < px; ++xi)
+                for (int xj = 0; xj < py; ++xj) {
+                    const int64_t hm = (xi + 1) * tm / px - xi * tm / px, hn = (xj + 1) * tn / py - xj * tn / py;
+                    const int64_t r = (hm * hn + 31) / 32;
+                    if (r > rounds) rounds = r;
+                }
+            const bool b_fits = b_bytes / py < 2.5e6;         // a cell's B slice stays in the XCD's 4-MiB L2
+            const double traffic = a_bytes * py + b_bytes * px * (b_fits ? 1.0 : (double)rounds);
+            const double cost = (double)rounds * 1e12 + traffic;
+            if (cost < best) { best = cost; ga.px = px; ga.py = py; }
+        }
+        if (best < 1e300) {
+            ga.xmode = 1; ga.tm = (int)tm; ga.tn = (int)tn;
+        }
+    }
     ga.tiles_n[0] = (int)tn;
     ga.tile_start[0] = 0;
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;

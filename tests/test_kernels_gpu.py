@@ -439,6 +439,9 @@ GEMM256_CASES = [
     (3072, 768, 1500, True, False),
     (768, 768, 5000, True, False),
     (640, 264, 704, True, True),
+    (8000, 3072, 192, False, False),    # >= 512 tiles: XCD-blocked tile order
+    (16000, 800, 128, False, True),     # same, ragged N and M
+    (9000, 1544, 128, True, False),
 ]
 
 
