@@ -9,6 +9,7 @@
 // Same contract and epilogue as gemm.hip (mr_gemm dispatches here for large problems).
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "mr_common.h"
 
 #ifdef MR_DIAG_SAMEK
@@ -118,6 +119,9 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int l
         return __builtin_bit_cast(bf16x8, both);
     }
 }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // One unit of work: an output tile (and, under split-K, one K range of it).
 struct Item {
@@ -320,9 +324,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
         u32x2 pre2[NPRE];       // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
+        // The residual / aux tile is as large as the output tile: fetched in one go by every CU at once it is a burst of
+        // ~17 MB that the last k-tile has to sit through (the counted vmcnt is in order).  So its four 16-row blocks are
+        // requested one per k-tile from the item's first k-tiles on, BEHIND that k-tile's LDS-DMA pieces (the ring's wait
+        // then leaves those NJ loads, and the previous k-tile's, in flight as well); whatever an item with few k-tiles
+        // has not requested by its last k-tile is requested there.
+        int pphase = (EARLY && epi_bf16 && pre_src != nullptr) ? 0 : 4, pre_prev = 0;
+        auto pre_rows = [&](int i) {
+            const int gm = ci.m0 + wm * 64 + i * 16 + li;
+            const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
+            // 16 bytes per lane in the layout of the widened stores (lanes of a row read 64 contiguous bytes); the
+            // epilogue undoes it with the same two v_permlane16_swap.  8-byte loads touched every line four times.
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                const int gn = ci.n0 + wn * (BN / 2) + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                const void* src_ = (gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src_);
+                pre2[(i * NJ + 2 * jp) % NPRE] = u32x2{v[0], v[1]};
+                pre2[(i * NJ + 2 * jp + 1) % NPRE] = u32x2{v[2], v[3]};
+            }
+            if (NJ & 1) {
+                const int gn = ci.n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4;
+                const void* src_ = (gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy;
+                PRE_LOAD_B64(pre2[(i * NJ + NJ - 1) % NPRE], src_);
+            }
+        };
         // k-loop with the LAST k-tile peeled: the prefetch registers are written (asm) and consumed in straight-line code,
         // so no loop-carried copy of a register whose load is still in flight can be generated.
-        auto kstep = [&]() {
+        auto kstep = [&](auto pre_row_c) {
+            constexpr int PRE_ROW = decltype(pre_row_c)::value;      // 16-row block of the residual / aux tile to request, or -1
             // the stage being refilled was last read one step ago, behind that step's barrier
             const char* As = smem + cstage * STAGE;
             const char* Bs = As + STAGE_A;
@@ -351,15 +381,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     for (int j = 0; j < JH; ++j)
                         MR_DIAG_MFMA(acc[i][h * JH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][h * JH + j], 0, 0, 0));
             }
+            int pre_now = 0;
+            if constexpr (EARLY && PRE_ROW >= 0) {
+                if (pphase < 4) {             // = this item has a residual / aux operand
+                    pre_rows(PRE_ROW);
+                    pphase = PRE_ROW + 1;
+                    pre_now = 1;
+                }
+            }
             // k-tile cseq+1 must have landed before anyone reads it: everything but this step's 6 pieces (this also
-            // retires the previous item's epilogue stores, which were issued before them)
-            RING_WAIT(issued);
+            // retires the previous item's epilogue stores, which were issued before them) and the residual / aux loads
+            // requested behind this k-tile's and the previous k-tile's pieces
+            if (EARLY && issued && pre_now + pre_prev == 2) wait_vmcnt<6 + 2 * NJ>();
+            else if (EARLY && issued && pre_now + pre_prev == 1) wait_vmcnt<6 + NJ>();
+            else RING_WAIT(issued);
+            pre_prev = pre_now;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
         };
         MR_STAMP(0);
-        for (int t = 0; t + 1 < ci.nkt; ++t) kstep();
+        {   // the first four k-tiles request the residual / aux row blocks (static register indices: peeled, not switched)
+            const int nloop = ci.nkt - 1;
+            if (nloop > 0) kstep(std::integral_constant<int, 0>{});
+            if (nloop > 1) kstep(std::integral_constant<int, 1>{});
+            if (nloop > 2) kstep(std::integral_constant<int, 2>{});
+            if (nloop > 3) kstep(std::integral_constant<int, 3>{});
+            for (int t = 4; t < nloop; ++t) kstep(std::integral_constant<int, -1>{});
+        }
         MR_STAMP(1);
         {
             if (EARLY && epi_bf16) {
@@ -374,13 +423,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     const int gm = ci.m0 + wm * 64 + i * 16 + li;
                     const bool mok = gm < eM;
                     if (pre_src != nullptr) {
-                        const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
-                            const void* src_ = (mok && gn < eN) ? (const void*)(rowp + gn) : dummy;
-                            PRE_LOAD_B64(pre2[(i * NJ + j) % NPRE], src_);
-                        }
+                        if (pphase <= i) pre_rows(i);
                     } else if (pre_rot) {
                         const int rr = (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
                         const float* rowp = e_rot + (int64_t)rr * 32 + g * 4;
@@ -392,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     }
                 }
             }
-            kstep();
+            pphase = 4;
+            kstep(std::integral_constant<int, -1>{});
         }
 
         MR_STAMP(2);
@@ -495,7 +539,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 const int64_t roff = (int64_t)out_row(gm) * e_ldc;
                 __bf16* const crow = eC + roff;
                 __bf16* const c2row = eC2 + roff;
-                bf16x4 oc[NJ], od[NJ];
+                bf16x4 oc[NJ], od[NJ], xs[NJ];
+                if (EARLY && (has_res || has_aux)) {
+#pragma unroll
+                    for (int jp = 0; jp < NJ / 2; ++jp) {
+                        const u32x2 lo = pre2[(i * NJ + 2 * jp) % NPRE], hi = pre2[(i * NJ + 2 * jp + 1) % NPRE];
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                        xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
+                        xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
+                    }
+                    if (NJ & 1) xs[NJ - 1] = __builtin_bit_cast(bf16x4, pre2[(i * NJ + NJ - 1) % NPRE]);
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     f32x4 v = finish_pre(i, j);
@@ -513,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     }
                     if (has_res || has_aux) {
                         bf16x4 xx;
-                        if (EARLY) xx = __builtin_bit_cast(bf16x4, pre2[(i * NJ + j) % NPRE]);
+                        if (EARLY) xx = xs[j];
                         else {
                             const int gn = wcol0 + j * 16 + g * 4;
                             xx = (mok && gn < eN) ? *reinterpret_cast<const bf16x4*>(pre_src + (int64_t)out_row(gm) * pre_ld + gn) : bf16x4{};
