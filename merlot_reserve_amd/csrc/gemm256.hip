@@ -485,112 +485,141 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             }
         } else {
             // ---------------- bf16 epilogue: registers only (operands were prefetched during the last k-tile) ----------------
-            if (!EARLY && e_bias != nullptr) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int gn = wcol0 + j * 16 + g * 4;
-                    pbias[j] = *reinterpret_cast<const u32x2*>(gn < eN ? e_bias + gn : e_bias);
+            // The epilogue is VALU-bound (two waves per SIMD run it with the MFMA pipe idle), so it is specialised at compile
+            // time for the five operand combinations the step uses -- plain / bias, "rotary", GELU + gelu' copy, residual,
+            // aux -- and chosen per item by one wave-uniform switch; MODE 5 keeps every flag dynamic for anything else.
+            auto epilogue = [&](auto mode_c) {
+                constexpr int MODE = decltype(mode_c)::value;
+                constexpr bool GEN = MODE == 5;
+                const bool f_rot = GEN ? pre_rot : MODE == 1, f_act = GEN ? do_act : MODE == 2;
+                const bool f_c2 = GEN ? eC2 != nullptr : MODE == 2;
+                const bool f_res = GEN ? has_res : MODE == 3, f_aux = GEN ? has_aux : MODE == 4;
+                if (!EARLY && e_bias != nullptr) {
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int gn = wcol0 + j * 16 + g * 4;
+                        pbias[j] = *reinterpret_cast<const u32x2*>(gn < eN ? e_bias + gn : e_bias);
+                    }
                 }
-            }
-            auto finish_pre = [&](int i, int j) -> f32x4 {
-                f32x4 v = acc[i][j];
-                if (!EARLY) {
-                    if (e_bias != nullptr) {
+                if (e_bias == nullptr) {            // no bias: add zeros (keeps the per-element code branch-free)
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) pbias[j] = u32x2{0u, 0u};
+                }
+                auto finish_pre = [&](int i, int j) -> f32x4 {
+                    f32x4 v = acc[i][j];
+                    if (!EARLY) {
+                        {
+                            const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+                        }
+                        if (f_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
+                            const int gm = wrow0 + i * 16 + li;
+                            const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+                            v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (j & 1) * 16 + g * 4);
+                        }
+                        return v;
+                    }
+                    {
                         const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
-#pragma unroll
+    #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
                     }
-                    if (pre_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
-                        const int gm = wrow0 + i * 16 + li;
-                        const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
-                        v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (j & 1) * 16 + g * 4);
+                    // "rotary" scale: host guarantees BN >= 128, so the wave's columns are whole heads and (n & 63) = 16 (j & 3) + 4 g;
+                    // the table depends on the row and the dim only, so one prefetched set serves both heads of a 128-wide wave
+                    if (f_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
+                        const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % NPRE], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % NPRE];
+                        v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
                     }
                     return v;
-                }
-                if (e_bias != nullptr) {
-                    const bf16x4 b4 = __builtin_bit_cast(bf16x4, pbias[j]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
-                }
-                // "rotary" scale: host guarantees BN >= 128, so the wave's columns are whole heads and (n & 63) = 16 (j & 3) + 4 g;
-                // the table depends on the row and the dim only, so one prefetched set serves both heads of a 128-wide wave
-                if (pre_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
-                    const u32x2 lo = pre2[(i * 4 + (j & 1) * 2) % NPRE], hi = pre2[(i * 4 + (j & 1) * 2 + 1) % NPRE];
-                    v *= __builtin_bit_cast(f32x4, u32x4{lo[0], lo[1], hi[0], hi[1]});
-                }
-                return v;
-            };
-            // Stores are widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 and 4g+4.. of the same row, so one
-            // v_permlane16_swap per dword between the registers of two adjacent 16-column blocks (rows 1,3 of the first
-            // <-> rows 0,2 of the second) leaves every lane with 8 contiguous columns: lane rows g = 0/2 own block 2jp
-            // (columns 0-7 / 8-15), g = 1/3 own block 2jp+1.  A wave instruction then writes 64 contiguous bytes per
-            // row instead of 32 (the 8-byte form was store-issue bound).
-            auto store_pair = [&](__bf16* rowp, bool mok, int jp, bf16x4 va, bf16x4 vb) {
-                u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
-                if (mok && col < eN) *reinterpret_cast<u32x4*>(rowp + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-            };
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gm = wrow0 + i * 16 + li;
-                const bool mok = gm < eM;
-                const int64_t roff = (int64_t)out_row(gm) * e_ldc;
-                __bf16* const crow = eC + roff;
-                __bf16* const c2row = eC2 + roff;
-                bf16x4 oc[NJ], od[NJ], xs[NJ];
-                if (EARLY && (has_res || has_aux)) {
-#pragma unroll
+                };
+                // Stores are widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 and 4g+4.. of the same row, so one
+                // v_permlane16_swap per dword between the registers of two adjacent 16-column blocks (rows 1,3 of the first
+                // <-> rows 0,2 of the second) leaves every lane with 8 contiguous columns: lane rows g = 0/2 own block 2jp
+                // (columns 0-7 / 8-15), g = 1/3 own block 2jp+1.  A wave instruction then writes 64 contiguous bytes per
+                // row instead of 32 (the 8-byte form was store-issue bound).
+                auto store_pair = [&](__bf16* rowp, bool mok, int jp, bf16x4 va, bf16x4 vb) {
+                    u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                    if (mok && col < eN) *reinterpret_cast<u32x4*>(rowp + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                };
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gm = wrow0 + i * 16 + li;
+                    const bool mok = gm < eM;
+                    const int64_t roff = (int64_t)out_row(gm) * e_ldc;
+                    __bf16* const crow = eC + roff;
+                    __bf16* const c2row = eC2 + roff;
+                    bf16x4 oc[NJ], od[NJ], xs[NJ];
+                    if (EARLY && (f_res || f_aux)) {
+    #pragma unroll
+                        for (int jp = 0; jp < NJ / 2; ++jp) {
+                            const u32x2 lo = pre2[(i * NJ + 2 * jp) % NPRE], hi = pre2[(i * NJ + 2 * jp + 1) % NPRE];
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+                            xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
+                            xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
+                        }
+                        if (NJ & 1) xs[NJ - 1] = __builtin_bit_cast(bf16x4, pre2[(i * NJ + NJ - 1) % NPRE]);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        f32x4 v = finish_pre(i, j);
+                        bf16x4 o;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                        od[j] = o;
+                        if (f_act) {
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float sg = sigmoid1702(v[r]);
+                                o[r] = (__bf16)(v[r] * sg);
+                                od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
+                            }
+                        }
+                        if (f_res || f_aux) {
+                            bf16x4 xx;
+                            if (EARLY) xx = xs[j];
+                            else {
+                                const int gn = wcol0 + j * 16 + g * 4;
+                                xx = (mok && gn < eN) ? *reinterpret_cast<const bf16x4*>(pre_src + (int64_t)out_row(gm) * pre_ld + gn) : bf16x4{};
+                            }
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
+                                o[r] = f_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
+                        }
+                        oc[j] = o;
+                    }
+    #pragma unroll
                     for (int jp = 0; jp < NJ / 2; ++jp) {
-                        const u32x2 lo = pre2[(i * NJ + 2 * jp) % NPRE], hi = pre2[(i * NJ + 2 * jp + 1) % NPRE];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-                        xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
-                        xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
+                        if (f_c2) store_pair(c2row, mok, jp, od[2 * jp], od[2 * jp + 1]);
+                        store_pair(crow, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
                     }
-                    if (NJ & 1) xs[NJ - 1] = __builtin_bit_cast(bf16x4, pre2[(i * NJ + NJ - 1) % NPRE]);
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x4 v = finish_pre(i, j);
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                    od[j] = o;
-                    if (do_act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float sg = sigmoid1702(v[r]);
-                            o[r] = (__bf16)(v[r] * sg);
-                            od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
+                    if (NJ & 1) {                                          // BN = 96: the odd block keeps 8-byte stores
+                        const int col = wcol0 + (NJ - 1) * 16 + g * 4;
+                        if (mok && col < eN) {
+                            if (f_c2) *reinterpret_cast<bf16x4*>(c2row + col) = od[NJ - 1];
+                            *reinterpret_cast<bf16x4*>(crow + col) = oc[NJ - 1];
                         }
                     }
-                    if (has_res || has_aux) {
-                        bf16x4 xx;
-                        if (EARLY) xx = xs[j];
-                        else {
-                            const int gn = wcol0 + j * 16 + g * 4;
-                            xx = (mok && gn < eN) ? *reinterpret_cast<const bf16x4*>(pre_src + (int64_t)out_row(gm) * pre_ld + gn) : bf16x4{};
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)      // aux = act'(pre-activation) saved by the forward GEMM's c2
-                            o[r] = has_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
-                    }
-                    oc[j] = o;
                 }
-#pragma unroll
-                for (int jp = 0; jp < NJ / 2; ++jp) {
-                    if (eC2 != nullptr) store_pair(c2row, mok, jp, od[2 * jp], od[2 * jp + 1]);
-                    store_pair(crow, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
-                }
-                if (NJ & 1) {                                          // BN = 96: the odd block keeps 8-byte stores
-                    const int col = wcol0 + (NJ - 1) * 16 + g * 4;
-                    if (mok && col < eN) {
-                        if (eC2 != nullptr) *reinterpret_cast<bf16x4*>(c2row + col) = od[NJ - 1];
-                        *reinterpret_cast<bf16x4*>(crow + col) = oc[NJ - 1];
-                    }
-                }
+            };
+            int mode = 5;
+            if (eC2 == nullptr && !do_act) {
+                if (pre_src == nullptr) mode = pre_rot ? 1 : (e_rot == nullptr ? 0 : 5);
+                else mode = has_res ? 3 : 4;
+            } else if (eC2 != nullptr && do_act && pre_src == nullptr && e_rot == nullptr) {
+                mode = 2;
+            }
+            switch (mode) {
+                case 0: epilogue(std::integral_constant<int, 0>{}); break;
+                case 1: epilogue(std::integral_constant<int, 1>{}); break;
+                case 2: epilogue(std::integral_constant<int, 2>{}); break;
+                case 3: epilogue(std::integral_constant<int, 3>{}); break;
+                case 4: epilogue(std::integral_constant<int, 4>{}); break;
+                default: epilogue(std::integral_constant<int, 5>{}); break;
             }
         }
         MR_STAMP(3);
