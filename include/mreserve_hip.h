@@ -207,6 +207,31 @@ int mr_nan_to_num_bf16(void* g, int64_t n, void* stream);
 /* work_bf16 = bf16(master) (P:323-324) */
 int mr_cast_f32_to_bf16_params(const float* master, void* work_bf16, int64_t n, void* stream);
 
+/* ---- fp32 forward path (use_bfloat16 = false: M:594; every zero-shot / feature caller runs fp32, M:999-1000) ----
+ * Same operations as above with fp32 storage and fp32 arithmetic (v_mfma_f32_16x16x4_f32 / fp32 VALU), forward only.
+ * Leading dims and H must be multiples of 4 (16-byte vectors) except mr_f32_gemm's lda / ldb (unaligned operands take a
+ * scalar-load path). */
+/* mr_gemm_args with A, B, C, bias, residual = fp32; c_dtype must be MR_DT_F32; c2 / aux / workspace unused (NULL).
+ * Epilogue order: + bias, * rot_tab, gelu1702, + residual (residual addressed with the mapped output row). */
+int mr_f32_gemm(const mr_gemm_args* args, void* stream);
+int mr_f32_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                         int64_t rows, int64_t H, float eps, void* stream);
+/* qkv [nseq*S, 3H] fp32 (layout of mr_attention_fwd); lse may be NULL */
+int mr_f32_attention_fwd(const float* qkv, const int32_t* code, float* out, float* lse, int64_t nseq, int64_t S,
+                         int64_t nh, void* stream);
+int mr_f32_poolattn_fwd(const float* q, const float* k, const float* v, int64_t ldkv, const int32_t* key_rows, float* out,
+                        int64_t G, int64_t R, int64_t nh, void* stream);
+int mr_f32_segment_sum(const float* src0, int64_t ld0, int64_t n0, const float* src1, int64_t ld1, int64_t n1,
+                       const float* src2, int64_t ld2, int64_t n2, const int32_t* indptr, const int32_t* indices,
+                       float* dst, int64_t ldd, int64_t n_dst, int64_t H, float scale, void* stream);
+int mr_f32_rows_mean_fwd(const float* src, int64_t lds, const int32_t* rows, float* dst, int64_t G, int64_t R, int64_t H,
+                         void* stream);
+/* y = x / sqrt(sum x^2 + 1e-5) * exp(min(*log_scale, ln 100) / 2); log_scale NULL -> plain unit_normalize (M:570-578) */
+int mr_f32_unit_norm_scale_fwd(const float* x, int64_t ldx, const float* log_scale, float* y, int64_t ldy, int64_t rows,
+                               int64_t H, void* stream);
+int mr_f32_fill_rows(const float* vec, float* dst, int64_t ldd, int64_t ngroups, int64_t grp_stride, int64_t off,
+                     int64_t H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,14 @@ PROTOTYPES = {
     'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     'mr_nan_to_num_bf16': (i32, [vp, i64, vp]),
     'mr_cast_f32_to_bf16_params': (i32, [vp, vp, i64, vp]),
+    'mr_f32_gemm': (i32, [C.POINTER(GemmArgs), vp]),
+    'mr_f32_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, i64, i64, f32, vp]),
+    'mr_f32_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    'mr_f32_poolattn_fwd': (i32, [vp, vp, vp, i64, vp, vp, i64, i64, i64, vp]),
+    'mr_f32_segment_sum': (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64, i64, f32, vp]),
+    'mr_f32_rows_mean_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
+    'mr_f32_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
+    'mr_f32_fill_rows': (i32, [vp, vp, i64, i64, i64, i64, i64, vp]),
 }
 
 _lib = None

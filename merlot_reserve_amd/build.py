@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmreserve_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'mr_error.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp']
 
 
 def _needs_build():

@@ -39,7 +39,10 @@ def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, ro
     M, K = (a.shape[1], a.shape[0]) if transA else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if transB else (b.shape[0], b.shape[1])
     assert K == Kb, f'gemm: K mismatch {K} vs {Kb}'
-    assert a.dtype == BF16 and b.dtype == BF16
+    assert a.dtype == b.dtype and a.dtype in (BF16, F32)
+    if a.dtype == F32:       # fp32 forward path (mr_f32_gemm): every operand fp32, forward-only epilogues
+        assert out.dtype == F32 and c2 is None and aux is None
+        assert all(t is None or t.dtype == F32 for t in (bias, residual))
     g = GemmArgs()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.transA = a.data_ptr(), _ld(a), int(transA)
@@ -76,6 +79,10 @@ def gemm(a, b, out, **kw):
     (or [N,K] if transB).  row_map = (grp, grp_stride, grp_off) remaps output rows (out must be big enough)."""
     lib = _lib.load()
     g = gemm_args(a, b, out, **kw)
+    if a.dtype == F32:
+        g.workspace, g.workspace_bytes = None, 0
+        check(lib.mr_f32_gemm(C.byref(g), _stream()), 'mr_f32_gemm')
+        return out
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -103,6 +110,10 @@ def gemm_grouped(arg_list):
 
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
     rows, H = x.shape
+    if x.dtype == F32:
+        check(_lib.load().mr_f32_layernorm_fwd(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ld(y),
+                                               rows, H, eps, _stream()), 'mr_f32_layernorm_fwd')
+        return y
     check(_lib.load().mr_layernorm_fwd(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ld(y),
                                        _ptr(mean), _ptr(rstd), rows, H, eps, _stream()), 'mr_layernorm_fwd')
     return y
@@ -155,6 +166,10 @@ def reduce_partials(jobs):
 
 def attention_fwd(qkv, code, out, lse, nseq, S, nh):
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (nseq * S, 3 * nh * 64)
+    if qkv.dtype == F32:
+        check(_lib.load().mr_f32_attention_fwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), _ptr(lse), nseq, S, nh, _stream()),
+              'mr_f32_attention_fwd')
+        return out
     check(_lib.load().mr_attention_fwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), lse.data_ptr(), nseq, S, nh, _stream()),
           'mr_attention_fwd')
     return out
@@ -172,6 +187,10 @@ def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh):
 def poolattn_fwd(q, k, v, key_rows, out, probs, nh):
     G, R = key_rows.shape
     assert _ld(k) == _ld(v)
+    if q.dtype == F32:
+        check(_lib.load().mr_f32_poolattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), out.data_ptr(),
+                                              G, R, nh, _stream()), 'mr_f32_poolattn_fwd')
+        return out
     check(_lib.load().mr_poolattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), out.data_ptr(),
                                       probs.data_ptr(), G, R, nh, _stream()), 'mr_poolattn_fwd')
     return out
@@ -192,6 +211,12 @@ def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
     ld = [0 if t is None else _ld(t) for t in s]
     n_dst, H = dst.shape
     assert indptr.numel() == n_dst + 1 and indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    if srcs[0].dtype == F32:
+        assert dst.dtype == F32 and not accumulate
+        check(_lib.load().mr_f32_segment_sum(_ptr(s[0]), ld[0], n[0], _ptr(s[1]), ld[1], n[1], _ptr(s[2]), ld[2], n[2],
+                                             indptr.data_ptr(), indices.data_ptr(), dst.data_ptr(), _ld(dst), n_dst, H, scale,
+                                             _stream()), 'mr_f32_segment_sum')
+        return dst
     check(_lib.load().mr_segment_sum(_ptr(s[0]), ld[0], n[0], _ptr(s[1]), ld[1], n[1], _ptr(s[2]), ld[2], n[2],
                                      indptr.data_ptr(), indices.data_ptr(), dst.data_ptr(), _ld(dst),
                                      MR_DT_F32 if dst.dtype == F32 else MR_DT_BF16, n_dst, H, scale, int(accumulate),
@@ -201,6 +226,10 @@ def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
 
 def rows_mean_fwd(src, rows, dst):
     G, R = rows.shape
+    if src.dtype == F32:
+        check(_lib.load().mr_f32_rows_mean_fwd(src.data_ptr(), _ld(src), rows.data_ptr(), dst.data_ptr(), G, R, dst.shape[1],
+                                               _stream()), 'mr_f32_rows_mean_fwd')
+        return dst
     check(_lib.load().mr_rows_mean_fwd(src.data_ptr(), _ld(src), rows.data_ptr(), dst.data_ptr(), G, R, dst.shape[1], _stream()),
           'mr_rows_mean_fwd')
     return dst
@@ -220,6 +249,10 @@ def pad_cols(src, dst):
 
 
 def fill_rows(vec, dst, ngroups, grp_stride, off):
+    if dst.dtype == F32:
+        check(_lib.load().mr_f32_fill_rows(vec.data_ptr(), dst.data_ptr(), _ld(dst), ngroups, grp_stride, off, dst.shape[1],
+                                           _stream()), 'mr_f32_fill_rows')
+        return
     check(_lib.load().mr_fill_rows(vec.data_ptr(), dst.data_ptr(), _ld(dst), ngroups, grp_stride, off, dst.shape[1], _stream()),
           'mr_fill_rows')
 
@@ -236,8 +269,13 @@ def add_(a, b, y=None):
     return y
 
 
-def unit_norm_scale_fwd(x, log_scale, y, inv_norm):
+def unit_norm_scale_fwd(x, log_scale, y, inv_norm=None):
+    """y = unit_normalize(x) * exp(min(log_scale, ln 100) / 2); fp32 path: log_scale None = plain unit_normalize."""
     rows, H = x.shape
+    if x.dtype == F32:
+        check(_lib.load().mr_f32_unit_norm_scale_fwd(x.data_ptr(), _ld(x), _ptr(log_scale), y.data_ptr(), _ld(y), rows, H,
+                                                     _stream()), 'mr_f32_unit_norm_scale_fwd')
+        return y
     check(_lib.load().mr_unit_norm_scale_fwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), y.data_ptr(), _ld(y),
                                              inv_norm.data_ptr(), rows, H, _stream()), 'mr_unit_norm_scale_fwd')
     return y
