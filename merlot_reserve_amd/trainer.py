@@ -52,6 +52,33 @@ class TrainState:
                              oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
         self.step += 1
 
+    # ---- checkpoint form: flax `to_state_dict(TrainState)` of the reference's optax chain (optimization.py:180-195):
+    # opt_state = (ScaleByAdamState{count, mu, nu}, add_decayed_weights (empty), ScaleByScheduleState{count}, scale (empty))
+    # serialised as dicts keyed '0'..'3' (merlot_reserve_amd/checkpoint.py writes / reads the msgpack file)
+    def state_dict(self):
+        p = self.params
+        return {'step': self.step, 'params': p.master_tree(),
+                'opt_state': {'0': {'count': torch.tensor(self.step, dtype=torch.int32), 'mu': p._to_tree(p.mu), 'nu': p._to_tree(p.nu)},
+                              '1': {}, '2': {'count': torch.tensor(self.step, dtype=torch.int32)}, '3': {}}}
+
+    def load_state_dict(self, sd):
+        p = self.params
+        p.load_tree(sd['params'])
+        self.step = int(sd.get('step', 0))
+        opt = sd.get('opt_state')
+        if opt:
+            adam = opt['0']
+            for flat, tree in ((p.mu, adam['mu']), (p.nu, adam['nu'])):
+                host = torch.zeros(p.total, dtype=torch.bfloat16)
+                for name, fshape, *_ in p.specs:
+                    o, n = p.offsets[name]
+                    leaf = tree
+                    for k in name.split('/'):
+                        leaf = leaf[k]
+                    host[o:o + n] = leaf.reshape(-1).to(torch.bfloat16)
+                flat.copy_(host)
+            self.step = int(adam.get('count', self.step))
+
 
 def construct_train_state(opt_config, params):
     return TrainState(params, opt_config)
