@@ -622,3 +622,38 @@ def loss_and_grads(params, config, batch, split_from_here, gumbel_z):
     loss.backward()
     grads = tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), params)
     return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in info.items()}, preds, grads
+
+
+# ----------------------------------------------------------------------------- zero-shot API (M:767-931)
+def embed_text_spans_only(params, config, text_spans):
+    """M:767-774: text_spans [B, L] int64 -> [B, H]."""
+    cfg = Cfg(config)
+    token_embs = token_embedder(params['token_encoder'], {'text_spans': text_spans})['text_spans']
+    return unit_normalize(span_transformer(params['span_encoder'], token_embs, text_spans != PADDING, cfg.span_num_layers))
+
+
+def embed_audio_only(params, config, audio_clips):
+    """M:776-785"""
+    cfg = Cfg(config)
+    enc = audio_transformer(params['audio_encoder'], audio_clips.reshape(-1, cfg.audio_seq_length, 65), cfg.audio_num_layers,
+                            cfg.audio_pooling_ratio, cfg.audio_patch_size)['cls']
+    return unit_normalize(enc).reshape(*audio_clips.shape[:-2], cfg.hidden_size)
+
+
+def embed_video(params, config, images, audio_clips, tokens, subseg_idxs):
+    """M:806-843: images [ns, P, 768], audio_clips [3 ns, 60, 65], tokens / subseg_idxs [L] int64 -> [L, H]."""
+    cfg = Cfg(config)
+    H = cfg.hidden_size
+    num_segments, num_patch_per_img, pp3 = images.shape
+    assert pp3 == 768 and audio_clips.shape[0] == 3 * num_segments
+    token_length = tokens.shape[0]
+    imgs_enc = vision_transformer(params['vision_encoder'], images, cfg.vit_num_layers, cfg.grid_h, cfg.grid_w,
+                                  cfg.vit_pooling_ratio)['seq_attnpool'].reshape(num_segments * num_patch_per_img // 4, H)
+    audio_enc = audio_transformer(params['audio_encoder'], audio_clips.reshape(-1, cfg.audio_seq_length, 65), cfg.audio_num_layers,
+                                  cfg.audio_pooling_ratio, cfg.audio_patch_size)['seq_attnpool']
+    mm = prepare_multimodal_inputs(params, cfg, tokens=tokens[None],
+                                   token_segment_idx=torch.div(subseg_idxs[None], 3, rounding_mode='floor'),     # jnp // floors
+                                   vision_input=imgs_enc[None], audio_pointers=subseg_idxs[None], audio_spans=audio_enc[None])
+    joint = transformer_encoder(params['joint_transformer'], mm['x'], cfg.joint_num_layers, rotary_coords=mm['rotary_coords'],
+                                attention_mask=mm['attention_mask'])['seq']
+    return unit_normalize(dense(joint[0, :token_length], params['head']))
