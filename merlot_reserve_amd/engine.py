@@ -24,34 +24,41 @@ BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 class TowerState:
     """Saved activations of one TransformerEncoder (modeling.py:283-376) over M = nseq*S rows."""
 
-    def __init__(self, M, H, L, nseq, S, dev):
+    def __init__(self, M, H, L, nseq, S, dev, dtype=BF16):
         nh = H // 64
-        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
         self.M, self.H, self.L, self.nseq, self.S = M, H, L, nseq, S
         self.xin, self.xf = z(M, H), z(M, H)
         self.X = z(L + 1, M, H)
         self.ln1, self.ln2, self.xmid, self.att = z(L, M, H), z(L, M, H), z(L, M, H), z(L, M, H)
         self.qkv = z(L, M, 3 * H)
-        self.hpre, self.hact = z(L, M, 4 * H), z(L, M, 4 * H)
+        self.hact = z(L, M, 4 * H)
+        self.hpre = z(L, M, 4 * H) if dtype == BF16 else None      # gelu'(pre-activation), only kept for backward
         self.lse = f(L, nseq, nh, S)
         self.stats = f(2 * L + 2, 2, M)       # [ln index][mean|rstd][row]; index 0 = pre_ln, 1+2l / 2+2l = layer l, last = final
 
 
 class PretrainEngine:
-    def __init__(self, config, B, params, device, rank=0, world=1):
+    def __init__(self, config, B, params, device, rank=0, world=1, dtype=BF16):
+        """dtype = torch.float32 builds the FORWARD-ONLY fp32 program (forward + loss on the fp32 master weights through
+        the mr_f32_* kernels: the reference's use_bfloat16 = False arithmetic, used for the 1e-3 forward-parity check);
+        the default bf16 program is the training path."""
         self.config, self.p, self.dev = config, params, torch.device(device)
         self.d = d = Dims(config, B)
         self.rank, self.world = rank, world
+        self.dtype = dtype
+        self.fwd_only = dtype != BF16
+        self.W = params.w if dtype == BF16 else params.wm
         dev, H = self.dev, d.H
         self.tables = {k: torch.as_tensor(v).to(dev) for k, v in static_tables(d).items()}
-        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
 
-        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev)
-        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev)
-        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev)
-        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev)
+        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype)
+        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype)
+        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype)
+        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype)
         Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
 
         # attention pools
@@ -98,6 +105,11 @@ class PretrainEngine:
                 ldv = (V_ + 7) // 8 * 8
                 self.logit_bufs[(name, direction)] = (f(L_, ldv), z(L_, ldv), z(L_, ldv), V_)
 
+        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
+        self.cur = None
+        if self.fwd_only:
+            return
         # backward scratch
         self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
         self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
@@ -127,7 +139,6 @@ class PretrainEngine:
         self.sc_side = make_scratch(self.ta.M, self.Ga, d.Na * d.a_len)
         self.cur = self.sc_main
         ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
-        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.dXpool = z(self.n_pool, H)
         self.d_hj = z(self.tj.M, H)
         self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
@@ -136,14 +147,16 @@ class PretrainEngine:
         self.unpad_v = self._unpad_csr(d.Nv, d.Sv)
         self.unpad_a = self._unpad_csr(d.Na, d.Sa)
 
-        # device copies of the per-batch plan (fixed sizes where possible; index lists are padded to capacity)
-        self.plan_dev = {}
-        self._plan_caps = {}
-        self._plan_views = {}
-        self.plan_frozen = False
+        # (device copies of the per-batch plan -- plan_dev / _plan_caps / _plan_views, set above -- have fixed sizes where
+        # possible; index lists are padded to capacity)
 
     def _on_side(self, fn):
         """Issue fn()'s kernels on the side stream (forked from / joined to the current stream by the caller)."""
+        if self.fwd_only:
+            if os.environ.get('MR_NO_SIDE_STREAM') == '1':
+                return fn()
+            with torch.cuda.stream(self.side_stream):
+                return fn()
         main_ws = ops.GEMM_WORKSPACE
         self.cur, ops.GEMM_WORKSPACE = self.sc_side, self.sc_side.gemm_ws
         try:
@@ -191,7 +204,7 @@ class PretrainEngine:
 
     def encoder_forward(self, st, prefix, rot, code):
         """TransformerEncoder body (modeling.py:360-366) on st.xin (CLS row already in place) -> st.xf."""
-        W, H, nh = self.p.w, st.H, st.H // 64
+        W, H, nh = self.W, st.H, st.H // 64
         ops.layernorm_fwd(st.xin, W[f'{prefix}/pre_ln/scale'], W[f'{prefix}/pre_ln/bias'], st.X[0], st.stats[0, 0], st.stats[0, 1])
         for l in range(st.L):
             n = self._names(prefix, l)
@@ -201,7 +214,7 @@ class PretrainEngine:
             ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
             ops.gemm(st.att[l], W[n['wo']], st.xmid[l], residual=x)
             ops.layernorm_fwd(st.xmid[l], W[n['g2']], W[n['b2']], st.ln2[l], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1])
-            ops.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=st.hpre[l])
+            ops.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
             ops.gemm(st.hact[l], W[n['w2']], st.X[l + 1], residual=st.xmid[l])
         k = 2 * st.L + 1
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
@@ -246,7 +259,7 @@ class PretrainEngine:
         return t.view(nseq, S * t.shape[1])[:, :t.shape[1]]
 
     def _tower_with_pool_forward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, out_seq, out_cls):
-        W, nh = self.p.w, st.H // 64
+        W, nh = self.W, st.H // 64
         ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
         self.encoder_forward(st, prefix_t, rot, None)
         ops.gemm(self._cls_view(st.xf, st.nseq, st.S), W[f'{prefix_t}/cls_proj/kernel'], out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
@@ -300,7 +313,7 @@ class PretrainEngine:
 
     def forward_device(self, images, audio_clips):
         """Device part of forward(): the plan is already in its device buffers."""
-        d, W, H = self.d, self.p.w, self.d.H
+        d, W, H = self.d, self.W, self.d.H
         batch = {'images': images, 'audio_clips': audio_clips}
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
 
@@ -308,8 +321,11 @@ class PretrainEngine:
         def audio_fwd():
             # audio tower (modeling.py:433-476): the stride-2 conv is a GEMM over 2 consecutive hops = 130 inputs
             audio = batch['audio_clips'].reshape(d.Na * d.a_len, d.a_patch * 65)
-            ops.pad_cols(audio, self.a_in)
-            a_view = self.a_in[:, :d.a_patch * 65]
+            if self.dtype == BF16:                       # 16-byte rows for the bf16 GEMM (the fp32 GEMM reads 130-wide rows as they are)
+                ops.pad_cols(audio, self.a_in)
+                a_view = self.a_in[:, :d.a_patch * 65]
+            else:
+                a_view = audio
             ops.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
             self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                           self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
@@ -395,6 +411,8 @@ class PretrainEngine:
                 src = self._pl('t2sp_src') if name == 'stuff_to_span' else None
                 ops.contrastive_lse(logits[:, :V], rank * nk, 0.5 / Lq, src, self.loss_acc[oi:oi + 1],
                                     self.diag[di] if src is not None else None)
+                if self.fwd_only:
+                    continue
                 ops.split_hilo(logits, dl_hi, dl_lo)                           # rows of dlogits sum to 0: keep 16 bits
                 dq = self.dE[q_off:q_off + Lq]
                 for r in range(world):
@@ -408,6 +426,10 @@ class PretrainEngine:
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self):
+        assert not self.fwd_only, 'the fp32 program is forward-only'
+        self._backward()
+
+    def _backward(self):
         """Backward of forward() given self.dE; fills self.p.grad (bf16, per rank, un-reduced).
         Three stages, in the order the flat gradient buffer is laid out (params.py), so that a data-parallel caller can
         all-reduce each finished range while the next stage runs: [scales, head, span, joint, token] -> audio -> vision."""

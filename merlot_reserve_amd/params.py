@@ -130,10 +130,11 @@ class ParamStore:
             self.mu = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
             self.nu = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.decay_flags = torch.tensor(flags, dtype=torch.uint8, device=self.device)
-        self.w, self.g = {}, {}
+        self.w, self.g, self.wm = {}, {}, {}       # bf16 working copy / bf16 grads / fp32 master, as 2-D kernel views
         for name, fshape, vshape, kind, fan in self.specs:
             o, n = self.offsets[name]
             self.w[name] = self.work[o:o + n].view(*vshape)
+            self.wm[name] = self.master[o:o + n].view(*vshape)
             self.g[name] = self.grad[o:o + n].view(*vshape)
         if init:
             self.load_tree(self.random_tree(seed))

@@ -178,3 +178,47 @@ def test_two_rank_contrastive_path_on_one_gpu(dev):
             e = relerr(total[o:o + n], Es[r].grad[o:o + n])
             print(f'rank {r} dE {name}: {e:.3e}')
             assert e <= 1e-2, (r, name, e)
+
+
+@pytest.mark.parametrize('hidden_size,B', [(128, 2), (256, 1)])
+def test_fp32_forward_parity_1e3(dev, hidden_size, B):
+    """The north-star forward bar: the fp32 program (mr_f32_* kernels on the fp32 master weights -- the reference's
+    use_bfloat16 = False arithmetic) against the fp32 oracle on identical inputs: every x / y tensor of the three
+    objectives and the loss within 1e-3 relative (measured ~1e-5); the integer decisions are shared (same plan)."""
+    from merlot_reserve_amd.config import Dims
+    from merlot_reserve_amd.engine import PretrainEngine
+    from merlot_reserve_amd.planner import build_plan
+    from merlot_reserve_amd.synthetic import make_batch
+    from oracle import ref_torch as R
+    cfg, store, _b, splits, z = tiny_setup(B=B, seed=11, device=dev, hidden_size=hidden_size)
+    batch = make_batch(cfg, B, seed=11, device=dev, float_dtype=torch.float32)
+    g = torch.Generator().manual_seed(3)                   # non-trivial biases / LN parameters / temperatures
+    tree = store.master_tree()
+
+    def jitter(t):
+        return {k: jitter(v) for k, v in t.items()} if isinstance(t, dict) else (t + 0.05 * torch.randn(t.shape, generator=g) if t.dim() == 1 else t)
+    store.load_tree(jitter(tree))
+    eng = PretrainEngine(cfg, B, store, dev, dtype=torch.float32)
+    eng.forward(batch, plan=build_plan(batch, Dims(cfg, B), splits, z))
+    eng.loss_and_grad_outputs()
+    torch.cuda.synchronize()
+    osp, oz = oracle_draws(splits, z)
+    with torch.no_grad():
+        preds = R.pretrain_forward(store.master_tree(), cfg, oracle_batch(batch), osp, oz)
+        loss, info = R.loss_fn_given_preds([preds])
+    outs = eng.outputs()
+    worst = 0.0
+    for k, k2, _ in SECTIONS:
+        assert outs[k][k2].dtype == torch.float32
+        e = relerr(outs[k][k2], preds[k][k2])
+        worst = max(worst, e)
+        assert e <= 1e-3, f'{k}/{k2}: rel err {e:.3e}'
+        emax = float(((outs[k][k2].cpu() - preds[k][k2]).abs().max() / preds[k][k2].abs().max()))
+        assert emax <= 1e-3, f'{k}/{k2}: max rel err {emax:.3e}'
+    li = eng.loss_info()
+    print(f'fp32 forward parity H={hidden_size}: worst rel-L2 {worst:.2e}, loss {li["loss"]:.6f} vs {float(loss):.6f}')
+    for k in ('imgs_to_audio', 'text_to_audio', 'stuff_to_span'):
+        assert abs(li[k] - float(info[k])) <= 1e-3 * abs(float(info[k])), (k, li[k], float(info[k]))
+    assert abs(li['loss'] - float(loss)) <= 1e-3 * abs(float(loss))
+    with pytest.raises(AssertionError):
+        eng.backward()                                      # the fp32 program is forward-only
