@@ -202,6 +202,18 @@ int mr_split_f32_to_bf16_hilo(const float* src, void* hi, void* lo, int64_t n, v
 int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
                         const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2, float eps,
                         float weight_decay, float sched, float neg_lr, float bias_corr1, float bias_corr2, void* stream);
+/* Finetuning chain (finetune/optimization.py:77-90: Adam with bias correction, subtract_old_weights, add_decayed_weights,
+ * linear schedule, -lr): as above plus `orig_bf16`, the bf16 copy of the initial parameters; under the decay mask
+ * (leaf ndim > 1 and size > 4096: finetune/optimization.py:74-75) u = u - wd * orig + wd * param. */
+int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                                 const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                                 float eps, float weight_decay, float sched, float neg_lr, float bias_corr1,
+                                 float bias_corr2, void* stream);
+/* ---- softmax cross-entropy over C <= 64 classes (finetune/vcr/qa_qar_joint_finetune.py:188-195) ----
+ * logits[r * row_stride + c * class_stride] fp32; loss_out += coef * sum_r -log_softmax(logits[r])[labels[r]];
+ * correct_out (nullable) += coef * #(argmax == label); dlogits_bf16 (nullable, same strides) = coef * (softmax - onehot). */
+int mr_softmax_xent(const float* logits, int64_t row_stride, int64_t class_stride, const int32_t* labels, int64_t rows,
+                    int64_t C, float coef, float* loss_out, float* correct_out, void* dlogits_bf16, void* stream);
 /* grads = nan_to_num(grads) in place (P:328), bf16, n % 8 == 0 */
 int mr_nan_to_num_bf16(void* g, int64_t n, void* stream);
 /* work_bf16 = bf16(master) (P:323-324) */

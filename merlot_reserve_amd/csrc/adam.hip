@@ -18,9 +18,13 @@ __device__ __forceinline__ float nan_to_num_f(float g) {
     return g;
 }
 
+// FT = the finetuning chain (finetune/optimization.py:77-90): after Adam, u -= wd * bf16(initial parameter), then
+// u += wd * parameter, both under the same mask.
+template <bool FT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, __bf16* __restrict__ work,
                                                    const __bf16* __restrict__ grad, __bf16* __restrict__ mu,
-                                                   __bf16* __restrict__ nu, const uint8_t* __restrict__ decay_flag, float c1,
+                                                   __bf16* __restrict__ nu, const __bf16* __restrict__ orig,
+                                                   const uint8_t* __restrict__ decay_flag, float c1,
                                                    float b1, float c2, float b2, float eps, float wd, float sched, float neg_lr,
                                                    float inv_bc1, float inv_bc2) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
@@ -32,7 +36,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, _
     const f32x4 p0 = *reinterpret_cast<const f32x4*>(master + i), p1 = *reinterpret_cast<const f32x4*>(master + i + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { p[e] = p0[e]; p[4 + e] = p1[e]; }
-    float mo[8], vo[8], wo[8];
+    float mo[8], vo[8], wo[8], og[8];
+    if (FT) unpack8(*reinterpret_cast<const u32x4*>(orig + i), og);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float ge = nan_to_num_f(g[e]);
@@ -46,6 +51,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, _
         const float err0 = fabsf(vb - v3), err1 = fabsf(vb * MISSING_PRECISION - v3);
         vo[e] = (err0 < err1) ? vb : -vb;
         float u = (nm * inv_bc1) / (sqrtf(nv * inv_bc2) + eps);                  // :104-110
+        if (FT && decay) u -= wd * og[e];                                        // finetune/optimization.py:30-31
         if (decay) u += wd * p[e];                                               // :182-184
         u = (u * sched) * neg_lr;                                                // :185-189
         p[e] += u;
@@ -88,11 +94,28 @@ extern "C" int mr_adam_bf16_update(float* master, void* work_bf16, const void* g
     MR_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "mr_adam_bf16_update: bias corrections must be > 0 (1 disables)");
     // (1 - b) evaluated like the reference: Python double subtraction, then cast to f32 (optimization.py:86, 91)
     const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
                        static_cast<__bf16*>(work_bf16), static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16),
-                       static_cast<__bf16*>(nu_bf16), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, sched, neg_lr,
-                       1.0f / bias_corr1, 1.0f / bias_corr2);
+                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, b1, c2, b2,
+                       eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
     MR_CHECK_LAUNCH("mr_adam_bf16_update");
+    return MR_OK;
+}
+
+extern "C" int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1,
+                                            float b2, float eps, float weight_decay, float sched, float neg_lr,
+                                            float bias_corr1, float bias_corr2, void* stream) {
+    MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && orig_bf16 && decay_flag_per_block,
+                 "mr_adam_bf16_update_finetune: null pointer");
+    MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update_finetune: n must be a positive multiple of 2048 (got %ld)", (long)n);
+    MR_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "mr_adam_bf16_update_finetune: bias corrections must be > 0");
+    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                       static_cast<__bf16*>(work_bf16), static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16),
+                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, b1, c2,
+                       b2, eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
+    MR_CHECK_LAUNCH("mr_adam_bf16_update_finetune");
     return MR_OK;
 }
 

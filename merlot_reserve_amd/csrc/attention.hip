@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
     const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
+    const float inv_S = 1.0f / (float)S;
 
     bf16x8 qf[QB][2], dof[QB][2];
     int64_t qi[QB];
@@ -321,7 +322,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(biased2<MASKED>(st[r], cq[qb], ck[r]) - lse2[qb]);
+                    float pv = __builtin_amdgcn_exp2f(biased2<MASKED>(st[r], cq[qb], ck[r]) - lse2[qb]);
+                    // a query row with no allowed key (PAD): every score is exactly -1e10, the softmax is uniform over the
+                    // S keys, and its LSE (-1e10 + ln S) is not representable in fp32: take P = 1/S instead of exp(s - lse)
+                    if (MASKED && lse2[qb] < 0.5f * NEG_BIG2) pv = (ck[r] == CODE_NONE) ? 0.f : inv_S;
                     ds[qb][kb][r] = pv * (dp[r] - del[qb]);
                 }
             }
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
     const int64_t seq = blockIdx.z, h = blockIdx.y, kbase = (int64_t)blockIdx.x * (64 * KB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
+    const float inv_S = 1.0f / (float)S;
 
     bf16x8 kf[KB][2], vf[KB][2];
     int64_t ki[KB];
@@ -458,7 +463,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
                     // query side code c4[r] (CODE_NONE: query beyond S -> p = 0), key side ck[kb]
                     float s = st[r] * SCALE2;
                     if (MASKED && !(c4[r] == ck[kb] && ck[kb] >= 0)) s += NEG_BIG2;
-                    const float pv = (c4[r] == CODE_NONE || ck[kb] == CODE_NONE) ? 0.f : __builtin_amdgcn_exp2f(s - l4[r]);
+                    float pv = (c4[r] == CODE_NONE || ck[kb] == CODE_NONE) ? 0.f : __builtin_amdgcn_exp2f(s - l4[r]);
+                    if (MASKED && l4[r] < 0.5f * NEG_BIG2 && c4[r] != CODE_NONE && ck[kb] != CODE_NONE) pv = inv_S;   // PAD query row: uniform
                     pp[kb][qb][r] = pv;
                     ds[kb][qb][r] = pv * (dp[r] - e4[r]);
                 }

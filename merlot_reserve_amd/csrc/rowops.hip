@@ -366,7 +366,44 @@ __global__ __launch_bounds__(256) void contrastive_lse_kernel(float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- softmax cross-entropy
+// finetune/vcr/qa_qar_joint_finetune.py:188-195: loss = -mean_r log_softmax(logits[r])[label[r]], is_right = mean(argmax == label);
+// one lane per row (C <= 64 classes); dlogits = coef * (softmax - onehot) written as bf16 at the same strides.
+__global__ void softmax_xent_kernel(const float* __restrict__ logits, int64_t row_stride, int64_t class_stride,
+                                    const int32_t* __restrict__ labels, int64_t rows, int C, float coef,
+                                    float* __restrict__ loss_out, float* __restrict__ correct_out, __bf16* __restrict__ dlogits) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* x = logits + r * row_stride;
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+        const float v = x[c * class_stride];
+        if (v > mx) { mx = v; arg = c; }          // first maximum, like argmax
+    }
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(x[c * class_stride] - mx);
+    const int lab = labels[r];
+    const float logp = x[lab * class_stride] - mx - logf(den);
+    atomicAdd(loss_out, -coef * logp);
+    if (correct_out != nullptr) atomicAdd(correct_out, coef * (arg == lab ? 1.0f : 0.0f));
+    if (dlogits != nullptr) {
+        const float inv = 1.0f / den;
+        for (int c = 0; c < C; ++c)
+            dlogits[r * row_stride + c * class_stride] = (__bf16)(coef * (expf(x[c * class_stride] - mx) * inv - (c == lab ? 1.0f : 0.0f)));
+    }
+}
+
 }  // namespace
+
+extern "C" int mr_softmax_xent(const float* logits, int64_t row_stride, int64_t class_stride, const int32_t* labels, int64_t rows,
+                               int64_t C, float coef, float* loss_out, float* correct_out, void* dlogits_bf16, void* stream) {
+    MR_CHECK_ARG(logits && labels && loss_out && rows > 0 && C > 0 && C <= 64, "mr_softmax_xent: bad args (C <= 64)");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), logits,
+                       row_stride, class_stride, labels, rows, (int)C, coef, loss_out, correct_out, static_cast<__bf16*>(dlogits_bf16));
+    MR_CHECK_LAUNCH("mr_softmax_xent");
+    return MR_OK;
+}
 
 extern "C" int mr_segment_sum(const void* src0, int64_t ld0, int64_t n0, const void* src1, int64_t ld1, int64_t n1,
                               const void* src2, int64_t ld2, int64_t n2, const int32_t* indptr, const int32_t* indices,

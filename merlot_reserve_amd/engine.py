@@ -39,116 +39,35 @@ class TowerState:
         self.stats = f(2 * L + 2, 2, M)       # [ln index][mean|rstd][row]; index 0 = pre_ln, 1+2l / 2+2l = layer l, last = final
 
 
-class PretrainEngine:
-    def __init__(self, config, B, params, device, rank=0, world=1, dtype=BF16):
-        """dtype = torch.float32 builds the FORWARD-ONLY fp32 program (forward + loss on the fp32 master weights through
-        the mr_f32_* kernels: the reference's use_bfloat16 = False arithmetic, used for the 1e-3 forward-parity check);
-        the default bf16 program is the training path."""
-        self.config, self.p, self.dev = config, params, torch.device(device)
-        self.d = d = Dims(config, B)
-        self.rank, self.world = rank, world
-        self.dtype = dtype
-        self.fwd_only = dtype != BF16
-        self.W = params.w if dtype == BF16 else params.wm
-        dev, H = self.dev, d.H
-        self.tables = {k: torch.as_tensor(v).to(dev) for k, v in static_tables(d).items()}
-        z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
+class TowerEngine:
+    """What every program built from TransformerEncoder towers shares (pretraining step, VCR finetuning step): the
+    encoder forward / hand-written backward over a TowerState, the CLS head + attention pool of the vision / audio
+    towers, the two scratch sets (main / side stream) and the device copies of the per-batch plan.
+    Subclasses set: self.p (ParamStore), self.W (weight views), self.dev, self.dtype, self.fwd_only, self.side_stream,
+    self.sc_main / self.sc_side / self.cur (via _make_scratch), self.plan_dev / _plan_caps / _plan_views / plan_frozen."""
+
+    def _make_scratch(self, Ms, Gs, Ps, H, nh):
+        dev = self.dev
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
 
-        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype)
-        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype)
-        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype)
-        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype)
-        Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
-
-        # attention pools
-        self.Gv, self.Ga = d.Nv * d.hw4, d.Na * d.a_tok
-        self.v_qin, self.v_q, self.v_po, self.imgs_seq = z(self.Gv, H), z(self.Gv, H), z(self.Gv, H), z(self.Gv, H)
-        self.v_k, self.v_v = z(self.tv.M, H), z(self.tv.M, H)
-        self.v_probs = f(self.Gv, d.nh, d.pr * d.pr)
-        self.v_cls = z(d.Nv, H)
-        self.a_pad_K = (d.a_patch * 65 + 7) // 8 * 8
-        self.a_in = z(d.Na * d.a_len, self.a_pad_K)
-        self.a_qin, self.a_q, self.a_po, self.audio_seq = z(self.Ga, H), z(self.Ga, H), z(self.Ga, H), z(self.Ga, H)
-        self.a_k, self.a_v = z(self.ta.M, H), z(self.ta.M, H)
-        self.a_probs = f(self.Ga, d.nh, d.a_pool)
-        self.a_cls = z(d.Na, H)
-        self.hj = z(self.tj.M, H)
-        self.s_cls = z(d.Ns, H)
-
-        # contrastive sections (rows per rank), order of the packed buffer E
-        n_i2a, n_t2a, n_ext, n_s2s = B * d.nseg, B * d.ntrg, B * (d.nspans - d.ntrg), B * d.n_inc
-        self.sec = {}
-        off = 0
-        for name, n in (('i2a_x', n_i2a), ('i2a_y', n_i2a), ('t2a_x', n_t2a), ('t2a_y', n_t2a), ('t2a_ye', n_ext),
-                        ('s2s_x', n_s2s), ('s2s_y', n_s2s)):
-            self.sec[name] = (off, n)
-            off += n
-        self.R = off
-        self.n_pool = n_i2a + n_t2a + n_s2s
-        self.Xpool = z(self.n_pool, H)
-        self.acls_g = z(d.Na, H)
-        self.E, self.dE = z(self.R, H), z(self.R, H)
-        self.inv_norm = f(self.R)
-        self.loss_acc = f(3)
-        self.diag = f(2, 6)
-        self.dls = f(3)
-        # objectives: (name, x section, y sections (gathered across ranks), scale index)
-        self.objectives = [('imgs_to_audio', 'i2a_x', ('i2a_y',), 0), ('text_to_audio', 't2a_x', ('t2a_y', 't2a_ye'), 1),
-                           ('stuff_to_span', 's2s_x', ('s2s_y',), 2)]
-        self.logit_bufs = {}
-        for name, xs, ys, _ in self.objectives:
-            nx = self.sec[xs][1]
-            ny = sum(self.sec[y][1] for y in ys)
-            ny0 = self.sec[ys[0]][1]
-            for direction, (L_, V_) in (('xy', (nx, world * ny)), ('yx', (ny0, world * nx))):
-                ldv = (V_ + 7) // 8 * 8
-                self.logit_bufs[(name, direction)] = (f(L_, ldv), z(L_, ldv), z(L_, ldv), V_)
-
-        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
-        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
-        self.cur = None
-        if self.fwd_only:
-            return
-        # backward scratch
-        self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
-        self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
-        # Two scratch sets: the audio tower runs on a side stream concurrently with the vision tower (forward and
-        # backward), so that one tower's kernels fill the CUs the other leaves idle (partial last rounds of the
-        # persistent GEMMs, small kernels).  `self.cur` is the set the ops being ISSUED right now may use.
         class Scratch:
             pass
-
-        def make_scratch(Ms, Gs, Ps):
-            sc = Scratch()
-            sc.T_a, sc.T_d1, sc.T_d2 = z(Ms, H), z(Ms, H), z(Ms, H)
-            sc.T_q, sc.T_h = z(Ms, 3 * H), z(Ms, 4 * H)
-            sc.delta = f(Ms * d.nh)
-            sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
-            sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
-            sc.cs_ws = ops.colsum_workspace(4 * H, dev)
-            # a layer's four deferred reductions (2 LayerNorm, 2 bias) each keep their partial rows until the layer's
-            # single mr_reduce_partials launch
-            sc.ln_ws2 = ops.layernorm_bwd_workspace(H, dev)
-            sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
-            sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
-            sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
-            sc.Dpatch = z(Ps, H)
-            return sc
-        self.sc_main = make_scratch(Mmax, max(self.Gv, self.Ga), max(d.Nv * d.hw, d.Na * d.a_len))   # also serves audio when issued in line
-        self.sc_side = make_scratch(self.ta.M, self.Ga, d.Na * d.a_len)
-        self.cur = self.sc_main
-        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
-        self.dXpool = z(self.n_pool, H)
-        self.d_hj = z(self.tj.M, H)
-        self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
-        self.d_audio_seq, self.d_imgs_seq = z(self.Ga, H), z(self.Gv, H)
-        # static gather lists: patch rows of a [nseq, S] grid without the CLS rows
-        self.unpad_v = self._unpad_csr(d.Nv, d.Sv)
-        self.unpad_a = self._unpad_csr(d.Na, d.Sa)
-
-        # (device copies of the per-batch plan -- plan_dev / _plan_caps / _plan_views, set above -- have fixed sizes where
-        # possible; index lists are padded to capacity)
+        sc = Scratch()
+        sc.T_a, sc.T_d1, sc.T_d2 = z(Ms, H), z(Ms, H), z(Ms, H)
+        sc.T_q, sc.T_h = z(Ms, 3 * H), z(Ms, 4 * H)
+        sc.delta = f(Ms * nh)
+        sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
+        sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
+        sc.cs_ws = ops.colsum_workspace(4 * H, dev)
+        # a layer's four deferred reductions (2 LayerNorm, 2 bias) each keep their partial rows until the layer's
+        # single mr_reduce_partials launch
+        sc.ln_ws2 = ops.layernorm_bwd_workspace(H, dev)
+        sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
+        sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
+        sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
+        sc.Dpatch = z(Ps, H)
+        return sc
 
     def _on_side(self, fn):
         """Issue fn()'s kernels on the side stream (forked from / joined to the current stream by the caller)."""
@@ -183,7 +102,7 @@ class PretrainEngine:
             if k not in self.plan_dev or t.numel() > cap:
                 assert not self.plan_frozen, f'plan buffer {k} would be reallocated after graph capture'
                 # index lists are bounded by the number of joint + span positions; everything else has a fixed size
-                newcap = (self.tj.M + self.ts.M + 64) if k.endswith('_idx') else t.numel()
+                newcap = self._idx_capacity() if k.endswith('_idx') else t.numel()
                 newcap = max(newcap, t.numel())
                 self.plan_dev[k] = torch.zeros(newcap, dtype=t.dtype, device=self.dev)
                 self._plan_caps[k] = newcap
@@ -193,6 +112,10 @@ class PretrainEngine:
 
     def _pl(self, k):
         return self._plan_views[k]
+
+    def _idx_capacity(self):
+        """Upper bound on the length of any index list of the plan (so the buffers never move after capture)."""
+        return self.tj.M + self.ts.M + 64
 
     # ------------------------------------------------------------------------------------------ encoder
     def _names(self, prefix, l):
@@ -299,6 +222,100 @@ class PretrainEngine:
         D = self.encoder_backward(st, prefix_t, rot, None, D)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
+
+
+
+class PretrainEngine(TowerEngine):
+    def __init__(self, config, B, params, device, rank=0, world=1, dtype=BF16):
+        """dtype = torch.float32 builds the FORWARD-ONLY fp32 program (forward + loss on the fp32 master weights through
+        the mr_f32_* kernels: the reference's use_bfloat16 = False arithmetic, used for the 1e-3 forward-parity check);
+        the default bf16 program is the training path."""
+        self.config, self.p, self.dev = config, params, torch.device(device)
+        self.d = d = Dims(config, B)
+        self.rank, self.world = rank, world
+        self.dtype = dtype
+        self.fwd_only = dtype != BF16
+        self.W = params.w if dtype == BF16 else params.wm
+        dev, H = self.dev, d.H
+        self.tables = {k: torch.as_tensor(v).to(dev) for k, v in static_tables(d).items()}
+        z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
+        f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+
+        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype)
+        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype)
+        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype)
+        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype)
+        Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
+
+        # attention pools
+        self.Gv, self.Ga = d.Nv * d.hw4, d.Na * d.a_tok
+        self.v_qin, self.v_q, self.v_po, self.imgs_seq = z(self.Gv, H), z(self.Gv, H), z(self.Gv, H), z(self.Gv, H)
+        self.v_k, self.v_v = z(self.tv.M, H), z(self.tv.M, H)
+        self.v_probs = f(self.Gv, d.nh, d.pr * d.pr)
+        self.v_cls = z(d.Nv, H)
+        self.a_pad_K = (d.a_patch * 65 + 7) // 8 * 8
+        self.a_in = z(d.Na * d.a_len, self.a_pad_K)
+        self.a_qin, self.a_q, self.a_po, self.audio_seq = z(self.Ga, H), z(self.Ga, H), z(self.Ga, H), z(self.Ga, H)
+        self.a_k, self.a_v = z(self.ta.M, H), z(self.ta.M, H)
+        self.a_probs = f(self.Ga, d.nh, d.a_pool)
+        self.a_cls = z(d.Na, H)
+        self.hj = z(self.tj.M, H)
+        self.s_cls = z(d.Ns, H)
+
+        # contrastive sections (rows per rank), order of the packed buffer E
+        n_i2a, n_t2a, n_ext, n_s2s = B * d.nseg, B * d.ntrg, B * (d.nspans - d.ntrg), B * d.n_inc
+        self.sec = {}
+        off = 0
+        for name, n in (('i2a_x', n_i2a), ('i2a_y', n_i2a), ('t2a_x', n_t2a), ('t2a_y', n_t2a), ('t2a_ye', n_ext),
+                        ('s2s_x', n_s2s), ('s2s_y', n_s2s)):
+            self.sec[name] = (off, n)
+            off += n
+        self.R = off
+        self.n_pool = n_i2a + n_t2a + n_s2s
+        self.Xpool = z(self.n_pool, H)
+        self.acls_g = z(d.Na, H)
+        self.E, self.dE = z(self.R, H), z(self.R, H)
+        self.inv_norm = f(self.R)
+        self.loss_acc = f(3)
+        self.diag = f(2, 6)
+        self.dls = f(3)
+        # objectives: (name, x section, y sections (gathered across ranks), scale index)
+        self.objectives = [('imgs_to_audio', 'i2a_x', ('i2a_y',), 0), ('text_to_audio', 't2a_x', ('t2a_y', 't2a_ye'), 1),
+                           ('stuff_to_span', 's2s_x', ('s2s_y',), 2)]
+        self.logit_bufs = {}
+        for name, xs, ys, _ in self.objectives:
+            nx = self.sec[xs][1]
+            ny = sum(self.sec[y][1] for y in ys)
+            ny0 = self.sec[ys[0]][1]
+            for direction, (L_, V_) in (('xy', (nx, world * ny)), ('yx', (ny0, world * nx))):
+                ldv = (V_ + 7) // 8 * 8
+                self.logit_bufs[(name, direction)] = (f(L_, ldv), z(L_, ldv), z(L_, ldv), V_)
+
+        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
+        self.cur = None
+        if self.fwd_only:
+            return
+        # backward scratch
+        self.Dv, self.Da, self.Dj, self.Ds = z(self.tv.M, H), z(self.ta.M, H), z(self.tj.M, H), z(self.ts.M, H)
+        self.d_v_cls, self.d_s_cls = z(d.Nv, H), z(d.Ns, H)
+        # Two scratch sets: the audio tower runs on a side stream concurrently with the vision tower (forward and
+        # backward), so that one tower's kernels fill the CUs the other leaves idle (partial last rounds of the
+        # persistent GEMMs, small kernels).  `self.cur` is the set the ops being ISSUED right now may use.
+        self.sc_main = self._make_scratch(Mmax, max(self.Gv, self.Ga), max(d.Nv * d.hw, d.Na * d.a_len), H, d.nh)   # also serves audio when issued in line
+        self.sc_side = self._make_scratch(self.ta.M, self.Ga, d.Na * d.a_len, H, d.nh)
+        self.cur = self.sc_main
+        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
+        self.dXpool = z(self.n_pool, H)
+        self.d_hj = z(self.tj.M, H)
+        self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
+        self.d_audio_seq, self.d_imgs_seq = z(self.Ga, H), z(self.Gv, H)
+        # static gather lists: patch rows of a [nseq, S] grid without the CLS rows
+        self.unpad_v = self._unpad_csr(d.Nv, d.Sv)
+        self.unpad_a = self._unpad_csr(d.Na, d.Sa)
+
+        # (device copies of the per-batch plan -- plan_dev / _plan_caps / _plan_views, set above -- have fixed sizes where
+        # possible; index lists are padded to capacity)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch, plan=None, draws=None):

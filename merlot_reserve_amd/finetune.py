@@ -1,0 +1,324 @@
+"""VCR finetuning step on the MI355X kernels (BASELINE config 5): the reference's
+finetune/vcr/qa_qar_joint_finetune.py (F) + finetune/optimization.py (FO), name for name.
+
+    reference                                                     here
+    ------------------------------------------------------------  ----------------------------------------------------
+    MerlotReserveVCR.from_config / __call__(batch)      F:144-170 MerlotReserveVCR.from_config(config, device=...) /
+                                                                  .apply({'params': p}, batch) -> logits [B, 2, A] fp32
+    train_loss_fn(state, params, batch)                 F:188-195 train_loss_fn(...) -> (loss, {'is_right', 'loss'})
+    construct_finetuning_train_state(opt_config, model, FO:56-105 same name -> (state, tx_fns=None)
+      params)
+    finetune_train_step(state, batch, loss_fn, tx_fns)  FO:106-191 same name -> (state, loss_info)
+
+One process per GPU; with a merlot_reserve_amd.dist.Comm the bf16 gradients are averaged over ranks (pmean, FO:143)
+in two buckets, the first overlapped with the vision tower's backward.  The optimizer is replicated: the 8-way
+sharding of the Adam state (FO:38-53, 148-171) is a 16 GB-TPU-core memory measure, not arithmetic.
+
+batch (one device's slice): 'image' [B, h*w, 768] bf16 on the GPU, 'answers' [B, 2, A, T] int32 (numpy),
+'labels' [B, 2] int32 (numpy).
+
+Program: ViT (S = h*w + 1) + attention pool -> [B, V, H]; ONE index-driven gather builds the 2*A*B joint sequences
+[T text tokens | V vision tokens] (the 8-fold `repeat` of the image rows, F:157, is just the gather list);
+joint encoder with one validity code per position; the row at the first MASK of every sequence; Dense(1); softmax
+cross-entropy over the A answers; hand-written backward through the same kernels as the pretraining step.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import BF16, F32, I32, TowerEngine, TowerState
+from .params import VOCAB, ParamStore, decay_finetune, vcr_param_specs
+from .planner import MASK, PADDING, csr_from_pairs, csr_gather, rot_scale_table, rotary_coords_2d
+
+
+def lr_scale_linearwarmup_lineardecay(step, num_warmup_steps, num_train_steps):
+    """pretrain/optimization.py:140-155 in float32"""
+    f = np.float32
+    step = f(step)
+    if step < num_warmup_steps:
+        return float(step / f(num_warmup_steps))
+    post = (step - f(num_warmup_steps)) / f(num_train_steps - num_warmup_steps + 1.0)
+    return float(f(1.0) - min(post, f(1.0)))
+
+
+class VCRDims:
+    def __init__(self, config, B):
+        d, m = config['data'], config['model']
+        self.B, self.H = B, m['hidden_size']
+        self.nh = self.H // 64
+        self.gh, self.gw = m['output_grid']
+        self.hw = self.gh * self.gw
+        self.pr = m['vit_pooling_ratio']
+        self.V = self.hw // (self.pr ** 2)
+        self.pp3 = m['vit_patch_size'] ** 2 * 3
+        self.A = d.get('num_answers', 4)
+        self.T = d['lang_seq_len']
+        self.n = B * 2 * self.A
+        self.Sv, self.Sj = self.hw + 1, self.T + self.V
+        self.Lv, self.Lj = m['vit_num_layers'], m['joint_num_layers']
+
+
+def build_vcr_plan(answers, d):
+    """Every integer decision of MerlotReserveVCR.__call__ (F:150-168), from `answers` [B, 2, A, T] alone."""
+    ans = np.asarray(answers).astype(np.int64).reshape(d.n, d.T)
+    assert ans.min() >= 0 and ans.max() < VOCAB, 'token id out of range'
+    b_of = np.arange(d.n) // (2 * d.A)
+    codes = np.concatenate([ans, VOCAB + b_of[:, None] * d.V + np.arange(d.V)[None]], 1)            # [n, Sj]
+    plan = {}
+    plan['joint_gather_indptr'], plan['joint_gather_idx'] = csr_gather(codes)
+    valid = np.concatenate([ans != PADDING, np.ones((d.n, d.V), bool)], 1)                          # M:726-728
+    plan['joint_code'] = np.where(valid, 0, -1).astype(np.int32).reshape(-1)
+    pool_idx = np.argmax((ans == MASK).astype(np.float32), 1)                                       # F:165: first MASK, else 0
+    rows = np.arange(d.n) * d.Sj + pool_idx
+    plan['pool_indptr'], plan['pool_idx'] = np.arange(d.n + 1, dtype=np.int32), rows.astype(np.int32)
+    plan['poolT_indptr'], plan['poolT_idx'] = csr_from_pairs(rows, np.arange(d.n), d.n * d.Sj)
+    # transpose of the embedding gather; PAD positions carry exactly zero gradient (masked keys, and never pooled)
+    pos_rows = (np.arange(d.n)[:, None] * d.Sj + np.arange(d.T)[None])
+    keep = ans != PADDING
+    # ... unless the pooled position is itself PAD (a sequence with no MASK whose first token is PAD): that query row
+    # attends uniformly to every position (all its keys carry the same -1e10, M:353-356), so the whole sequence gets gradient
+    keep |= (ans[np.arange(d.n), pool_idx] == PADDING)[:, None]
+    plan['embT_indptr'], plan['embT_idx'] = csr_from_pairs(ans[keep], pos_rows[keep], VOCAB)
+    plan['pool_pos'] = pool_idx.astype(np.int32)
+    return plan
+
+
+class VCREngine(TowerEngine):
+    def __init__(self, config, B, params, device):
+        self.config, self.p, self.dev = config, params, torch.device(device)
+        self.d = d = VCRDims(config, B)
+        self.dtype, self.fwd_only, self.W = BF16, False, params.w
+        dev, H = self.dev, d.H
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        self.tv = TowerState(B * d.Sv, H, d.Lv, B, d.Sv, dev)
+        self.tj = TowerState(d.n * d.Sj, H, d.Lj, d.n, d.Sj, dev)
+        # static tables: ViT rotary / pool rows; joint rotary (text: segment 0, token index 1..T; vision: pooled-grid (h, w),
+        # segment 0 -- identical for every sequence: M:697-720 with token_segment_idx = 0, F:161)
+        self.vit_rot = torch.from_numpy(rot_scale_table(np.concatenate([np.zeros((1, 2)), rotary_coords_2d(d.gh, d.gw)], 0))).to(dev)
+        pr, h2, w2 = d.pr, d.gh // d.pr, d.gw // d.pr
+        n_, i2, j2, di, dj = np.meshgrid(np.arange(B), np.arange(h2), np.arange(w2), np.arange(pr), np.arange(pr), indexing='ij')
+        self.vit_pool_rows = torch.from_numpy((n_ * d.Sv + 1 + (i2 * pr + di) * d.gw + j2 * pr + dj).reshape(B * h2 * w2, pr * pr).astype(np.int32)).to(dev)
+        coords = np.zeros((d.Sj, 4))
+        coords[:d.T, 3] = (1.0 + np.arange(d.T)) / 1024.0
+        coords[d.T:, :2] = rotary_coords_2d(h2, w2)
+        self.joint_rot = torch.from_numpy(rot_scale_table(coords)).to(dev)
+        # static transpose of the image-row tiling: d_imgs_seq[b*V + i] = sum_j Dj[(b*2A + j)*Sj + T + i]
+        bb, ii, jj = np.meshgrid(np.arange(B), np.arange(d.V), np.arange(2 * d.A), indexing='ij')
+        ip, ix = csr_from_pairs((bb * d.V + ii).reshape(-1), ((bb * 2 * d.A + jj) * d.Sj + d.T + ii).reshape(-1), B * d.V)
+        self.visT = (torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev))
+        self.unpad_v = self._unpad_csr(B, d.Sv)
+        G = B * d.V
+        self.v_qin, self.v_q, self.v_po, self.imgs_seq = z(G, H), z(G, H), z(G, H), z(G, H)
+        self.v_k, self.v_v = z(self.tv.M, H), z(self.tv.M, H)
+        self.v_probs = f(G, d.nh, pr * pr)
+        self.v_cls = z(B, H)
+        self.pooled_h, self.d_pooled = z(d.n, H), z(d.n, H)
+        self.logits = f(d.n, 8)                       # column 0 = the Dense(1) output
+        self.dlogits = z(d.n, 8)
+        self.loss_acc = f(2)                          # [loss, is_right]
+        self.labels_dev = torch.zeros(2 * B, dtype=I32, device=dev)
+        self.Dv, self.Dj = z(self.tv.M, H), z(self.tj.M, H)
+        self.d_imgs_seq, self.d_v_cls = z(G, H), z(B, H)
+        Mmax = max(self.tv.M, self.tj.M)
+        self.sc_main = self._make_scratch(Mmax, G, B * d.hw, H, d.nh)
+        self.sc_side = self.sc_main                   # single-stream program: the two towers are strictly sequential
+        self.cur = self.sc_main
+        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
+        self.side_stream = None
+        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
+
+    def _idx_capacity(self):
+        return self.tj.M + 64
+
+    def forward(self, batch, plan=None):
+        d, W = self.d, self.W
+        if plan is None:
+            plan = build_vcr_plan(batch['answers'], d)
+        self.set_plan(plan)
+        self.labels_dev.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(batch['labels']).astype(np.int32).reshape(-1))), non_blocking=True)
+        return self.forward_device(batch['image'])
+
+    def forward_device(self, image):
+        d, W, tv, tj = self.d, self.W, self.tv, self.tj
+        self._images2d = image.reshape(d.B * d.hw, d.pp3)
+        ops.gemm(self._images2d, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
+                                      self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.imgs_seq, self.v_cls)
+        ops.segment_sum([W['token_encoder/Embed_0/embedding'], self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
+        self.encoder_forward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'))
+        ops.segment_sum([tj.xf], self._pl('pool_indptr'), self._pl('pool_idx'), self.pooled_h)
+        ops.gemm(self.pooled_h, W['proj/kernel'], self.logits, transB=True)          # Dense(1): [n, H] x [1, H]^T -> column 0
+        return self.logits[:, 0].view(d.B, 2, d.A)
+
+    def loss_and_grad_logits(self):
+        """train_loss_fn (F:188-195) on the device + dL/dlogits."""
+        d = self.d
+        self.loss_acc.zero_()
+        ops.softmax_xent(self.logits, d.A * 8, 8, self.labels_dev, 2 * d.B, d.A, 1.0 / (2 * d.B), self.loss_acc[0:1], self.loss_acc[1:2], self.dlogits)
+        return self.loss_acc
+
+    def backward(self):
+        self.backward_stage_joint()
+        self.backward_stage_vision()
+
+    def backward_stage_joint(self):
+        d, W, G, tj = self.d, self.W, self.p.g, self.tj
+        dl = self.dlogits[:, :1]
+        ops.gemm(dl, self.pooled_h, G['proj/kernel'], transA=True)                   # d proj [1, H] = dlogits^T . pooled_h
+        ops.gemm(dl, W['proj/kernel'], self.d_pooled)                                # d pooled_h = dlogits . proj^T
+        ops.segment_sum([self.d_pooled], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.Dj)   # zero except the pooled rows
+        Dj = self.encoder_backward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'), self.Dj)
+        ops.segment_sum([Dj], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
+        ops.segment_sum([Dj], self.visT[0], self.visT[1], self.d_imgs_seq)
+
+    def backward_stage_vision(self):
+        d, G, tv = self.d, self.p.g, self.tv
+        Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
+                                            self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.d_imgs_seq,
+                                            self.d_v_cls, self.Dv)
+        Dp = self.cur.Dpatch[:d.B * d.hw]
+        ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
+        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
+        ops.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
+
+    def loss_info(self):
+        la = self.loss_acc.tolist()
+        return {'loss': la[0], 'is_right': la[1]}
+
+
+# ------------------------------------------------------------------------------------------------ reference-named API
+class MerlotReserveVCR:
+    """F:144-170"""
+
+    def __init__(self, config, device='cuda:0', rank=0, world=1, comm=None, seed=0):
+        self.config, self.device, self.rank, self.world, self.comm, self.seed = config, torch.device(device), rank, world, comm, seed
+        self.params_store, self.engine, self._last_tree = None, None, None
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        if 'model' not in config or 'data' not in config:
+            raise ValueError("config must have 'model' and 'data' sections (the reference's YAML schema)")
+        return cls(config, **kwargs)
+
+    def _ensure(self, batch):
+        B = int(batch['image'].shape[0])
+        if self.engine is None:
+            self.params_store = ParamStore(self.config, self.device, seed=self.seed, specs=vcr_param_specs(self.config),
+                                           decay_rule=decay_finetune, with_orig=True)
+            self.engine = VCREngine(self.config, B, self.params_store, self.device)
+        elif self.engine.d.B != B:
+            raise ValueError(f'this model was initialised for {self.engine.d.B} examples per device, got {B}')
+        return self.engine
+
+    def init_from_dummy_batch(self, dummy_batch):
+        self._ensure(dummy_batch)
+        self._last_tree = self.params_store.master_tree()
+        return self._last_tree
+
+    def _load(self, variables):
+        if variables is None:
+            return
+        tree = variables['params'] if 'params' in variables else variables
+        if tree is not self._last_tree:
+            # a pretrained tree still holds audio_encoder / head / span_encoder (popped at F:181-183) -- they are not read
+            self.params_store.load_tree(tree)
+            self._last_tree = tree
+
+    def apply(self, variables, batch):
+        eng = self._ensure(batch)
+        self._load(variables)
+        return eng.forward(batch)
+
+    def __call__(self, batch):
+        return self.apply(None, batch)
+
+
+class FinetuneTrainState:
+    def __init__(self, model, opt_config):
+        self._model, self.opt_config, self.step = model, dict(opt_config), 0
+        self.apply_fn = model.apply
+
+    @property
+    def params(self):
+        return self._model.params_store.master_tree()
+
+    def apply_gradients(self):
+        """FO:77-90 + apply_updates, one fused launch over the flat buffers."""
+        oc, p = self.opt_config, self._model.params_store
+        assert oc.get('use_bfloat16_adam', True)
+        sched = lr_scale_linearwarmup_lineardecay(self.step, oc['num_warmup_steps'], oc['num_train_steps'])
+        b1, b2 = oc.get('beta_1', 0.9), oc.get('beta_2', 0.98)
+        bc1 = bc2 = 1.0
+        if oc.get('do_bias_correction', True):
+            bc1, bc2 = 1.0 - b1 ** (self.step + 1), 1.0 - b2 ** (self.step + 1)
+        ops.adam_bf16_update_finetune(p.master, p.work, p.grad, p.mu, p.nu, p.orig, p.decay_flags, b1, b2, oc.get('eps', 1e-6),
+                                      oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
+        self.step += 1
+        return self
+
+
+def construct_finetuning_train_state(opt_config, model, params=None, only_state=False):
+    """FO:56-105.  Returns (state, tx_fns) like the reference (tx_fns is None: the chain is one fused kernel)."""
+    if model.engine is None:
+        raise ValueError('call model.init_from_dummy_batch(batch) first')
+    if params is not None:
+        model._load({'params': params})
+    state = FinetuneTrainState(model, opt_config)
+    return state if only_state else (state, None)
+
+
+def train_loss_fn(state, params, batch):
+    """F:188-195: forward + softmax cross-entropy; returns (loss, {'is_right', 'loss'}) as host floats."""
+    model = state._model
+    model.apply(None if params is None else {'params': params}, batch)
+    model.engine.loss_and_grad_logits()
+    info = model.engine.loss_info()
+    return info['loss'], info
+
+
+def finetune_train_step(state, batch, loss_fn=None, tx_fns=None, scan_minibatch=False):
+    """FO:106-191: bf16 parameter copy -> forward -> loss -> backward -> nan_to_num -> mean over ranks -> optimizer."""
+    if scan_minibatch:
+        raise NotImplementedError('scan_minibatch (a TPU memory measure) is not needed with 288 GB of HBM')
+    model = state._model
+    eng = model._ensure(batch)
+    eng.forward(batch)
+    eng.loss_and_grad_logits()
+    comm, p = model.comm, model.params_store
+    if comm is not None:
+        v0, v1 = p.tower_ranges['vision_encoder']
+        assert v1 == p.total
+        eng.backward_stage_joint()
+        ops.nan_to_num_(p.grad[:v0])
+        w0 = comm.allreduce_mean_async(p.grad[:v0])              # overlaps the vision tower's backward
+        eng.backward_stage_vision()
+        ops.nan_to_num_(p.grad[v0:])
+        w1 = comm.allreduce_mean_async(p.grad[v0:])
+        for w in (w0, w1):
+            if w is not None:
+                w.wait()
+    else:
+        eng.backward()
+    state.apply_gradients()
+    info = eng.loss_info()
+    if comm is not None and comm.world > 1:
+        t = torch.tensor([info['loss'], info['is_right']], dtype=torch.float32, device=eng.dev)
+        comm.allreduce_mean(t)
+        info = {'loss': float(t[0]), 'is_right': float(t[1])}
+    return state, info
+
+
+def make_vcr_batch(config, B, seed=0, device='cpu'):
+    """Synthetic VCR batch with the structure of finetune/data: answers = [question tokens, MASK, answer tokens, PAD...]."""
+    d = VCRDims(config, B)
+    rng = np.random.default_rng(seed)
+    ans = np.zeros((B, 2, d.A, d.T), dtype=np.int32)
+    for idx in np.ndindex(B, 2, d.A):
+        nq, na = int(rng.integers(4, d.T // 3)), int(rng.integers(2, d.T // 3))
+        ans[idx][:nq] = rng.integers(10, VOCAB, size=nq)
+        ans[idx][nq] = MASK
+        ans[idx][nq + 1:nq + 1 + na] = rng.integers(10, VOCAB, size=na)
+    g = torch.Generator().manual_seed(seed)
+    return {'image': torch.rand(B, d.hw, d.pp3, generator=g).to(torch.bfloat16).to(device), 'answers': ans,
+            'labels': rng.integers(0, d.A, size=(B, 2)).astype(np.int32)}

@@ -318,3 +318,14 @@ def nan_to_num_(g):
 def cast_params(master, work):
     check(_lib.load().mr_cast_f32_to_bf16_params(master.data_ptr(), work.data_ptr(), master.numel(), _stream()),
           'mr_cast_f32_to_bf16_params')
+
+
+def adam_bf16_update_finetune(master, work, grad, mu, nu, orig, decay_flags, b1, b2, eps, weight_decay, sched, neg_lr, bc1, bc2):
+    check(_lib.load().mr_adam_bf16_update_finetune(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
+                                                   orig.data_ptr(), decay_flags.data_ptr(), master.numel(), b1, b2, eps,
+                                                   weight_decay, sched, neg_lr, bc1, bc2, _stream()), 'mr_adam_bf16_update_finetune')
+
+
+def softmax_xent(logits, row_stride, class_stride, labels, rows, C, coef, loss_out, correct_out=None, dlogits=None):
+    check(_lib.load().mr_softmax_xent(logits.data_ptr(), row_stride, class_stride, labels.data_ptr(), rows, C, coef,
+                                      loss_out.data_ptr(), _ptr(correct_out), _ptr(dlogits), _stream()), 'mr_softmax_xent')

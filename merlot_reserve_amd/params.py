@@ -91,6 +91,8 @@ def init_leaf(kind, flax_shape, fan_in, H, gen):
         return torch.ones(flax_shape)
     if kind == 'normal02':
         return torch.randn(flax_shape, generator=gen) * 0.02
+    if kind == 'normal001':                      # qa_qar_joint_finetune.py:184
+        return torch.randn(flax_shape, generator=gen) * 0.01
     if kind == 'kernel':
         return _trunc_normal(flax_shape, min(18.0 / fan_in, 0.02) / math.sqrt(2.0), gen)
     if kind == 'lecun':
@@ -103,12 +105,41 @@ def init_leaf(kind, flax_shape, fan_in, H, gen):
     raise ValueError(kind)
 
 
+def vcr_param_specs(config):
+    """Parameter tree of MerlotReserveVCR (finetune/vcr/qa_qar_joint_finetune.py:144-185): the pretraining tree without
+    audio_encoder / head / span_encoder (and contrastive_scales, which the finetuning graph never reads), plus
+    proj/kernel [H, 1] (Dense(1), no bias; viewed [1, H] = its memory layout as an [N, K] operand).
+    Order = the order backward finishes them."""
+    m = config['model']
+    H = m['hidden_size']
+    pp3 = m['vit_patch_size'] ** 2 * 3
+    specs = [('proj/kernel', (H, 1), (1, H), 'normal001', None)]
+    specs += _encoder_specs('joint_transformer', H, m['joint_num_layers'], False)
+    specs += [('token_encoder/Embed_0/embedding', (VOCAB, H), (VOCAB, H), 'embed', None)]
+    specs += [('vision_encoder/embedding/kernel', (pp3, H), (pp3, H), 'kernel', pp3),
+              ('vision_encoder/embedding/bias', (H,), (H,), 'zeros', None)]
+    specs += _encoder_specs('vision_encoder/transformer', H, m['vit_num_layers'], True)
+    specs += _attnpool_specs('vision_encoder/seq_attnpool', H)
+    return specs
+
+
+def decay_pretrain(flax_shape):
+    """pretrain/optimization.py:182-184"""
+    return len(flax_shape) > 1
+
+
+def decay_finetune(flax_shape):
+    """finetune/optimization.py:74-75"""
+    return len(flax_shape) > 1 and int(np.prod(flax_shape)) > 4096
+
+
 class ParamStore:
-    def __init__(self, config, device, seed=0, with_optimizer=True, init=True):
+    def __init__(self, config, device, seed=0, with_optimizer=True, init=True, specs=None, decay_rule=decay_pretrain,
+                 with_orig=False):
         self.config = config
         self.device = torch.device(device)
         self.H = config['model']['hidden_size']
-        self.specs = param_specs(config)
+        self.specs = param_specs(config) if specs is None else specs
         self.offsets = OrderedDict()
         off = 0
         flags = []
@@ -117,7 +148,7 @@ class ParamStore:
             n = int(np.prod(fshape))
             npad = (n + ALIGN - 1) // ALIGN * ALIGN
             self.offsets[name] = (off, n)
-            flags += [1 if len(fshape) > 1 else 0] * (npad // ALIGN)     # optimization.py:182-184: ndim > 1
+            flags += [1 if decay_rule(fshape) else 0] * (npad // ALIGN)     # the optax weight-decay mask, per leaf
             t = tower_of(name)
             lo, _ = self.tower_ranges.get(t, (off, off))
             self.tower_ranges[t] = (lo, off + npad)
@@ -129,6 +160,8 @@ class ParamStore:
         if with_optimizer:
             self.mu = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
             self.nu = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        # finetuning keeps a bf16 copy of the initial parameters (subtract_old_weights, finetune/optimization.py:20-34)
+        self.orig = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if with_orig else None
         self.decay_flags = torch.tensor(flags, dtype=torch.uint8, device=self.device)
         self.w, self.g, self.wm = {}, {}, {}       # bf16 working copy / bf16 grads / fp32 master, as 2-D kernel views
         for name, fshape, vshape, kind, fan in self.specs:
@@ -156,6 +189,8 @@ class ParamStore:
             assert tuple(leaf.shape) == tuple(fshape), f'{name}: {tuple(leaf.shape)} != {fshape}'
             host[o:o + n] = leaf.reshape(-1).to(torch.float32)
         self.master.copy_(host)
+        if self.orig is not None:
+            self.orig.copy_(host.to(torch.bfloat16))
         self.refresh_work()
 
     def refresh_work(self):

@@ -657,3 +657,55 @@ def embed_video(params, config, images, audio_clips, tokens, subseg_idxs):
     joint = transformer_encoder(params['joint_transformer'], mm['x'], cfg.joint_num_layers, rotary_coords=mm['rotary_coords'],
                                 attention_mask=mm['attention_mask'])['seq']
     return unit_normalize(dense(joint[0, :token_length], params['head']))
+
+
+# ----------------------------------------------------------------------------- VCR finetuning (BASELINE config 5)
+def vcr_forward(params, config, batch):
+    """MerlotReserveVCR.__call__, finetune/vcr/qa_qar_joint_finetune.py:150-170.
+    batch: 'image' [B, hw, 768] float, 'answers' [B, 2, A, T] int64 -> logits [B, 2, A]."""
+    cfg = Cfg(config)
+    H = cfg.hidden_size
+    batch_size, two_, num_ans_per, token_length = batch['answers'].shape
+    n = batch_size * 2 * num_ans_per
+    answers2d = batch['answers'].reshape(n, token_length)
+    imgs_enc = vision_transformer(params['vision_encoder'], batch['image'], cfg.vit_num_layers, cfg.grid_h, cfg.grid_w,
+                                  cfg.vit_pooling_ratio)['seq_attnpool'].repeat_interleave(2 * num_ans_per, dim=0)
+    mm = prepare_multimodal_inputs(params, cfg, tokens=answers2d, token_segment_idx=torch.zeros(n, token_length, dtype=torch.int64),
+                                   vision_input=imgs_enc)
+    joint = transformer_encoder(params['joint_transformer'], mm['x'], cfg.joint_num_layers, rotary_coords=mm['rotary_coords'],
+                                attention_mask=mm['attention_mask'])['seq'][:, :token_length]
+    pool_idx = torch.argmax((answers2d == MASK).to(torch.float32), 1)        # first MASK (0 when there is none)
+    pooled_h = joint[torch.arange(n), pool_idx]
+    return (pooled_h @ params['proj']['kernel']).reshape(batch_size, 2, num_ans_per)
+
+
+def vcr_train_loss(logits, labels):
+    """train_loss_fn, qa_qar_joint_finetune.py:188-195."""
+    log_p = torch.log_softmax(logits, dim=-1)
+    loss = -(torch.nn.functional.one_hot(labels, log_p.shape[-1]).to(log_p.dtype) * log_p).sum(-1).mean()
+    is_right = (torch.argmax(log_p, -1) == labels).to(torch.float32).mean()
+    return loss, {'is_right': is_right, 'loss': loss}
+
+
+def finetune_adam_apply(param, orig_bf16, grad, mu_bf16, nu_bf16, count, opt_config):
+    """finetune/optimization.py:56-105 (tx chain) + :151-185 for ONE leaf (replicated optimizer: the 8-way sharding of
+    :148-171 only re-lays the same arithmetic).  Bias correction ON, eps 1e-6 by default, decay mask ndim > 1 and
+    size > 4096, `- wd * bf16(initial param)` before `+ wd * param`, linear warmup / linear decay."""
+    f32 = np.float32
+    b1, b2 = opt_config.get('beta_1', 0.9), opt_config.get('beta_2', 0.98)
+    eps = opt_config.get('eps', 1e-6)
+    next_m = f32(1 - b1) * grad + f32(b1) * mu_bf16.to(torch.float32)
+    next_v = f32(1 - b2) * grad * grad + f32(b2) * unsigned_bf16_decode(nu_bf16)
+    new_mu, new_nu = next_m.to(torch.bfloat16), unsigned_bf16_encode(next_v)
+    m_hat, v_hat = next_m, next_v
+    if opt_config.get('do_bias_correction', True):
+        c = count + 1
+        m_hat, v_hat = next_m / f32(1 - b1 ** c), next_v / f32(1 - b2 ** c)
+    u = m_hat / (torch.sqrt(v_hat) + f32(eps))
+    if param.ndim > 1 and param.numel() > 4096:
+        wd = f32(opt_config['weight_decay_rate'])
+        u = u - wd * orig_bf16.to(torch.float32)
+        u = u + wd * param
+    u = u * lr_scale_linearwarmup_lineardecay(count, opt_config['num_warmup_steps'], opt_config['num_train_steps'])
+    u = u * f32(-opt_config['learning_rate'])
+    return param + u, new_mu, new_nu

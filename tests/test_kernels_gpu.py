@@ -258,6 +258,34 @@ def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
     assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
 
 
+@pytest.mark.parametrize('nseq,S,nh', [(2, 22, 2), (1, 130, 2)])
+def test_attention_bwd_through_pad_query_rows(dev, nseq, S, nh):
+    """A PAD query row has no allowed key: every score is exactly -1e10, the reference's softmax is uniform over all S
+    keys and autodiff sends its upstream gradient to q, k and v (the VCR head can pool at such a row when a sequence has
+    no MASK).  Its LSE (-1e10 + ln S) is not representable in fp32, so the backward must not recompute P from it."""
+    from merlot_reserve_amd import ops
+    H = nh * 64
+    qkv = rnd((nseq * S, 3 * H), dev, seed=4)
+    c = torch.zeros(nseq, S, dtype=torch.int32)
+    c[:, 3:9] = -1
+    c[0, :] = -1                                   # an entirely empty sequence
+    code = c.reshape(-1).to(dev)
+    out = torch.zeros(nseq * S, H, dtype=BF16, device=dev)
+    lse = torch.zeros(nseq, nh, S, device=dev)
+    ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref_o, _ = ref_attention(qr, code, nseq, S, nh)
+    assert_close(out, ref_o, 4e-3, 'attn out (pad rows included)')
+    dout = rnd((nseq * S, H), dev, seed=5)         # non-zero upstream gradient on the PAD rows too
+    ref_o.backward(dout.float())
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.zeros(nseq, nh, S, device=dev)
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
+        assert_close(dqkv[:, sl], qr.grad[:, sl], 1.5e-2, f'attn {name} with pad query rows')
+
+
 def test_poolattn(dev):
     from merlot_reserve_amd import ops
     nh, H, G, R, rows = 2, 128, 37, 5, 37 * 5 + 3

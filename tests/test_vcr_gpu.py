@@ -1,0 +1,132 @@
+"""VCR finetuning step (BASELINE config 5; finetune/vcr/qa_qar_joint_finetune.py + finetune/optimization.py) on the MI355X
+against the oracle: logits, loss / is_right, every parameter gradient (oracle autograd), the finetuning optimizer chain
+leaf by leaf, and a short training run.  Tolerances as for the pretraining step (bf16 compute vs fp32 oracle reading the
+same bf16-rounded weights and inputs): logits rel-L2 <= 2e-2, gradients |d| <= 8e-2 |g| + 1.5e-2 max|g| and cos >= 0.995."""
+import numpy as np
+import pytest
+import torch
+
+from merlot_reserve_amd.config import tiny_config
+from oracle import ref_torch as R
+from tests.util import relerr, tree_to
+
+pytestmark = pytest.mark.gpu
+
+
+def vcr_cfg(H=128):
+    cfg = tiny_config(hidden_size=H, grid=(4, 6))
+    cfg['data'].update(lang_seq_len=16, num_answers=4)
+    cfg['optimizer'] = {'beta_2': 0.98, 'eps': 1e-6, 'learning_rate': 1e-3, 'num_train_steps': 100, 'num_warmup_steps': 2,
+                        'use_bfloat16_adam': True, 'weight_decay_rate': 0.1, 'do_bias_correction': True}
+    return cfg
+
+
+def setup(dev, B=2, seed=0):
+    from merlot_reserve_amd import finetune as F
+    cfg = vcr_cfg()
+    model = F.MerlotReserveVCR.from_config(cfg, device=dev, seed=seed)
+    batch = F.make_vcr_batch(cfg, B, seed=seed, device=dev)
+    batch['answers'][0, 1, 2, :] = 0                       # an empty sequence: no MASK, pooled at a PAD position
+    batch['answers'][1, 0, 1, 5:] = 0
+    batch['answers'][1, 0, 1, 2] = 3
+    params = model.init_from_dummy_batch(batch)
+    g = torch.Generator().manual_seed(1)                   # non-trivial biases / LN parameters; a larger Dense(1)
+    def jit(t):
+        return {k: jit(v) for k, v in t.items()} if isinstance(t, dict) else (t + 0.05 * torch.randn(t.shape, generator=g) if t.dim() == 1 else t)
+    params = jit(params)
+    params['proj']['kernel'] = torch.randn(128, 1, generator=g) * 0.3
+    return F, cfg, model, batch, params
+
+
+def oracle_batch(batch):
+    return {'image': batch['image'].float().cpu(), 'answers': torch.from_numpy(batch['answers'].astype(np.int64)),
+            'labels': torch.from_numpy(batch['labels'].astype(np.int64))}
+
+
+def test_vcr_forward_loss_and_gradients(dev):
+    F, cfg, model, batch, params = setup(dev)
+    logits = model.apply({'params': params}, batch)
+    eng, store = model.engine, model.params_store
+    eng.loss_and_grad_logits()
+    torch.cuda.synchronize()
+    dl_loss = eng.dlogits[:, 0].float().cpu().view(2, 2, 4)
+    # backward from an INJECTED dL/dlogits: at initialisation softmax is uniform, dL/dlogits = (-3/16, 1/16, 1/16, 1/16)
+    # exactly, and every shared-parameter gradient is a sum of near-cancelling terms (ill-conditioned in bf16 for the
+    # reference as well) -- same treatment as the contrastive loss in tests/test_pretrain_gpu.py
+    g = torch.Generator().manual_seed(9)
+    inj = (torch.randn(16, generator=g) * 0.2).to(torch.bfloat16)
+    eng.dlogits[:, 0] = inj.to(dev)
+    eng.backward()
+    torch.cuda.synchronize()
+    ob = oracle_batch(batch)
+    wp = tree_to(store.work_tree(), torch.float32)
+    wp = R.tree_map(lambda t: t.clone().requires_grad_(True), wp)
+    ref = R.vcr_forward(wp, cfg, ob)
+    assert logits.shape == ref.shape == (2, 2, 4)
+    e = relerr(logits, ref)
+    print('logits rel err', e, logits.flatten()[:4].tolist(), ref.flatten()[:4].tolist())
+    assert e < 2e-2
+    loss, info = R.vcr_train_loss(ref, ob['labels'])
+    li = eng.loss_info()
+    assert abs(li['loss'] - float(loss)) < 2e-2 * abs(float(loss)), (li, float(loss))
+    assert abs(li['is_right'] - float(info['is_right'])) < 0.26          # argmax can flip on near-ties in bf16
+    p_ref = torch.softmax(ref.detach(), -1)
+    want_dl = (p_ref - torch.nn.functional.one_hot(ob['labels'], 4).float()) / 4.0
+    assert relerr(dl_loss, want_dl) < 1e-2                                # the loss gradient (bf16 storage)
+    (ref * inj.float().view(2, 2, 4)).sum().backward()
+    grads = R.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), wp)
+    gt = store.grad_tree()
+    gmax = max(float(g.norm()) for _, g in R.tree_leaves(grads))
+    bad = []
+    for name, g in R.tree_leaves(grads):
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn, err = float(g.norm()), float((mine.double() - g.double()).norm())
+        cos = float((mine.double().flatten() @ g.double().flatten()) / (mine.double().norm() * g.double().norm() + 1e-30))
+        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+            bad.append((name, err, gn, cos))
+    assert not bad, bad
+    # the parameters the finetuning graph does not reach get exactly zero gradient (cls_proj of the ViT)
+    assert float(gt['vision_encoder']['transformer']['cls_proj']['kernel'].abs().sum()) == 0.0
+
+
+def test_finetune_optimizer_matches_oracle(dev):
+    F, cfg, model, batch, params = setup(dev, seed=2)
+    state, tx = F.construct_finetuning_train_state(cfg['optimizer'], model, params)
+    store = model.params_store
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        store.grad.copy_((torch.randn(store.total, generator=g) * 0.01).to(torch.bfloat16))
+        before = {'p': store.master_tree(), 'mu': store._to_tree(store.mu), 'nu': store._to_tree(store.nu),
+                  'g': store.grad_tree(), 'orig': store._to_tree(store.orig)}
+        state.apply_gradients()
+        torch.cuda.synchronize()
+        after = {'p': store.master_tree(), 'mu': store._to_tree(store.mu), 'nu': store._to_tree(store.nu)}
+        for name, p0 in R.tree_leaves(before['p']):
+            get = lambda t: [t := t[k] for k in name.split('/')][-1]
+            np_, nm, nv = R.finetune_adam_apply(p0, get(before['orig']), get(before['g']).float(), get(before['mu']), get(before['nu']), step, cfg['optimizer'])
+            assert torch.allclose(get(after['p']), np_, rtol=2e-6, atol=1e-9), (name, step)
+            # bf16 momentum: at most one ulp apart (the kernel contracts c1*g + b1*m into an fma)
+            assert float((get(after['mu']).float() - nm.float()).abs().max()) <= 2 ** -7 * float(nm.float().abs().max()) + 1e-12, (name, step)
+            # the cube-root codec may differ by one bf16 ulp where cbrt rounds differently on the two sides
+            dv = (R.unsigned_bf16_decode(get(after['nu'])) - R.unsigned_bf16_decode(nv)).abs()
+            assert float((dv / (R.unsigned_bf16_decode(nv).abs() + 1e-30)).max()) < 6e-3, (name, step)
+    # decay mask: ndim > 1 and size > 4096 (FO:74-75): qkv bias [6, 64] and proj [128, 1] are NOT decayed, kernels are
+    flags = {n: int(store.decay_flags[store.offsets[n][0] // 2048]) for n, *_ in store.specs}
+    assert flags['joint_transformer/layer_00/attention_layer/qkv/bias'] == 0 and flags['proj/kernel'] == 0
+    assert flags['joint_transformer/layer_00/attention_layer/qkv/kernel'] == 1 and flags['token_encoder/Embed_0/embedding'] == 1
+
+
+def test_finetune_steps_reduce_loss(dev):
+    """finetune_train_step end to end on one repeated batch: the loss falls and is_right reaches 1."""
+    F, cfg, model, batch, params = setup(dev, seed=3)
+    state, tx = F.construct_finetuning_train_state(cfg['optimizer'], model, params)
+    hist = []
+    for _ in range(30):
+        state, info = F.finetune_train_step(state, batch, loss_fn=F.train_loss_fn, tx_fns=tx)
+        hist.append(info['loss'])
+    assert state.step == 30 and np.isfinite(hist).all()
+    assert hist[-1] < 0.5 * hist[0], hist
+    loss, info = F.train_loss_fn(state, None, batch)
+    assert info['is_right'] == 1.0
