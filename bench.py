@@ -39,9 +39,9 @@ def algorithmic_flops_per_record(config, train=True):
 
 def cpu_baseline(config, threads=None):
     """The oracle (torch CPU restatement of the reference's step, fp32) timed on a BOUNDED sample of the bench workload:
-    forward + backward of ONE record with every tower truncated to a quarter of its depth (3/3/3/1 of 12/12/12/4
-    layers at base), the same widths, sequence lengths and batch structure; the time is scaled to the full depth by
-    the ratio of algorithmic FLOPs and reported in the metric's unit."""
+    forward + backward of ONE record (2 video-segment groups) of the full-depth base model (or, for larger models,
+    every tower at 1/`depth_div` of its depth, scaled back by the ratio of algorithmic FLOPs), the same
+    widths, sequence lengths and batch structure; reported in the metric's unit."""
     import copy
     import torch
     from oracle import ref_torch as R
@@ -52,8 +52,9 @@ def cpu_baseline(config, threads=None):
     torch.set_num_threads(threads)
     small = copy.deepcopy(config)
     m = small['model']
+    depth_div = 1 if m['hidden_size'] <= 768 and m['output_grid'][0] * m['output_grid'][1] <= 240 else 4     # ~10-30 s of CPU work
     for k in ('vit_num_layers', 'audio_num_layers', 'joint_num_layers', 'span_num_layers'):
-        m[k] = max(1, m[k] // 4)
+        m[k] = max(1, m[k] // depth_div)
     scale = algorithmic_flops_per_record(config) / algorithmic_flops_per_record(small)
     store = ParamStore(small, 'cpu', seed=0, with_optimizer=False)
     params = store.master_tree()
@@ -65,8 +66,8 @@ def cpu_baseline(config, threads=None):
     R.loss_and_grads(params, small, ob, osp, oz)
     dt = time.time() - t0
     return {'value': 2.0 / (dt * scale), 'unit': 'video-segments/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle (fp32 torch-CPU port) forward+backward of 1 record (2 video-segment groups x 8 frames) with each '
-                      f'tower at 1/4 depth ({m["vit_num_layers"]}/{m["audio_num_layers"]}/{m["joint_num_layers"]}/{m["span_num_layers"]} '
+            'sample': f'oracle (fp32 torch-CPU port) forward+backward of 1 record (2 video-segment groups x 8 frames), towers '
+                      f'at 1/{depth_div} depth ({m["vit_num_layers"]}/{m["audio_num_layers"]}/{m["joint_num_layers"]}/{m["span_num_layers"]} '
                       f'layers): {dt:.1f} s measured, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
@@ -77,6 +78,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--model', default='base')
     ap.add_argument('--records-per-gpu', type=int, default=4)
+    ap.add_argument('--resadapt', action='store_true', help='resolution-adaptation grid 18x32 (BASELINE config 4; joint length 1312)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
@@ -102,7 +104,11 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
         comm = Comm()
 
-    config = load_config(args.model)
+    if args.resadapt:
+        from merlot_reserve_amd.config import resadapt_config
+        config = resadapt_config(args.model)
+    else:
+        config = load_config(args.model)
     B = args.records_per_gpu
     trainer = Trainer(config, B, dev, rank=rank, world=world, seed=0, comm=comm)
     batches = [make_batch(config, B, seed=1234 + rank + 1000 * i, device=dev) for i in range(2)]
@@ -149,15 +155,26 @@ def main():
         n = len(ops.GEMM_PROFILE)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
+        # the same launches with the side stream disabled: each GEMM then has the GPU to itself (in the step two towers
+        # run concurrently, so a launch's duration above includes the CUs it yields to the other stream)
+        os.environ['MR_NO_SIDE_STREAM'] = '1'
+        ops.GEMM_PROFILE = []
+        run(min(args.steps, 3), graph=False)
+        torch.cuda.synchronize()
+        ms_x = sum(r[0].elapsed_time(r[1]) for r in ops.GEMM_PROFILE)
+        fl_x = sum(r[2] for r in ops.GEMM_PROFILE)
+        ops.GEMM_PROFILE = None
+        del os.environ['MR_NO_SIDE_STREAM']
+        ach_x = fl_x / (ms_x * 1e-3) / 1e12
         traffic = None                # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
         pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')   # counters cannot be read from inside this process
         if os.path.exists(pmc):
             p = json.load(open(pmc))
-            if p['workload'] == {'model': args.model, 'records_per_gpu': B}:
+            if p['workload'] == {'model': args.model, 'records_per_gpu': B} and not args.resadapt:
                 g = [v for k, v in p['kernels'].items() if 'gemm' in k]
                 traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
         roof = {'bound': 'mfma', 'kernel': 'g256::gemm256_kernel<*> (+ gemm_bf16_kernel for small shapes)', 'achieved': ach, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per GEMM launch (PMC, profiles/r01_pmc_hbm_traffic.json)', 'launches': n,
+                'frac': ach / (MFMA_BF16_PEAK / 1e12), 'achieved_exclusive': ach_x, 'frac_exclusive': ach_x / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per GEMM launch (PMC, profiles/r01_pmc_hbm_traffic.json)', 'launches': n,
                 'avg_launch_us': ms * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
 
     if rank == 0:
