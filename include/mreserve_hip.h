@@ -40,7 +40,7 @@ extern "C" {
 int mr_version(void);
 const char* mr_last_error(void);
 /* Tuning / diagnostic knobs (process-wide, not thread-safe against concurrent launches).  Known names:
- *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 256 : forces the output-tile width of the 256-row GEMM
+ *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 192 | 256 : forces the output-tile width of the 256-row GEMM
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
  * Returns MR_EINVAL for an unknown name. */
 int mr_set_option(const char* name, int value);

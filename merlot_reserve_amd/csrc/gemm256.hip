@@ -52,11 +52,14 @@ constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
 // stages, 2-stage ring, one k-tile ahead).  The k-loop is bound by the LDS-DMA fill rate of a CU (~60-70 GB/s measured
 // with the MFMAs compiled out), so the 256 x 256 tile -- 2/3 of the bytes per FLOP -- is the fast one wherever the
 // problem has enough tiles for it.
+// BN = 192 uses the 256-wide geometry with the B columns beyond 192 left to the buffer descriptor's zero fill (no L2
+// traffic): 244 tiles instead of 183 for M = 15424, N = 768 -- one full round of the 256 CUs -- at 3/4 of the MFMAs
+// and 7/8 of the bytes of a 256-wide tile.
 template <int BN> struct Geo {
-    static constexpr int BW = (BN == 256) ? 256 : 128;
+    static constexpr int BW = (BN > 128) ? 256 : 128;
     static constexpr int STAGE_B = BW * BK * 2;
     static constexpr int STAGE = STAGE_A + STAGE_B;
-    static constexpr int NSTAGE = (BN == 256) ? 2 : 3;
+    static constexpr int NSTAGE = (BN > 128) ? 2 : 3;
     static constexpr int NBP = BW / 64;                    // 1-KiB B pieces per wave and k-tile
     static constexpr int NPIECE = 4 + NBP;
     static constexpr int WAITN = (NSTAGE - 2) * NPIECE;    // pieces that may stay in flight behind a k-tile's barrier
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     // Epilogue operands: fetched EARLY (top of the last k-tile, see PRE_LOAD_B64) by the 3-stage variants; the 256-wide
     // variant has no registers to park them in, and its 2-stage ring is drained (vmcnt(0)) behind every k-tile anyway, so
     // it loads them in the epilogue itself, row block by row block.
-    constexpr bool EARLY = BN != 256;
+    constexpr bool EARLY = BN <= 128;
     constexpr int NPRE = EARLY ? 4 * NJ : 1;
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
 
@@ -223,11 +226,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ii.m0, M_);                                                  \
         ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ii.m0, M_);                                                  \
         ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ii.m0, M_);                                                  \
-        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ii.n0, N_);                                                \
-        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ii.n0, N_);                                                \
+        const int64_t nb_ = (BN < BW && ii.n0 + BN < N_) ? ii.n0 + BN : N_;    /* columns the tile really covers */       \
+        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ii.n0, nb_);                                               \
+        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ii.n0, nb_);                                               \
         if (NBP == 4) {                                                                                                 \
-            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ii.n0, N_);                                            \
-            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ii.n0, N_);                                            \
+            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ii.n0, nb_);                                           \
+            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ii.n0, nb_);                                           \
         }                                                                                                               \
     } while (0)
     // The 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any), issued in two halves so that they can
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
         const bool do_act = (pc.act == MR_ACT_GELU1702);
         const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
-        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;
+        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && (BN == 128 || BN == 256);   // waves must own whole heads
         const void* const dummy = pc.A;
         auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
@@ -661,11 +665,12 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     const int64_t tm = (a->M + g256::BM - 1) / g256::BM;
     // tile width: the one that wastes the fewest CU-rounds (256 workgroups per round, one per CU)
     int bn = 128;
-    static int force_bn = -1, grid_mode = -1, c256_cost = -1;
+    static int force_bn = -1, grid_mode = -1, c256_cost = -1, c192_cost = -1;
     if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
     if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
     if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 180; }
-    const bool can256 = a->N >= 256;
+    if (c192_cost < 0) { const char* e = getenv("MR_G256_C192"); c192_cost = e ? atoi(e) : 150; }
+    const bool can256 = a->N >= 256, can192 = a->N >= 192 && !a->rot_tab;
     {
         const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96), t256 = tm * ((a->N + 255) / 256);
         // measured: a 96-wide tile costs ~0.91 of a 128-wide one (the A side and the LDS-DMA issue do not shrink); a
@@ -674,8 +679,10 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
         int64_t best = c128;
         if (c96 < best && !a->rot_tab) { bn = 96; best = c96; }       // the prefetched "rotary" scales assume whole heads per wave
         if (can256 && c256 < best) { bn = 256; best = c256; }
+        const int64_t t192 = tm * ((a->N + 191) / 192), c192 = ((t192 + 255) / 256) * c192_cost;
+        if (can192 && c192 < best) { bn = 192; best = c192; }
     }
-    { const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn; if (f == 96 || f == 128 || (f == 256 && can256)) bn = f; }
+    { const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn; if (f == 96 || f == 128 || (f == 256 && can256) || (f == 192 && can192)) bn = f; }
     if (a->rot_tab && bn == 96) bn = 128;
     const int64_t tn = (a->N + bn - 1) / bn;
     const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
@@ -729,6 +736,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
     ga.p[0] = *a;
     if (bn == 256) g256::launch<256>(ga, grid, s);
+    else if (bn == 192) g256::launch<192>(ga, grid, s);
     else if (bn == 128) g256::launch<128>(ga, grid, s);
     else g256::launch<96>(ga, grid, s);
     if (splits > 1) reduce(a, splits, s);
