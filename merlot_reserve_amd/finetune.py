@@ -309,6 +309,35 @@ def finetune_train_step(state, batch, loss_fn=None, tx_fns=None, scan_minibatch=
     return state, info
 
 
+class VCRGraphStep:
+    """hipGraph replay of finetune_train_step (single rank): the step is a fixed launch sequence over fixed buffers, so
+    forward + loss + backward are captured once and replayed; per batch only the image, the labels and the plan's index
+    lists are copied into their persistent buffers.  Same results as finetune_train_step (tests/test_vcr_gpu.py)."""
+
+    def __init__(self, state, batch):
+        self.state, self.model = state, state._model
+        eng = self.eng = self.model._ensure(batch)
+        assert self.model.comm is None, 'graph replay is the single-rank fast path'
+        finetune_train_step(state, batch)                  # eager step: every buffer and plan capacity exists afterwards
+        self.image_in = torch.zeros_like(batch['image'])
+        eng.plan_frozen = True
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            eng.forward_device(self.image_in)
+            eng.loss_and_grad_logits()
+            eng.backward()
+
+    def __call__(self, batch, plan=None):
+        eng = self.eng
+        self.image_in.copy_(batch['image'], non_blocking=True)
+        eng.set_plan(plan if plan is not None else build_vcr_plan(batch['answers'], eng.d))
+        eng.labels_dev.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(batch['labels']).astype(np.int32).reshape(-1))), non_blocking=True)
+        self.graph.replay()
+        self.state.apply_gradients()
+        return self.state
+
+
 def make_vcr_batch(config, B, seed=0, device='cpu'):
     """Synthetic VCR batch with the structure of finetune/data: answers = [question tokens, MASK, answer tokens, PAD...]."""
     d = VCRDims(config, B)

@@ -20,16 +20,24 @@ model = F.MerlotReserveVCR.from_config(cfg, device=dev)
 batches = [F.make_vcr_batch(cfg, B, seed=i, device=dev) for i in range(2)]
 model.init_from_dummy_batch(batches[0])
 state, tx = F.construct_finetuning_train_state(cfg['optimizer'], model)
+graph = '--eager' not in sys.argv
+if graph:
+    step = F.VCRGraphStep(state, batches[0])
+    plans = [F.build_vcr_plan(b['answers'], model.engine.d) for b in batches]
+    run = lambda i: step(batches[i % 2], plans[i % 2])
+else:
+    run = lambda i: F.finetune_train_step(state, batches[i % 2])
 for i in range(3):
-    state, info = F.finetune_train_step(state, batches[i % 2])
+    run(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
-    state, info = F.finetune_train_step(state, batches[i % 2])
+    run(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+info = model.engine.loss_info()
 H, Lv, Lj = cfg['model']['hidden_size'], cfg['model']['vit_num_layers'], cfg['model']['joint_num_layers']
 enc = lambda n, S, L: n * S * L * (24 * H * H + 4 * S * H)
 fwd = enc(1, 577, Lv) + enc(8, 288, Lj) + 576 * 2 * 768 * H + 144 * 20 * H * H
-print(f'VCR {name} B={B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} examples/s, loss {info["loss"]:.4f}, '
+print(f'VCR {name} B={B} ({"hipGraph" if graph else "eager"}): {dt * 1e3:.2f} ms/step, {B / dt:.1f} examples/s, loss {info["loss"]:.4f}, '
       f'{3 * fwd * B / dt / 1e12:.1f} TFLOP/s algorithmic ({3 * fwd * B / dt / 2.5e15 * 100:.1f} % of bf16 MFMA peak)')

@@ -130,3 +130,22 @@ def test_finetune_steps_reduce_loss(dev):
     assert hist[-1] < 0.5 * hist[0], hist
     loss, info = F.train_loss_fn(state, None, batch)
     assert info['is_right'] == 1.0
+
+
+def test_graph_replay_matches_eager(dev):
+    """VCRGraphStep (hipGraph replay) and finetune_train_step give the same parameters after the same batches."""
+    F, cfg, model_a, batch, params = setup(dev, seed=4)
+    _F, _c, model_b, _b, _p = setup(dev, seed=4)
+    b2 = F.make_vcr_batch(cfg, 2, seed=11, device=dev)
+    sa, _ = F.construct_finetuning_train_state(cfg['optimizer'], model_a, params)
+    sb, _ = F.construct_finetuning_train_state(cfg['optimizer'], model_b, params)
+    F.finetune_train_step(sa, batch)
+    step = F.VCRGraphStep(sb, batch)                      # runs the first step eagerly, then captures
+    for b in (b2, batch, b2):
+        F.finetune_train_step(sa, b)
+        step(b)
+    torch.cuda.synchronize()
+    assert sa.step == sb.step == 4
+    pa, pb = model_a.params_store, model_b.params_store
+    assert torch.equal(pa.master, pb.master) and torch.equal(pa.nu, pb.nu)
+    assert model_a.engine.loss_info() == model_b.engine.loss_info()
