@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
         const bool do_act = (pc.act == MR_ACT_GELU1702);
         const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
-        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && (BN == 128 || BN == 256);   // waves must own whole heads
+        const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;   // BN = 96 never gets a rot_tab (host)
         const void* const dummy = pc.A;
         auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
@@ -517,10 +517,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
                         }
-                        if (f_rot && (j & 3) < 2 && wcol0 + (j >> 2) * 64 < e_rot_cols) {
+                        // "rotary" scale for ANY tile width (a 192-wide tile gives a wave 1.5 heads): the lane's 4 columns start
+                        // at a multiple of 4, so they lie inside one head's first or second 32 dims
+                        const int gn0 = wcol0 + j * 16 + g * 4;
+                        if (f_rot && (gn0 & 63) < 32 && gn0 < e_rot_cols) {
                             const int gm = wrow0 + i * 16 + li;
                             const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
-                            v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (j & 1) * 16 + g * 4);
+                            v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (gn0 & 63));
                         }
                         return v;
                     }
@@ -670,7 +673,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
     if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 180; }
     if (c192_cost < 0) { const char* e = getenv("MR_G256_C192"); c192_cost = e ? atoi(e) : 150; }
-    const bool can256 = a->N >= 256, can192 = a->N >= 192 && !a->rot_tab;
+    const bool can256 = a->N >= 256, can192 = a->N >= 192;
     {
         const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96), t256 = tm * ((a->N + 255) / 256);
         // measured: a 96-wide tile costs ~0.91 of a 128-wide one (the A side and the LDS-DMA issue do not shrink); a
