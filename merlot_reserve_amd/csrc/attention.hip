@@ -82,6 +82,23 @@ __device__ __forceinline__ float biased2(float raw, int cq, int ck) {
     return (ck == CODE_NONE) ? -INFINITY : s;
 }
 
+// XCD-aware block order.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, so with the plain
+// (block, head, sequence) grid the query blocks of ONE (sequence, head) -- which all stream the same K / V rows -- landed
+// on different XCDs and every XCD's L2 fetched those rows for itself (rocprofv3 FETCH_SIZE: 3.7x the algorithmic bytes
+// on the joint tower).  With this bijective remap the ids an XCD receives are consecutive, block index fastest.
+struct AttnBlock { int64_t seq, h, blk; };
+__device__ __forceinline__ AttnBlock attn_block(int nblk, int nh) {
+    const unsigned n = gridDim.x, b = blockIdx.x;
+    const unsigned xcd = b & 7, qd = n >> 3, rm = n & 7;
+    const unsigned id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
+    AttnBlock a;
+    a.blk = id % nblk;
+    const unsigned t = id / nblk;
+    a.h = t % nh;
+    a.seq = t / nh;
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int QB, bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
@@ -91,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restri
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDV];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * (64 * QB);
+    const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
+    const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
 
@@ -254,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDR];   // row reads (dP^T)
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * (64 * QB);
+    const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
+    const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
     const float inv_S = 1.0f / (float)S;
@@ -383,7 +402,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int64_t seq = blockIdx.z, h = blockIdx.y, kbase = (int64_t)blockIdx.x * (64 * KB);
+    const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
+    const int64_t seq = ab_.seq, h = ab_.h, kbase = ab_.blk * (64 * KB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
     const float inv_S = 1.0f / (float)S;
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
 
 template <int QB>
 static dim3 attn_grid(int64_t S, int64_t nh, int64_t nseq) {
-    return dim3((unsigned)((S + 64 * QB - 1) / (64 * QB)), (unsigned)nh, (unsigned)nseq);
+    return dim3((unsigned)(((S + 64 * QB - 1) / (64 * QB)) * nh * nseq));      // 1-D: see attn_block()
 }
 
 }  // namespace
