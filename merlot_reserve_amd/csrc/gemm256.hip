@@ -58,12 +58,23 @@ constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
 template <int BN> struct Geo {
     static constexpr int BW = (BN > 128) ? 256 : 128;
     static constexpr int STAGE_B = BW * BK * 2;
-    static constexpr int STAGE = STAGE_A + STAGE_B;
-    static constexpr int NSTAGE = (BN > 128) ? 2 : 3;
+    // Two rings.  A (32 KiB per k-tile) always runs TWO k-tiles ahead of the MFMAs in 3 stages.  B runs two ahead in 3
+    // stages when it is 128 wide (144 KiB in all) and ONE ahead in 2 stages when it is 256 wide (96 + 64 = 160 KiB, all of
+    // the LDS): the B pieces of k-tile t+1 are issued first in step t and must have landed by its end, the A pieces of
+    // k-tile t+2 are issued behind them and may stay in flight across the barrier.  (With both operands one k-tile ahead
+    // in 2 stages the whole 64-KiB fill sat between the issue and the end of the same k-tile: 3600 cycles per k-tile
+    // against 2060 of MFMA.)
+    static constexpr int NSTAGE_A = 3;
+    static constexpr int B_AHEAD = (BN > 128) ? 1 : 2;
+    static constexpr int NSTAGE_B = B_AHEAD + 1;
+    static constexpr int OFF_B = NSTAGE_A * STAGE_A;
+    static constexpr int LDS_BYTES = OFF_B + NSTAGE_B * STAGE_B;
     static constexpr int NBP = BW / 64;                    // 1-KiB B pieces per wave and k-tile
-    static constexpr int NPIECE = 4 + NBP;
-    static constexpr int WAITN = (NSTAGE - 2) * NPIECE;    // pieces that may stay in flight behind a k-tile's barrier
+    // pieces of one step that may still be in flight behind its barrier: the step's A pieces, plus its B pieces when B
+    // also runs two ahead
+    static constexpr int WAITN = 4 + (B_AHEAD == 2 ? NBP : 0);
 };
+static_assert(Geo<256>::LDS_BYTES == 160 * 1024 && Geo<128>::LDS_BYTES == 144 * 1024, "LDS budget");
 constexpr unsigned OOB = 0x80000000u;      // >= any operand extent (< 2^31 B, checked on the host); + soffset cannot wrap
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -186,14 +197,14 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
 template <int BN, bool TA, bool TB>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     constexpr int NJ = BN / 32;                  // 16-col MFMA tiles per wave (wave tile = 64 x BN/2)
-    constexpr int BW = Geo<BN>::BW, STAGE = Geo<BN>::STAGE, NSTAGE = Geo<BN>::NSTAGE, NBP = Geo<BN>::NBP;
+    constexpr int BW = Geo<BN>::BW, NBP = Geo<BN>::NBP, STAGE_B = Geo<BN>::STAGE_B, OFF_B = Geo<BN>::OFF_B;
+    constexpr int NSTAGE_A = Geo<BN>::NSTAGE_A, NSTAGE_B = Geo<BN>::NSTAGE_B, B_AHEAD = Geo<BN>::B_AHEAD;
     constexpr int WAITN = Geo<BN>::WAITN;
-    // Epilogue operands: fetched EARLY (top of the last k-tile, see PRE_LOAD_B64) by the 3-stage variants; the 256-wide
-    // variant has no registers to park them in, and its 2-stage ring is drained (vmcnt(0)) behind every k-tile anyway, so
-    // it loads them in the epilogue itself, row block by row block.
+    // Epilogue operands: fetched EARLY (top of the last k-tile, see PRE_LOAD_B64) by the 128 / 96-wide variants; the 256 /
+    // 192-wide ones have no registers to park them in and load them in the epilogue itself, row block by row block.
     constexpr bool EARLY = BN <= 128;
     constexpr int NPRE = EARLY ? 4 * NJ : 1;
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[Geo<BN>::LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: LDS-DMA bases stay scalar
@@ -208,73 +219,88 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     const int splits = ga.splits;
 #define GET_ITEM(w) make_item(ga, (w), BN)
 
-    // ---- issue cursor: runs two k-tiles ahead of the compute cursor, across item boundaries ----
-    int iw = bperm, ik = 0, istage = 0;
-    Item ii = GET_ITEM(iw);
+    // ---- issue cursors (one per operand): run ahead of the compute cursor, across item boundaries ----
+    int iwa = bperm, ika = 0, ista = 0, iwb = bperm, ikb = 0, istb = 0;
+    Item ia = GET_ITEM(iwa), ib = ia;
     unsigned ao0, ao1, ao2, ao3, bo0, bo1, bo2 = 0, bo3 = 0, a_step = 0, b_step = 0;
-    __amdgpu_buffer_rsrc_t ra, rb;      // wave-uniform descriptors of the issue cursor's problem (zero-fill beyond the extent)
-#define SET_OFFSETS()                                                                                                   \
+    __amdgpu_buffer_rsrc_t ra, rb;      // wave-uniform descriptors of each cursor's problem (zero-fill beyond the extent)
+#define SET_OFFSETS_A()                                                                                                 \
     do {                                                                                                                \
-        const mr_gemm_args& q_ = ga.p[ii.pi];                                                                           \
-        const int64_t lda_ = q_.lda, ldb_ = q_.ldb, M_ = q_.M, N_ = q_.N, K_ = q_.K;                                    \
-        const int64_t a_rows = TA ? K_ : M_, a_cols = TA ? M_ : K_, b_rows = TB ? N_ : K_, b_cols = TB ? K_ : N_;      \
+        const mr_gemm_args& q_ = ga.p[ia.pi];                                                                           \
+        const int64_t lda_ = q_.lda, M_ = q_.M, K_ = q_.K;                                                              \
+        const int64_t a_rows = TA ? K_ : M_, a_cols = TA ? M_ : K_;                                                     \
         ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.A), 0, (int)(((a_rows - 1) * lda_ + a_cols) * 2), 0x00020000); \
-        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.B), 0, (int)(((b_rows - 1) * ldb_ + b_cols) * 2), 0x00020000); \
         a_step = TA ? (unsigned)(BK * lda_ * 2) : (unsigned)(BK * 2);                                                   \
+        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, lda_, ia.m0, M_);                                                  \
+        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ia.m0, M_);                                                  \
+        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ia.m0, M_);                                                  \
+        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ia.m0, M_);                                                  \
+    } while (0)
+#define SET_OFFSETS_B()                                                                                                 \
+    do {                                                                                                                \
+        const mr_gemm_args& q_ = ga.p[ib.pi];                                                                           \
+        const int64_t ldb_ = q_.ldb, N_ = q_.N, K_ = q_.K;                                                              \
+        const int64_t b_rows = TB ? N_ : K_, b_cols = TB ? K_ : N_;                                                     \
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.B), 0, (int)(((b_rows - 1) * ldb_ + b_cols) * 2), 0x00020000); \
         b_step = TB ? (unsigned)(BK * 2) : (unsigned)(BK * ldb_ * 2);                                                   \
-        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, lda_, ii.m0, M_);                                                  \
-        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ii.m0, M_);                                                  \
-        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ii.m0, M_);                                                  \
-        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ii.m0, M_);                                                  \
-        const int64_t nb_ = (BN < BW && ii.n0 + BN < N_) ? ii.n0 + BN : N_;    /* columns the tile really covers */       \
-        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ii.n0, nb_);                                               \
-        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ii.n0, nb_);                                               \
+        const int64_t nb_ = (BN < BW && ib.n0 + BN < N_) ? ib.n0 + BN : N_;    /* columns the tile really covers */       \
+        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ib.n0, nb_);                                               \
+        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ib.n0, nb_);                                               \
         if (NBP == 4) {                                                                                                 \
-            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ii.n0, nb_);                                           \
-            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ii.n0, nb_);                                           \
+            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ib.n0, nb_);                                           \
+            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ib.n0, nb_);                                           \
         }                                                                                                               \
     } while (0)
-    // The 6 LDS-DMA pieces of this wave for the next k-tile in sequence (if any), issued in two halves so that they can
-    // sit between the two MFMA batches of a k-tile instead of stalling the wave right after the barrier.
+    // The wave's 4 A pieces / NBP B pieces of the next k-tile of each cursor's sequence (if any).  They are issued between
+    // the MFMA batches of a k-tile instead of stalling the wave right after the barrier.
 #define ISSUE_A(issued)                                                                                                 \
     do {                                                                                                                \
-        (issued) = ii.valid;                                                                                            \
-        if (ii.valid) {                                                                                                 \
-            char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
-            const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step;                                                        \
-            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                     \
-            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);              \
-            MR_DMA(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);              \
-            if (NBP == 4) MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);                                  \
+        (issued) = ia.valid;                                                                                            \
+        if (ia.valid) {                                                                                                 \
+            char* st_ = smem + ista * STAGE_A + wave * 4096;                                                            \
+            const unsigned sa = MR_DIAG_K(ia.kt0 + ika) * a_step;                                                       \
+            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, ao0, sa, 0, 0);                                                       \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao1, sa, 0, 0);                                                \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao2, sa, 0, 0);                                                \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);                                                \
+            ista = (ista == NSTAGE_A - 1) ? 0 : ista + 1;                                                               \
+            if (++ika == ia.nkt) {                                                                                      \
+                iwa += G;                                                                                               \
+                ika = 0;                                                                                                \
+                ia = GET_ITEM(iwa);                                                                                     \
+                if (ia.valid) SET_OFFSETS_A();                                                                          \
+            }                                                                                                           \
         }                                                                                                               \
     } while (0)
 #define ISSUE_B()                                                                                                       \
     do {                                                                                                                \
-        if (ii.valid) {                                                                                                 \
-            char* st_ = smem + istage * STAGE + wave * 4096;                                                            \
-            char* sb_ = smem + istage * STAGE + STAGE_A + wave * (NBP * 1024);                                          \
-            const unsigned sa = MR_DIAG_K(ii.kt0 + ik) * a_step, sb = MR_DIAG_K(ii.kt0 + ik) * b_step;                  \
-            if (NBP != 4) MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao3, sa, 0, 0);                                  \
+        if (ib.valid) {                                                                                                 \
+            char* sb_ = smem + OFF_B + istb * STAGE_B + wave * (NBP * 1024);                                            \
+            const unsigned sb = MR_DIAG_K(ib.kt0 + ikb) * b_step;                                                       \
             MR_DMA(rb, MR_LDS_PTR(void, sb_), 16, bo0, sb, 0, 0);                                                       \
             MR_DMA(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo1, sb, 0, 0);                                                \
             if (NBP == 4) {                                                                                             \
                 MR_DMA(rb, MR_LDS_PTR(void, sb_ + 2048), 16, bo2, sb, 0, 0);                                            \
                 MR_DMA(rb, MR_LDS_PTR(void, sb_ + 3072), 16, bo3, sb, 0, 0);                                            \
             }                                                                                                           \
-            istage = (istage == NSTAGE - 1) ? 0 : istage + 1;                                                           \
-            if (++ik == ii.nkt) {                                                                                       \
-                iw += G;                                                                                                \
-                ik = 0;                                                                                                 \
-                ii = GET_ITEM(iw);                                                                                      \
-                if (ii.valid) SET_OFFSETS();                                                                            \
+            istb = (istb == NSTAGE_B - 1) ? 0 : istb + 1;                                                               \
+            if (++ikb == ib.nkt) {                                                                                      \
+                iwb += G;                                                                                               \
+                ikb = 0;                                                                                                \
+                ib = GET_ITEM(iwb);                                                                                     \
+                if (ib.valid) SET_OFFSETS_B();                                                                          \
             }                                                                                                           \
         }                                                                                                               \
     } while (0)
-#define ISSUE_NEXT(issued) do { ISSUE_A(issued); ISSUE_B(); } while (0)
+    // B before A: when B runs only one k-tile ahead its pieces are the ones the next step needs, and the A pieces behind
+    // them are the ones allowed to stay in flight
+#define ISSUE_NEXT(issued) do { ISSUE_B(); ISSUE_A(issued); } while (0)
 
 
-    if (ii.valid) SET_OFFSETS();
-    int cw = bperm, cstage = 0;
+
+
+    if (ia.valid) { SET_OFFSETS_A(); SET_OFFSETS_B(); }
+    int cw = bperm, csa = 0, csb = 0;
 #ifdef MR_DIAG_STAMPS
     unsigned long long* stamps = static_cast<unsigned long long*>(ga.p[0].workspace);
     int nstamp = 0;
@@ -282,15 +308,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     Item ci = GET_ITEM(cw);
     if (!ci.valid) return;
     bool issued;
-    // all but the youngest WAITN pieces have landed (everything when nothing was issued this step: the stream is ending)
+    // all but the youngest WAITN pieces have landed (everything when no A piece was issued this step: the stream is ending)
 #define RING_WAIT(issued)                                                                                               \
     do {                                                                                                                \
-        if (WAITN == 6 && (issued)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                    \
+        if (issued) wait_vmcnt<WAITN>();                                                                                \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
     } while (0)
-    static_assert(WAITN == 6 || WAITN == 0, "RING_WAIT spells the counts out");
+    // prologue: k-tile 0 of both operands, then the steady state's lead (A: k-tile 1; B: k-tile 1 when it runs two ahead)
     ISSUE_NEXT(issued);
-    if (NSTAGE == 3) ISSUE_NEXT(issued);
+    if (B_AHEAD == 2) ISSUE_NEXT(issued); else ISSUE_A(issued);
     RING_WAIT(issued);
     __builtin_amdgcn_s_barrier();
 
@@ -358,8 +384,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         auto kstep = [&](auto pre_row_c) {
             constexpr int PRE_ROW = decltype(pre_row_c)::value;      // 16-row block of the residual / aux tile to request, or -1
             // the stage being refilled was last read one step ago, behind that step's barrier
-            const char* As = smem + cstage * STAGE;
-            const char* Bs = As + STAGE_A;
+            const char* As = smem + csa * STAGE_A;
+            const char* Bs = smem + OFF_B + csb * STAGE_B;
             // Units of 16 MFMAs: (kk, half) with the wave's B columns taken JH 16-column blocks at a time (all of them when
             // NJ <= 4), so the fragments in flight stay at A(kk) + 2 B halves even for the 128-column waves of BN = 256.
             constexpr int NH = (NJ > 4) ? 2 : 1, JH = NJ / NH;
@@ -375,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
 #pragma unroll
                 for (int j = 0; j < JH; ++j) bfr[j] = MR_DIAG_FRAG((frag<!TB, BW>(Bs, wn * (BN / 2) + (h * JH + j) * 16, kk, lane)));
                 // the DMA issue rides in the shadow of the fragment reads' latency / the previous unit's MFMAs
-                if (u == 0) ISSUE_A(issued);
-                if (u == NH) ISSUE_B();
+                if (u == 0) ISSUE_B();
+                if (u == NH) ISSUE_A(issued);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -396,13 +422,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             // k-tile cseq+1 must have landed before anyone reads it: everything but this step's 6 pieces (this also
             // retires the previous item's epilogue stores, which were issued before them) and the residual / aux loads
             // requested behind this k-tile's and the previous k-tile's pieces
-            if (EARLY && issued && pre_now + pre_prev == 2) wait_vmcnt<6 + 2 * NJ>();
-            else if (EARLY && issued && pre_now + pre_prev == 1) wait_vmcnt<6 + NJ>();
+            if (EARLY && issued && pre_now + pre_prev == 2) wait_vmcnt<WAITN + 2 * NJ>();
+            else if (EARLY && issued && pre_now + pre_prev == 1) wait_vmcnt<WAITN + NJ>();
             else RING_WAIT(issued);
             pre_prev = pre_now;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            cstage = (cstage == NSTAGE - 1) ? 0 : cstage + 1;
+            csa = (csa == NSTAGE_A - 1) ? 0 : csa + 1;
+            csb = (csb == NSTAGE_B - 1) ? 0 : csb + 1;
         };
         MR_STAMP(0);
         {   // the first four k-tiles request the residual / aux row blocks (static register indices: peeled, not switched)
