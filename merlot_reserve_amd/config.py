@@ -30,13 +30,30 @@ def tiny_config(hidden_size=128, grid=(4, 6), num_segments=4, seq_len=48, lang_s
     return cfg
 
 
-def resadapt_config(name, grid=(18, 32)):
-    """pretrain/train_fixres.py:78-90: higher-resolution grid, joint seq_len re-derived."""
+RESADAPT_GRIDS = [[18, 32], [24, 24]]        # pretrain/train_fixres.py:78: alternated over processes
+
+
+def resadapt_config(name, grid=None, rank=0):
+    """pretrain/train_fixres.py:78-90, 141-144: the resolution-adaptation stage.  Grid = `grid`, or the reference's
+    per-process choice possible_res[rank % 2]; joint seq_len re-derived (lang + 8 * h * w / 4); data-augmentation keys and
+    the short schedule (75k steps, 15k warm-up, final_lr_scale 0, learning rate x 0.02) as the reference sets them.
+    Every rank keeps the same parameter shapes, so ranks on different grids still all-reduce gradients together."""
     cfg = load_config(name)
-    cfg['model']['output_grid'] = list(grid)
+    grid = list(grid) if grid is not None else list(RESADAPT_GRIDS[rank % len(RESADAPT_GRIDS)])
+    cfg['model']['output_grid'] = grid
     d = cfg['data']
+    d['random_scale_max'] = max(min(grid) / max(grid) * 16 / 9, 1.0) + 0.1
+    d['shrink_both_sides'] = False
+    d['random_scale_min'] = 1.0
+    d['max_text_seq_len'] = 1024
+    d['do_flip_if_vertical'] = False
     per_group = d['num_segments'] // d['num_segment_groups']
     d['seq_len'] = d['lang_seq_len'] + per_group * (grid[0] * grid[1]) // (cfg['model']['vit_pooling_ratio'] ** 2)
+    o = cfg['optimizer']
+    o['num_train_steps'] = 75000
+    o['final_lr_scale'] = 0.0
+    o['num_warmup_steps'] = 15000
+    o['learning_rate'] = 0.02 * o['learning_rate']
     return cfg
 
 

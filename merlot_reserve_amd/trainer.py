@@ -61,7 +61,9 @@ class TrainState:
                 'opt_state': {'0': {'count': torch.tensor(self.step, dtype=torch.int32), 'mu': p._to_tree(p.mu), 'nu': p._to_tree(p.nu)},
                               '1': {}, '2': {'count': torch.tensor(self.step, dtype=torch.int32)}, '3': {}}}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, reset_schedule=False):
+        """reset_schedule = True is the resolution-adaptation restart (pretrain/train_fixres.py:94-113): parameters and the
+        Adam moments are kept, the step and the schedule's count start again from 0."""
         p = self.params
         p.load_tree(sd['params'])
         self.step = int(sd.get('step', 0))
@@ -78,6 +80,8 @@ class TrainState:
                     host[o:o + n] = leaf.reshape(-1).to(torch.bfloat16)
                 flat.copy_(host)
             self.step = int(adam.get('count', self.step))
+        if reset_schedule:
+            self.step = 0
 
 
 def construct_train_state(opt_config, params):

@@ -79,3 +79,27 @@ def test_train_state_layout_roundtrip(tmp_path):
         o, n = ps.offsets[name]
         assert torch.equal(ps2.mu[o:o + n], ps.mu[o:o + n]) and torch.equal(ps2.nu[o:o + n], ps.nu[o:o + n]), name
         assert torch.equal(ps2.master[o:o + n], ps.master[o:o + n].to(torch.float16).float()), name   # fp16 on disk
+
+
+def test_resadapt_restart(tmp_path):
+    """train_fixres.py:78-113: per-process grid, re-derived joint length, short schedule, Adam moments kept, counts reset."""
+    from merlot_reserve_amd.config import resadapt_config, tiny_config
+    from merlot_reserve_amd.params import ParamStore
+    from merlot_reserve_amd.trainer import construct_train_state
+    c0, c1 = resadapt_config('base', rank=0), resadapt_config('base', rank=1)
+    assert c0['model']['output_grid'] == [18, 32] and c1['model']['output_grid'] == [24, 24]
+    assert c0['data']['seq_len'] == c1['data']['seq_len'] == 160 + 8 * 576 // 4 == 1312
+    assert abs(c0['data']['random_scale_max'] - 1.1) < 1e-12 and abs(c1['data']['random_scale_max'] - (16 / 9 + 0.1)) < 1e-12
+    o = c0['optimizer']
+    assert (o['num_train_steps'], o['num_warmup_steps'], o['final_lr_scale']) == (75000, 15000, 0.0) and abs(o['learning_rate'] - 8e-6) < 1e-12
+    cfg = tiny_config(hidden_size=64)
+    ps = ParamStore(cfg, 'cpu', seed=1)
+    st = construct_train_state(cfg['optimizer'], ps)
+    st.step = 750
+    ps.mu.copy_(torch.randn(ps.total).to(torch.bfloat16))
+    C.save_checkpoint(st, str(tmp_path))
+    ps2 = ParamStore(cfg, 'cpu', seed=2)
+    st2 = construct_train_state(cfg['optimizer'], ps2)
+    st2.load_state_dict(C.load_checkpoint(str(tmp_path)), reset_schedule=True)
+    o, n = ps.offsets['head/kernel']
+    assert st2.step == 0 and torch.equal(ps2.mu[o:o + n], ps.mu[o:o + n])
