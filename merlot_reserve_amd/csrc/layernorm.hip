@@ -70,8 +70,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
         for (int e = 0; e < 8; ++e) { pg[k][e] = 0.f; pb[k][e] = 0.f; gm[k][e] = 0.f; }
         if (c < nch) unpack8(*reinterpret_cast<const u32x4*>(gamma + 8 * c), gm[k]);
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+    // Rows are software-pipelined: the next row's x / dy / dx_add chunks are requested before the current row's two
+    // dependent phases (row reductions, then the dx formula) run, so a wave keeps two rows of loads in flight instead of
+    // one (the kernel is HBM-latency-bound at 16 waves per CU: 3.8 TB/s before).
+    const int64_t rstride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    u32x4 rx[MC], rd[MC], ra[MC];
+    float mu = 0.f, rs = 0.f;
+    auto fetch = [&](int64_t r, u32x4 (&X)[MC], u32x4 (&D)[MC], u32x4 (&A)[MC], float& m_, float& r_) {
+        m_ = mean[r];
+        r_ = rstd[r];
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            X[k] = u32x4{0u, 0u, 0u, 0u}; D[k] = X[k]; A[k] = X[k];
+            if (c < nch) {
+                X[k] = *reinterpret_cast<const u32x4*>(x + r * ldx + 8 * c);
+                D[k] = *reinterpret_cast<const u32x4*>(dy + r * lddy + 8 * c);
+                if (dx_add != nullptr) A[k] = *reinterpret_cast<const u32x4*>(dx_add + r * ldadd + 8 * c);
+            }
+        }
+    };
+    if (row < rows) fetch(row, rx, rd, ra, mu, rs);
+    for (; row < rows; row += rstride) {
+        u32x4 nx[MC], nd[MC], na[MC];
+        float nmu = 0.f, nrs = 0.f;
+        const bool more = row + rstride < rows;
+        if (more) fetch(row + rstride, nx, nd, na, nmu, nrs);
         float xh[MC][8], gg[MC][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -79,8 +104,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
             const int c = lane + 64 * k;
             if (c < nch) {
                 float xv[8], dv[8];
-                unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + 8 * c), xv);
-                unpack8(*reinterpret_cast<const u32x4*>(dy + row * lddy + 8 * c), dv);
+                unpack8(rx[k], xv);
+                unpack8(rd[k], dv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     xh[k][e] = (xv[e] - mu) * rs;
@@ -103,12 +128,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
                 for (int e = 0; e < 8; ++e) o[e] = rs * (gg[k][e] - s1 - xh[k][e] * s2);
                 if (dx_add != nullptr) {
                     float old[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(dx_add + row * ldadd + 8 * c), old);
+                    unpack8(ra[k], old);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += old[e];
                 }
                 *reinterpret_cast<u32x4*>(dx + row * lddx + 8 * c) = pack8(o);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < MC; ++k) { rx[k] = nx[k]; rd[k] = nd[k]; ra[k] = na[k]; }
+            mu = nmu;
+            rs = nrs;
         }
     }
     // reduce the 4 waves' column partials through LDS, one fp32 row [2H] per block
@@ -181,8 +212,20 @@ __global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb
     const mr_reduce_job& q = rb.job[j];
     const int c = ((int)blockIdx.x - rb.blk_start[j]) * 64 + lane, ncols = q.ncols, nparts = q.nparts;
     float s = 0.f;
-    if (c < ncols)
-        for (int p = grp; p < nparts; p += 16) s += q.partials[(int64_t)p * ncols + c];
+    if (c < ncols) {
+        // four independent chains: the loads of a group's partial rows are all in flight at once (this kernel reduces a few
+        // MB and was bound by one load latency per row), summed in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = grp;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += q.partials[(int64_t)p * ncols + c];
+            s1 += q.partials[(int64_t)(p + 16) * ncols + c];
+            s2 += q.partials[(int64_t)(p + 32) * ncols + c];
+            s3 += q.partials[(int64_t)(p + 48) * ncols + c];
+        }
+        for (; p < nparts; p += 16) s0 += q.partials[(int64_t)p * ncols + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < ncols) {
