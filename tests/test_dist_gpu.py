@@ -113,3 +113,46 @@ def test_rccl_collectives_single_rank(dev):
     assert ret['eager_equals_graph'], 'graph-segmented RCCL step differs from the eager RCCL step'
     # one rank: the gathered loss / averaged gradients equal the local ones up to the bf16 round trip of dE
     assert abs(L['plain'][-1] - L['rccl_eager'][-1]) < 2e-2 * abs(L['plain'][-1])
+
+
+def _vcr_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from merlot_reserve_amd import finetune as F
+    from merlot_reserve_amd.dist import Comm
+    from tests.test_vcr_gpu import vcr_cfg
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    cfg = vcr_cfg()
+    model = F.MerlotReserveVCR.from_config(cfg, device=dev, rank=rank, world=world, comm=Comm(), seed=0)   # same seed: replicated init
+    batches = [F.make_vcr_batch(cfg, 2, seed=50 + rank + 10 * i, device=dev) for i in range(3)]
+    model.init_from_dummy_batch(batches[0])
+    state, tx = F.construct_finetuning_train_state(cfg['optimizer'], model)
+    infos = []
+    for b in batches:
+        state, info = F.finetune_train_step(state, b, loss_fn=F.train_loss_fn, tx_fns=tx)
+        infos.append(info)
+    torch.cuda.synchronize()
+    # single-rank model fed BOTH ranks' batches with averaged gradients must match: emulate by comparing replicas only
+    master = model.params_store.master.detach().cpu()
+    gathered = [torch.zeros_like(master) for _ in range(world)]
+    dist.all_gather(gathered, master)
+    local_loss = model.engine.loss_info()['loss']
+    ret[rank] = dict(replicas_equal=bool(torch.equal(gathered[0], gathered[1])), infos=infos, local_last=local_loss,
+                     moved=bool((master != 0).any()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_vcr_finetune_step_on_one_gpu(dev):
+    """finetune_train_step with world_size 2 (finetune/optimization.py:143 pmean of the bf16 gradients, :178 pmean of the
+    metrics): replicas stay bit-identical, the reported loss is the mean over ranks (not the local one)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_vcr_worker, args=(world, 29800 + (os.getpid() % 1000), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0['replicas_equal'] and r1['replicas_equal'], 'ranks diverged: gradient averaging is broken'
+    assert r0['infos'] == r1['infos'], 'loss_info must be averaged over ranks'
+    assert abs(r0['infos'][-1]['loss'] - 0.5 * (r0['local_last'] + r1['local_last'])) < 1e-6
+    assert r0['local_last'] != r1['local_last']
