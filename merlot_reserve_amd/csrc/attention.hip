@@ -18,6 +18,7 @@
 // written to the other buffer afterwards -- one barrier per tile, global latency under the MFMAs.  Softmax runs in the
 // exp2 domain (scores pre-multiplied by log2 e); the additive -1e10 bias and tile tails are folded into a staged
 // per-key code tile (-2 = beyond the sequence).
+#include <stdlib.h>
 #include "mr_common.h"
 
 namespace {
@@ -528,6 +529,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
     }
 }
 
+// MR_ATTN_QB_S (diagnostic): sequences longer than this use two query / key blocks per workgroup (default 64)
+static int64_t attn_qb_threshold() {
+    static int64_t v = -1;
+    if (v < 0) { const char* e = getenv("MR_ATTN_QB_S"); v = e ? atoll(e) : 64; }
+    return v;
+}
+
 template <int QB>
 static dim3 attn_grid(int64_t S, int64_t nh, int64_t nseq) {
     return dim3((unsigned)(((S + 64 * QB - 1) / (64 * QB)) * nh * nseq));      // 1-D: see attn_block()
@@ -543,7 +551,7 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const __bf16* q = static_cast<const __bf16*>(qkv);
     __bf16* o = static_cast<__bf16*>(out);
-    const bool two = S > 64;        // short sequences (audio 31, span 16): one 16-query block per wave
+    const bool two = S > attn_qb_threshold();        // short sequences (audio 31, span 16): one 16-query block per wave
     if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
     else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
     else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
@@ -566,7 +574,7 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     __bf16* g = static_cast<__bf16*>(dqkv);
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                        static_cast<const __bf16*>(out), d, delta, rows, S, nh);
-    const bool two = S > 64;
+    const bool two = S > attn_qb_threshold();
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
