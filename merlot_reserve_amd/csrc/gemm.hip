@@ -365,7 +365,7 @@ extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* st
     MR_CHECK_ARG(list != nullptr && count >= 1, "mr_gemm_grouped: empty list");
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool all_big = use_gemm256() && count > 1 && count <= 4;
-    for (int k = 0; all_big && k < count; ++k) all_big = list[k].M > 0 && list[k].N % 128 == 0;
+    for (int k = 0; all_big && k < count; ++k) all_big = list[k].M > 0 && list[k].N % 128 == 0;     // (256-wide tiles: N % 256, checked inside)
     if (all_big && mr_gemm256_grouped(list, count, s)) {
         MR_CHECK_LAUNCH("mr_gemm_grouped");
         return MR_OK;

@@ -679,6 +679,7 @@ static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
 
 constexpr int64_t NUM_CU = 256;    // MI355X
 extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
+extern int g_mr_opt_group_tile_n;  // mr_set_option("gemm_group_tile_n")
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -777,6 +778,25 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
 // limited to bias; 128-wide tiles, no split-K.  Returns false if the group does not qualify (caller falls back).
 bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     if (count < 1 || count > g256::MAXG) return false;
+    for (int k = 0; k < count; ++k) {
+        const mr_gemm_args* a = &list[k];
+        if (!mr_gemm256_eligible(a) || a->transA != list[0].transA || a->transB != list[0].transB) return false;
+        if (a->rot_tab || a->c2 || a->act != MR_ACT_NONE || a->residual || a->aux || a->out_grp != 0) return false;
+    }
+    // tile width for the whole group: fewest CU-rounds, a 256-wide tile costing ~1.8 of a 128-wide one (the large model's
+    // four weight gradients are 384 tiles of 128 = 1.5 rounds -> 2, but 192 tiles of 256 = one round)
+    static int c256_cost = -1;
+    if (c256_cost < 0) { const char* e = getenv("MR_G256_GROUP_C256"); c256_cost = e ? atoi(e) : 180; }
+    int64_t t128 = 0, t256 = 0;
+    bool can256 = true;
+    for (int k = 0; k < count; ++k) {
+        const int64_t tm = (list[k].M + g256::BM - 1) / g256::BM;
+        t128 += tm * ((list[k].N + 127) / 128);
+        t256 += tm * ((list[k].N + 255) / 256);
+        can256 = can256 && list[k].N % 256 == 0;
+    }
+    int bn = (can256 && ((t256 + NUM_CU - 1) / NUM_CU) * c256_cost < ((t128 + NUM_CU - 1) / NUM_CU) * 100) ? 256 : 128;
+    if (g_mr_opt_group_tile_n == 128 || (g_mr_opt_group_tile_n == 256 && can256)) bn = g_mr_opt_group_tile_n;
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     int64_t tiles = 0;
@@ -784,9 +804,7 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     int64_t nk_max = 0;
     for (int k = 0; k < count; ++k) {
         const mr_gemm_args* a = &list[k];
-        if (!mr_gemm256_eligible(a) || a->transA != list[0].transA || a->transB != list[0].transB) return false;
-        if (a->rot_tab || a->c2 || a->act != MR_ACT_NONE || a->residual || a->aux || a->out_grp != 0) return false;
-        const int64_t tm = (a->M + g256::BM - 1) / g256::BM, tn = (a->N + 127) / 128;
+        const int64_t tm = (a->M + g256::BM - 1) / g256::BM, tn = (a->N + bn - 1) / bn;
         ga.tiles_n[k] = (int)tn;
         ga.tile_start[k] = (int)tiles;
         tiles += tm * tn;
@@ -796,6 +814,7 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     }
     ga.count = count; ga.nwork = (int)tiles; ga.splits = 1; ga.kt_per_split = (int)nk_max;
     dim3 grid((unsigned)(tiles < NUM_CU ? tiles : NUM_CU));
-    g256::launch<128>(ga, grid, s);
+    if (bn == 256) g256::launch<256>(ga, grid, s);
+    else g256::launch<128>(ga, grid, s);
     return true;
 }

@@ -533,10 +533,12 @@ def test_gemm256_epilogues(dev, tile_n):
     assert relerr(o32, ref) < 1e-5
 
 
-def test_gemm_grouped(dev):
-    """Four wgrad-shaped problems in one persistent launch == four separate GEMMs."""
-    from merlot_reserve_amd import ops
+@pytest.mark.parametrize('group_tile', [0, 128, 256])
+def test_gemm_grouped(dev, group_tile):
+    """Four wgrad-shaped problems in one persistent launch == four separate GEMMs (both tile widths of the shared launch)."""
+    from merlot_reserve_amd import _lib, ops
     ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+    _lib.check(_lib.load().mr_set_option(b'gemm_group_tile_n', group_tile), 'mr_set_option')
     Mtok, H = 1500, 512
     xs = [rnd((Mtok, 4 * H), dev, seed=1), rnd((Mtok, H), dev, seed=2), rnd((Mtok, H), dev, seed=3), rnd((Mtok, H), dev, seed=4)]
     ds = [rnd((Mtok, H), dev, seed=5), rnd((Mtok, 4 * H), dev, seed=6), rnd((Mtok, H), dev, seed=7), rnd((Mtok, 3 * H), dev, seed=8)]
@@ -551,3 +553,4 @@ def test_gemm_grouped(dev):
     ops.gemm_grouped([ops.gemm_args(x, dd, o, transA=True) for x, o in zip(small, so)])
     for x, o in zip(small, so):
         assert_close(o, x.float().T @ dd.float(), 3e-3, 'grouped fallback')
+    _lib.load().mr_set_option(b'gemm_group_tile_n', 0)
