@@ -210,6 +210,14 @@ int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* gra
                                  const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
                                  float eps, float weight_decay, float sched, float neg_lr, float bias_corr1,
                                  float bias_corr2, void* stream);
+/* Either chain with the four per-step scalars read from DEVICE memory: hyper_dev = {sched, neg_lr, 1/bias_corr1,
+ * 1/bias_corr2} (fp32).  The launch can then be part of a captured hipGraph, and a caller can run the optimizer on a
+ * sub-range of the flat buffers (pointers offset by a multiple of 2048 elements, decay flags by the same number of blocks)
+ * as soon as that range's gradients are final -- overlapped with the rest of backward.  orig_bf16 = NULL selects the
+ * pretraining chain, non-NULL the finetuning chain. */
+int mr_adam_bf16_update_dev(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                            float eps, float weight_decay, const float* hyper_dev, void* stream);
 /* ---- softmax cross-entropy over C <= 64 classes (finetune/vcr/qa_qar_joint_finetune.py:188-195) ----
  * logits[r * row_stride + c * class_stride] fp32; loss_out += coef * sum_r -log_softmax(logits[r])[labels[r]];
  * correct_out (nullable) += coef * #(argmax == label); dlogits_bf16 (nullable, same strides) = coef * (softmax - onehot). */

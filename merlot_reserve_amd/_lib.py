@@ -62,6 +62,7 @@ PROTOTYPES = {
     'mr_split_f32_to_bf16_hilo': (i32, [vp, vp, vp, i64, vp]),
     'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     'mr_adam_bf16_update_finetune': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    'mr_adam_bf16_update_dev': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
     'mr_softmax_xent': (i32, [vp, i64, i64, vp, i64, i64, f32, vp, vp, vp, vp]),
     'mr_nan_to_num_bf16': (i32, [vp, i64, vp]),
     'mr_cast_f32_to_bf16_params': (i32, [vp, vp, i64, vp]),

@@ -20,13 +20,16 @@ __device__ __forceinline__ float nan_to_num_f(float g) {
 
 // FT = the finetuning chain (finetune/optimization.py:77-90): after Adam, u -= wd * bf16(initial parameter), then
 // u += wd * parameter, both under the same mask.
-template <bool FT>
+// DEV: the four per-step scalars (schedule value, -lr, 1/bias_corr1, 1/bias_corr2) are read from device memory, so the
+// launch can live inside a captured hipGraph (or be issued before the host has computed them for a later step).
+template <bool FT, bool DEV = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, __bf16* __restrict__ work,
                                                    const __bf16* __restrict__ grad, __bf16* __restrict__ mu,
                                                    __bf16* __restrict__ nu, const __bf16* __restrict__ orig,
                                                    const uint8_t* __restrict__ decay_flag, float c1,
                                                    float b1, float c2, float b2, float eps, float wd, float sched, float neg_lr,
-                                                   float inv_bc1, float inv_bc2) {
+                                                   float inv_bc1, float inv_bc2, const float* __restrict__ hyper = nullptr) {
+    if (DEV) { sched = hyper[0]; neg_lr = hyper[1]; inv_bc1 = hyper[2]; inv_bc2 = hyper[3]; }
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     const bool decay = decay_flag[blockIdx.x] != 0;
     float g[8], m[8], v[8], p[8];
@@ -116,6 +119,29 @@ extern "C" int mr_adam_bf16_update_finetune(float* master, void* work_bf16, cons
                        static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, b1, c2,
                        b2, eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
     MR_CHECK_LAUNCH("mr_adam_bf16_update_finetune");
+    return MR_OK;
+}
+
+extern "C" int mr_adam_bf16_update_dev(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
+                                       const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                                       float eps, float weight_decay, const float* hyper_dev, void* stream) {
+    MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && decay_flag_per_block && hyper_dev,
+                 "mr_adam_bf16_update_dev: null pointer");
+    MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update_dev: n must be a positive multiple of 2048 (got %ld)", (long)n);
+    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)(n / 2048));
+    if (orig_bf16 != nullptr)
+        hipLaunchKernelGGL((adam_kernel<true, true>), grid, dim3(256), 0, st, master, static_cast<__bf16*>(work_bf16),
+                           static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16), static_cast<__bf16*>(nu_bf16),
+                           static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, 0.f, 0.f,
+                           1.f, 1.f, hyper_dev);
+    else
+        hipLaunchKernelGGL((adam_kernel<false, true>), grid, dim3(256), 0, st, master, static_cast<__bf16*>(work_bf16),
+                           static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16), static_cast<__bf16*>(nu_bf16),
+                           static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, 0.f, 0.f,
+                           1.f, 1.f, hyper_dev);
+    MR_CHECK_LAUNCH("mr_adam_bf16_update_dev");
     return MR_OK;
 }
 

@@ -329,3 +329,10 @@ def adam_bf16_update_finetune(master, work, grad, mu, nu, orig, decay_flags, b1,
 def softmax_xent(logits, row_stride, class_stride, labels, rows, C, coef, loss_out, correct_out=None, dlogits=None):
     check(_lib.load().mr_softmax_xent(logits.data_ptr(), row_stride, class_stride, labels.data_ptr(), rows, C, coef,
                                       loss_out.data_ptr(), _ptr(correct_out), _ptr(dlogits), _stream()), 'mr_softmax_xent')
+
+
+def adam_bf16_update_dev(master, work, grad, mu, nu, orig, decay_flags, b1, b2, eps, weight_decay, hyper):
+    """Adam chain on (a sub-range of) the flat buffers with the per-step scalars in the device vector `hyper` [4]."""
+    check(_lib.load().mr_adam_bf16_update_dev(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
+                                              _ptr(orig), decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay,
+                                              hyper.data_ptr(), _stream()), 'mr_adam_bf16_update_dev')

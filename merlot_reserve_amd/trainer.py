@@ -36,20 +36,45 @@ class TrainState:
         self.opt_config = dict(opt_config)
         self.step = 0
 
-    def apply_gradients(self):
-        """optax chain of optimization.py:180-190 + apply_updates, one fused launch over the flat buffers.
-        scale_by_schedule uses its own count, evaluated BEFORE the increment (first update is zero)."""
-        oc, p = self.opt_config, self.params
+    def _scalars(self):
+        """(sched, neg_lr, bias_corr1, bias_corr2) of the current step: scale_by_schedule uses its own count, evaluated
+        BEFORE the increment (first update is zero); no bias correction unless the config asks (optimization.py:177)."""
+        oc = self.opt_config
         assert oc.get('use_bfloat16_adam', True), 'only the bf16-state Adam of the reference configs is implemented'
-        num_steps = oc.get('num_train_steps_override', oc['num_train_steps'])
         sched = lr_scale_linearwarmup_cosinedecay(self.step, oc['num_warmup_steps'], oc['num_train_steps'],
                                                   oc.get('final_lr_scale', 0.02))
         b1, b2 = oc.get('beta_1', 0.9), oc.get('beta_2', 0.98)
         bc1 = bc2 = 1.0
         if oc.get('do_bias_correction', False):
             bc1, bc2 = 1.0 - b1 ** (self.step + 1), 1.0 - b2 ** (self.step + 1)
-        ops.adam_bf16_update(p.master, p.work, p.grad, p.mu, p.nu, p.decay_flags, b1, b2, oc.get('eps', 1e-8),
-                             oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
+        return sched, -oc['learning_rate'], bc1, bc2
+
+    def apply_gradients(self):
+        """optax chain of optimization.py:180-190 + apply_updates, one fused launch over the flat buffers."""
+        oc, p = self.opt_config, self.params
+        sched, neg_lr, bc1, bc2 = self._scalars()
+        ops.adam_bf16_update(p.master, p.work, p.grad, p.mu, p.nu, p.decay_flags, oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
+                             oc.get('eps', 1e-8), oc['weight_decay_rate'], sched, neg_lr, bc1, bc2)
+        self.step += 1
+
+    # ---- the same update in pieces: per-step scalars in a device vector (so the launches can sit inside a hipGraph) and
+    # one launch per finished range of the flat gradient buffer, overlapped with the rest of backward (trainer.Trainer)
+    def prepare_step(self):
+        if getattr(self, 'hyper', None) is None:
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=self.params.device)
+        sched, neg_lr, bc1, bc2 = self._scalars()
+        # a fresh pageable source every step (like the plan's index lists): the runtime stages it before returning, so the
+        # host may run ahead of the stream without a later step's scalars overwriting an earlier step's pending copy
+        self.hyper.copy_(torch.tensor([sched, neg_lr, 1.0 / bc1, 1.0 / bc2], dtype=torch.float32), non_blocking=True)
+
+    def apply_range(self, lo, hi):
+        oc, p = self.opt_config, self.params
+        assert lo % 2048 == 0 and hi % 2048 == 0
+        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], None,
+                                 p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
+                                 oc.get('eps', 1e-8), oc['weight_decay_rate'], self.hyper)
+
+    def finish_step(self):
         self.step += 1
 
     # ---- checkpoint form: flax `to_state_dict(TrainState)` of the reference's optax chain (optimization.py:180-195):
@@ -96,6 +121,12 @@ class Trainer:
         self.state = construct_train_state(config['optimizer'], self.params)
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
         self.comm = comm
+        tr_ = self.params.tower_ranges
+        a0_, a1_ = tr_['audio_encoder']
+        v0_, v1_ = tr_['vision_encoder']
+        assert a1_ == v0_ and v1_ == self.params.total
+        # the three ranges of the flat buffers whose gradients become final one backward stage after the other
+        self.ranges = [(0, a0_), (a0_, a1_), (v0_, v1_)]
         # the collective path runs whenever a Comm is given -- also with a single rank, which is how the RCCL calls
         # themselves are exercised on a 1-GPU box (tests/test_dist_gpu.py)
         assert world == 1 or comm is not None
@@ -138,7 +169,7 @@ class Trainer:
                      lambda: (eng.backward_stage_audio(), ops.nan_to_num_(b[1])),
                      lambda: (eng.backward_stage_vision(), ops.nan_to_num_(b[2]))]
         else:
-            segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), eng.backward())]
+            segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), self._backward_and_update())]
         pool = None
         for fn in segs:
             g = torch.cuda.CUDAGraph()
@@ -147,8 +178,28 @@ class Trainer:
             pool = g.pool()
             self.graphs.append(g)
 
+    def _backward_and_update(self):
+        """Single-rank backward with the optimizer folded in: each range of the flat buffers is updated as soon as its
+        gradients are final -- [scales, head, span, joint, token] on the side stream ahead of the audio tower's backward,
+        the audio range behind it (both beside the vision tower's backward on the main stream), the vision range last --
+        so only the last launch (27 % of the parameters) is exposed.  A later stage never reads an earlier range's weights."""
+        eng, st = self.engine, self.state
+        eng.backward_stage_joint()
+        main = torch.cuda.current_stream()
+        eng.side_stream.wait_stream(main)
+
+        def side_work():
+            st.apply_range(*self.ranges[0])
+            eng.backward_stage_audio()
+            st.apply_range(*self.ranges[1])
+        eng._on_side(side_work)
+        eng.backward_stage_vision()
+        st.apply_range(*self.ranges[2])
+        main.wait_stream(eng.side_stream)
+
     def train_step_graph(self, batch, plan):
         eng = self.engine
+        self.state.prepare_step()
         self.images_in.copy_(batch['images'], non_blocking=True)
         self.audio_in.copy_(batch['audio_clips'], non_blocking=True)
         eng.set_plan(plan)
@@ -161,18 +212,25 @@ class Trainer:
             for k in range(3):       # bucket k is all-reduced (pretrain_model.py:329) while stage k+1 runs
                 self.graphs[2 + k].replay()
                 works.append(self.comm.allreduce_mean_async(self.buckets[k]))
-            for w in works:
-                if w is not None:
-                    w.wait()
+            self._update_buckets(works)
         else:
             self.graphs[0].replay()
-        self.state.apply_gradients()
+        self.state.finish_step()
         return eng.loss_acc
+
+    def _update_buckets(self, works):
+        """Every backward stage is already enqueued: wait for each bucket's all-reduce in turn and update its range while
+        the later buckets are still being reduced."""
+        for k, w in enumerate(works):
+            if w is not None:
+                w.wait()
+            self.state.apply_range(*self.ranges[k])
 
     def train_step(self, batch, plan=None, draws=None):
         eng = self.engine
         if plan is None:
             plan = self.plan(batch, draws)
+        self.state.prepare_step()
         eng.forward(batch, plan=plan)
         if self.use_comm:
             self.comm.gather_embeddings(eng.E, self.E_all)                  # pretrain_model.py:290
@@ -187,12 +245,10 @@ class Trainer:
                 stage()
                 ops.nan_to_num_(self.buckets[k])                            # pretrain_model.py:328, before the pmean
                 works.append(self.comm.allreduce_mean_async(self.buckets[k]))   # :329 (bf16, like the reference)
-            for w in works:
-                if w is not None:
-                    w.wait()
+            self._update_buckets(works)
         else:
-            eng.backward()
-        self.state.apply_gradients()
+            self._backward_and_update()
+        self.state.finish_step()
         return eng.loss_acc
 
     def loss_info(self):
