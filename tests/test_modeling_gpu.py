@@ -189,3 +189,28 @@ def test_config1_zero_shot_forward_base_size(dev):
     ls = pm.get_label_space(['making coffee', 'going backpacking'])
     probs = torch.softmax(100.0 * got[torch.from_numpy(v['tokens'] == M.MASK).to(dev)] @ ls.T, -1)
     assert probs.shape == (1, 2) and abs(float(probs.sum()) - 1.0) < 1e-5
+
+
+def test_image_only_embedding_methods(dev):
+    """embed_preencoded_noaudio / embed_singleimg_with_multiimg_prompt (M:848-904): vision-only joint encoding, against the
+    oracle's composition of the same pieces, and against each other (a precomputed prompt + fresh images == all fresh)."""
+    cfg, model, params = make_model(dev, False)
+    model.bind(params)
+    rng = np.random.default_rng(8)
+    imgs = rng.random((4, 24, 768)).astype(np.float32)
+    tokens = np.concatenate([rng.integers(10, 32768, size=20), [3], np.zeros(11, dtype=np.int64)]).astype(np.int32)
+    subseg = np.concatenate([np.repeat(np.arange(4) * 3, 5), [9], -np.ones(11, dtype=np.int64)]).astype(np.int32)
+    enc = model.get_imgseq_only(imgs)                                      # [4, 6, H]
+    a = model.embed_preencoded_noaudio(enc, tokens, subseg)
+    b = model.embed_singleimg_with_multiimg_prompt(enc[:2], imgs[2:], tokens, subseg)
+    valid = torch.from_numpy(tokens != 0).to(dev)
+    assert a.shape == (32, 128) and relerr(a[valid], b[valid]) < 1e-5
+    # oracle composition
+    C = R.Cfg(cfg)
+    oenc = R.vision_transformer(params['vision_encoder'], torch.from_numpy(imgs), 2, 4, 6, 2)['seq_attnpool'].reshape(1, 24, 128)
+    mm = R.prepare_multimodal_inputs(params, C, tokens=torch.from_numpy(tokens.astype(np.int64))[None],
+                                     token_segment_idx=torch.div(torch.from_numpy(subseg.astype(np.int64))[None], 3, rounding_mode='floor'),
+                                     vision_input=oenc)
+    joint = R.transformer_encoder(params['joint_transformer'], mm['x'], 2, rotary_coords=mm['rotary_coords'], attention_mask=mm['attention_mask'])['seq']
+    ref = R.unit_normalize(R.dense(joint[0, :32], params['head']))
+    assert relerr(a[valid], ref[valid.cpu()]) < 1e-3
