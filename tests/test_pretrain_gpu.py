@@ -249,3 +249,48 @@ def test_training_reduces_the_contrastive_loss(dev):
     assert all(np.isfinite(hist)), hist
     assert hist[-1] < 0.8 * first, (first, hist)
     assert tr.state.step == 101
+
+
+def test_base_size_forward_parity(dev):
+    """Full-size check (BASELINE config 2's model, one record): the fp32 program against the fp32 oracle on the host
+    cores (1e-3), and the bf16 training program against the fp32 program on the same weights rounded to bf16 (2e-2)."""
+    import os
+    from merlot_reserve_amd.config import Dims, load_config
+    from merlot_reserve_amd.engine import PretrainEngine
+    from merlot_reserve_amd.params import ParamStore
+    from merlot_reserve_amd.planner import build_plan
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from oracle import ref_torch as R
+    cfg = load_config('base')
+    B = 1
+    store = ParamStore(cfg, dev, seed=0, with_optimizer=False)
+    store.load_tree(tree_to(store.work_tree(), torch.float32))          # master := bf16-representable values (both programs read the same numbers)
+    batch16 = make_batch(cfg, B, seed=5, device=dev)
+    batch32 = dict(batch16, images=batch16['images'].float(), audio_clips=batch16['audio_clips'].float())
+    splits, z = make_draws(cfg, B, seed=5)
+    plan = build_plan(batch16, Dims(cfg, B), splits, z)
+    e32 = PretrainEngine(cfg, B, store, dev, dtype=torch.float32)
+    e32.forward(batch32, plan=plan)
+    e32.loss_and_grad_outputs()
+    out32 = {k: {k2: v.clone() for k2, v in d.items()} for k, d in e32.outputs().items()}
+    loss32 = e32.loss_info()['loss']
+    del e32
+    torch.cuda.empty_cache()
+    e16 = PretrainEngine(cfg, B, store, dev)
+    e16.forward(batch16, plan=plan)
+    e16.loss_and_grad_outputs()
+    torch.cuda.synchronize()
+    for k, k2, _ in SECTIONS:
+        e = relerr(e16.outputs()[k][k2], out32[k][k2])
+        assert e <= 2e-2, f'bf16 vs fp32 program, {k}/{k2}: {e:.3e}'
+    assert abs(e16.loss_info()['loss'] - loss32) <= 2e-2 * abs(loss32)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    osp, oz = oracle_draws(splits, z)
+    with torch.no_grad():
+        preds = R.pretrain_forward(store.master_tree(), cfg, oracle_batch(batch32), osp, oz)
+        loss, _ = R.loss_fn_given_preds([preds])
+    for k, k2, _ in SECTIONS:
+        e = relerr(out32[k][k2], preds[k][k2])
+        assert e <= 1e-3, f'fp32 program vs oracle, {k}/{k2}: {e:.3e}'
+    assert abs(loss32 - float(loss)) <= 1e-3 * abs(float(loss))
+    print(f'base-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
