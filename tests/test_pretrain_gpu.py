@@ -294,3 +294,59 @@ def test_base_size_forward_parity(dev):
         assert e <= 1e-3, f'fp32 program vs oracle, {k}/{k2}: {e:.3e}'
     assert abs(loss32 - float(loss)) <= 1e-3 * abs(float(loss))
     print(f'base-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
+
+
+def test_base_size_backward_parity(dev):
+    """Every parameter gradient of the FULL base model (one record) for an injected upstream gradient dE against autograd of
+    the oracle on the host cores: same tolerance as the tiny-configuration test (|d| <= 8e-2 |g| + 1.5e-2 max|g|, cos >=
+    0.995 on every leaf that carries gradient).  Exercises the 256-row GEMM tiles, grouped weight gradients and the long
+    sequences (241 / 640) that the tiny configuration cannot."""
+    import os
+    from merlot_reserve_amd.config import Dims, load_config
+    from merlot_reserve_amd.engine import PretrainEngine
+    from merlot_reserve_amd.params import ParamStore
+    from merlot_reserve_amd.planner import build_plan
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from oracle import ref_torch as R
+    cfg = load_config('base')
+    B = 1
+    store = ParamStore(cfg, dev, seed=0, with_optimizer=False)
+    g = torch.Generator().manual_seed(2)
+    tree = store.master_tree()
+
+    def jitter(t):      # non-trivial LN / bias parameters
+        return {k: jitter(v) for k, v in t.items()} if isinstance(t, dict) else (t + 0.05 * torch.randn(t.shape, generator=g) if t.dim() == 1 else t)
+    store.load_tree(jitter(tree))
+    batch = make_batch(cfg, B, seed=6, device=dev)
+    splits, z = make_draws(cfg, B, seed=6)
+    eng = PretrainEngine(cfg, B, store, dev)
+    eng.forward(batch, plan=build_plan(batch, Dims(cfg, B), splits, z))
+    dE = (torch.randn(eng.R, eng.d.H, generator=g) * 1e-2).to(torch.bfloat16)
+    eng.dE.copy_(dE.to(dev))
+    eng.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    params = R.tree_map(lambda t: t.clone().requires_grad_(True), tree_to(store.work_tree(), torch.float32))
+    osp, oz = oracle_draws(splits, z)
+    preds = R.pretrain_forward(params, cfg, oracle_batch(batch), osp, oz)
+    total = 0.0
+    for k, k2, name in SECTIONS:
+        o, n = eng.sec[name]
+        total = total + (preds[k][k2] * dE[o:o + n].float()).sum()
+    total.backward()
+    gt = store.grad_tree()
+    leaves = [(name, t.grad if t.grad is not None else torch.zeros_like(t)) for name, t in R.tree_leaves(params)]
+    gmax = max(float(gr.norm()) for _, gr in leaves)
+    bad, worst = [], (0.0, '')
+    for name, gr in leaves:
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn, err = float(gr.norm()), float((mine.double() - gr.double()).norm())
+        cos = float((mine.double().flatten() @ gr.double().flatten()) / (mine.double().norm() * gr.double().norm() + 1e-30))
+        if gn > 5e-2 * gmax:
+            worst = max(worst, (err / gn, name))
+        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+            bad.append((name, err, gn, cos))
+    print(f'base-size backward parity: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]})')
+    assert not bad, bad[:10]
