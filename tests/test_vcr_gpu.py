@@ -149,3 +149,47 @@ def test_graph_replay_matches_eager(dev):
     pa, pb = model_a.params_store, model_b.params_store
     assert torch.equal(pa.master, pb.master) and torch.equal(pa.nu, pb.nu)
     assert model_a.engine.loss_info() == model_b.engine.loss_info()
+
+
+def test_vcr_base_size_forward_backward(dev):
+    """The VCR step at the reference's shapes (base model, image grid 18x32 -> ViT S = 577, answers [B, 2, 4, 144], joint
+    [8B, 288]; B = 1): logits and every gradient leaf (injected dL/dlogits) against the oracle on the host cores."""
+    import os
+    from merlot_reserve_amd import finetune as F
+    from merlot_reserve_amd.config import load_config
+    cfg = load_config('base')
+    cfg['model']['output_grid'] = [18, 32]
+    cfg['data'].update(lang_seq_len=144, num_answers=4)
+    model = F.MerlotReserveVCR.from_config(cfg, device=dev, seed=0)
+    batch = F.make_vcr_batch(cfg, 1, seed=0, device=dev)
+    params = model.init_from_dummy_batch(batch)
+    g = torch.Generator().manual_seed(1)
+    params['proj']['kernel'] = torch.randn(768, 1, generator=g) * 0.3
+    logits = model.apply({'params': params}, batch)
+    eng, store = model.engine, model.params_store
+    eng.loss_and_grad_logits()
+    inj = (torch.randn(8, generator=g) * 0.2).to(torch.bfloat16)
+    eng.dlogits[:, 0] = inj.to(dev)
+    eng.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ob = oracle_batch(batch)
+    wp = R.tree_map(lambda t: t.clone().requires_grad_(True), tree_to(store.work_tree(), torch.float32))
+    ref = R.vcr_forward(wp, cfg, ob)
+    e = relerr(logits, ref)
+    assert logits.shape == (1, 2, 4) and e < 2e-2, e
+    (ref * inj.float().view(1, 2, 4)).sum().backward()
+    gt = store.grad_tree()
+    leaves = [(n, t.grad if t.grad is not None else torch.zeros_like(t)) for n, t in R.tree_leaves(wp)]
+    gmax = max(float(gr.norm()) for _, gr in leaves)
+    bad = []
+    for name, gr in leaves:
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn, err = float(gr.norm()), float((mine.double() - gr.double()).norm())
+        cos = float((mine.double().flatten() @ gr.double().flatten()) / (mine.double().norm() * gr.double().norm() + 1e-30))
+        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+            bad.append((name, err, gn, cos))
+    print(f'VCR base-size parity: logits rel err {e:.2e}, {len(leaves)} gradient leaves checked')
+    assert not bad, bad[:10]
