@@ -14,6 +14,28 @@ from .planner import AUDIOSPAN
 PADDING, START, END, MASK, MASKAUDIO, LTOVPOOL, RESETCTX = 0, 1, 2, 3, 4, 6, 9
 
 
+_encoder = None
+
+
+def __getattr__(name):
+    """`from mreserve.preprocess import encoder` (preprocess.py:24): the tokenizer, loaded on first use from the vocabulary
+    file the user supplies (modeling.get_encoder)."""
+    global _encoder
+    if name == 'encoder':
+        if _encoder is None:
+            from .modeling import get_encoder
+            _encoder = get_encoder()
+        return _encoder
+    raise AttributeError(name)
+
+
+def video_to_segments(*args, **kwargs):
+    """mreserve/preprocess.py:352-460 decodes a video file with ffmpeg / librosa into frames and mel spectrograms: media
+    decoding is outside this package -- pass decoded arrays to preprocess_video."""
+    raise NotImplementedError('video decoding (ffmpeg / librosa) is out of scope: build the segment dicts from decoded frames '
+                              "('frame' or 'patches') and spectrograms ('spectrogram' [3, 60, 65]) and call preprocess_video")
+
+
 def patchify(img, output_grid_size, P=16):
     """img [h1*P, w1*P, 3] float -> [h1*w1, P*P*3]: space_to_depth in NHWC order (block row, block col, channel)."""
     h1, w1 = output_grid_size
@@ -38,7 +60,11 @@ def preprocess_video(video_segments, output_grid_size, encoder=None, verbose=Fal
             txt = segm_i.get('text', '')
             if isinstance(txt, str):
                 if encoder is None:
-                    raise ValueError('a tokenizer (`encoder`) is needed for string text; pass token ids otherwise')
+                    try:
+                        encoder = __getattr__('encoder')          # the module-level tokenizer, as in the reference
+                    except FileNotFoundError as e:
+                        raise ValueError('a tokenizer is needed for string text (pass encoder=..., set MRESERVE_TOKENIZER_JSON, '
+                                         'or pass token ids)') from e
                 txt_tok = encoder.encode(txt).ids
             else:
                 txt_tok = list(txt)
