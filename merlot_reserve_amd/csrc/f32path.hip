@@ -7,9 +7,8 @@
 //                        global -> VGPR -> LDS k-major ([k][own + pad]) so that the MFMA operand reads are conflict-free
 //                        ds_read_b32; next k-tile's global loads in flight during the multiply; epilogue
 //                        bias / "rotary" scale / gelu / residual in the MFMA layout.
-//   f32_attn_fwd_kernel  one query per lane (q and the output accumulator live in registers), keys/values staged
-//                        through LDS in chunks of 32 and read as broadcasts; exact reference mask semantics
-//                        (additive -1e10, modeling.py:353-356).
+//   f32_attn_fwd_kernel  flash attention on the same fp32 MFMA, both products transposed so that the softmax stays in
+//                        registers (see the kernel); exact reference mask semantics (additive -1e10, modeling.py:353-356).
 #include "mr_common.h"
 
 namespace {
@@ -188,38 +187,46 @@ __global__ __launch_bounds__(256) void f32_ln_fwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------- attention
-constexpr int AQ = 128;     // queries (threads) per workgroup
-constexpr int AK = 32;      // keys per LDS chunk
+// fp32 flash attention on v_mfma_f32_16x16x4_f32.  One wave = 16 queries of one (sequence, head); a workgroup = 4 waves = 64
+// queries sharing the K / V tiles (64 keys) staged in LDS.  Everything is computed TRANSPOSED so that no layout change is
+// needed between the two products:
+//   S^T[key][q] = K . Q^T      A = K  (lane: key = 16 kb + (l & 15), d = 4 s + (l >> 4)),  B = Q^T (lane: d = 4 s + g, q = l & 15)
+//   accumulator: lane (g, q) holds keys 16 kb + 4 g + r  (r = 0..3)  of its query q
+//   O^T[d][q]  += V^T . P^T    one k-step per (kb, r): the lane's own P value is the B operand (k slot g <-> key 16 kb + 4 g + r),
+//                              A = V^T (lane: key = 16 kb + 4 g + r, d = 16 db + (l & 15))
+// so the softmax runs on registers: per query, over the lane's 16 values and the 4 lane groups (two xor-shuffles).
+// Exact reference mask semantics (additive -1e10, modeling.py:353-356); keys beyond S are excluded.
+constexpr int FA_TK = 64;          // keys per LDS tile
+constexpr int FA_KLD = 66;         // K row stride (floats): (2 key + g) mod 32 distinct over a 32-lane read group
+constexpr int FA_VLD = 68;         // V row stride: rows 4 apart land 16 banks apart
 
-__global__ __launch_bounds__(AQ) void f32_attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256) void f32_attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ code,
                                                            float* __restrict__ out, float* __restrict__ lse, int S, int nh) {
-    __shared__ __attribute__((aligned(16))) float Ks[AK][64];
-    __shared__ __attribute__((aligned(16))) float Vs[AK][64];
-    __shared__ int kcode[AK];
-    __shared__ float sc[AK][AQ];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float Ks[FA_TK * FA_KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[FA_TK * FA_VLD];
+    __shared__ int kcode[FA_TK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
     const int seq = blockIdx.z, head = blockIdx.y;
     const int H = nh * 64;
-    const int qi = blockIdx.x * AQ + tid;
-    const bool qok = qi < S;
     const int64_t rowbase = (int64_t)seq * S;
-    float q[64], acc[64];
+    const int qi = blockIdx.x * 64 + wave * 16 + li;          // this lane's query (same for the 4 lane groups)
+    const bool qok = qi < S;
+    float qreg[16];                                            // Q^T operand: d = 4 s + g, pre-scaled by 1/sqrt(64) (flax: before the product)
     {
         const float* qp = qkv + (rowbase + (qok ? qi : 0)) * (3 * H) + head * 64;
 #pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
-            q[d] = v[0] * 0.125f; q[d + 1] = v[1] * 0.125f; q[d + 2] = v[2] * 0.125f; q[d + 3] = v[3] * 0.125f;   // query / sqrt(depth) first (flax)
-        }
+        for (int s = 0; s < 16; ++s) qreg[s] = qok ? qp[4 * s + g] * 0.125f : 0.f;
     }
+    const int cq = (code != nullptr && qok) ? code[rowbase + qi] : 0;
+    f32x4 ot[4];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
-    const int qc = (code != nullptr && qok) ? code[rowbase + qi] : 0;
+    for (int db = 0; db < 4; ++db) ot[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < S; k0 += AK) {
-        const int nkeys = min(AK, S - k0);
+    for (int k0 = 0; k0 < S; k0 += FA_TK) {
+        const int nkeys = min(FA_TK, S - k0);
         __syncthreads();
-        for (int c = tid; c < AK * 16; c += AQ) {
+        for (int c = tid; c < FA_TK * 16; c += 256) {          // 16 float4 chunks per key row
             const int kr = c >> 4, ch = c & 15;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (kr < nkeys) {
@@ -227,49 +234,70 @@ __global__ __launch_bounds__(AQ) void f32_attn_fwd_kernel(const float* __restric
                 kv = *reinterpret_cast<const f32x4*>(base + H);
                 vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
             }
-            *reinterpret_cast<f32x4*>(&Ks[kr][4 * ch]) = kv;
-            *reinterpret_cast<f32x4*>(&Vs[kr][4 * ch]) = vv;
+            float* kd = Ks + kr * FA_KLD + 4 * ch;             // 264-byte rows: 8-byte aligned
+            kd[0] = kv[0]; kd[1] = kv[1]; kd[2] = kv[2]; kd[3] = kv[3];
+            *reinterpret_cast<f32x4*>(Vs + kr * FA_VLD + 4 * ch) = vv;
         }
-        if (tid < AK) kcode[tid] = (code != nullptr && tid < nkeys) ? code[rowbase + k0 + tid] : 0;
+        if (tid < FA_TK) kcode[tid] = (code != nullptr && tid < nkeys) ? code[rowbase + k0 + tid] : 0;
         __syncthreads();
-        float cmax = -INFINITY;
-        for (int j = 0; j < nkeys; ++j) {
-            float s = 0.f;
+        // S^T = K . Q^T
+        f32x4 st[4];
 #pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                const f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[j][d]);
-                s += q[d] * kv[0] + q[d + 1] * kv[1] + q[d + 2] * kv[2] + q[d + 3] * kv[3];
-            }
-            if (code != nullptr) {
-                const bool allowed = (qc >= 0) && (qc == kcode[j]);
-                s += allowed ? 0.f : -1e10f;
-            }
-            sc[j][tid] = s;
-            cmax = fmaxf(cmax, s);
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const float* kp = Ks + (16 * kb + li) * FA_KLD + g;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], a, 0, 0, 0);
+            st[kb] = a;
         }
-        const float mnew = fmaxf(m, cmax);
-        const float corr = __expf(m - mnew);      // exp(-inf) = 0 on the first chunk
-        l *= corr;
+        // bias / tail, running max
+        float tmax = -INFINITY;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) acc[d] *= corr;
-        for (int j = 0; j < nkeys; ++j) {
-            const float pj = __expf(sc[j][tid] - mnew);
-            l += pj;
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[j][d]);
-                acc[d] += pj * vv[0]; acc[d + 1] += pj * vv[1]; acc[d + 2] += pj * vv[2]; acc[d + 3] += pj * vv[3];
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kb + 4 * g + r;
+                float v = st[kb][r];
+                if (code != nullptr) v += ((cq >= 0) && (cq == kcode[key])) ? 0.f : -1e10f;
+                if (key >= nkeys) v = -INFINITY;
+                st[kb][r] = v;
+                tmax = fmaxf(tmax, v);
             }
-        }
-        m = mnew;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __expf(m - mn);                    // exp(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(st[kb][r] - mn);
+                st[kb][r] = pv;
+                psum += pv;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) ot[db] *= alpha;
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = Vs + (16 * kb + 4 * g + r) * FA_VLD + li;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) ot[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * db], st[kb][r], ot[db], 0, 0, 0);
+            }
     }
     if (qok) {
         const float inv = 1.0f / l;
-        float* op = out + (rowbase + qi) * H + head * 64;
+        float* op = out + (rowbase + qi) * H + head * 64;       // lane holds d = 16 db + 4 g + r
 #pragma unroll
-        for (int d = 0; d < 64; d += 4)
-            *reinterpret_cast<f32x4*>(op + d) = f32x4{acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
-        if (lse != nullptr) lse[((int64_t)seq * nh + head) * S + qi] = m + __logf(l);
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(op + 16 * db + 4 * g) = ot[db] * inv;
+        if (lse != nullptr && g == 0) lse[((int64_t)seq * nh + head) * S + qi] = m + __logf(l);
     }
 }
 
@@ -419,8 +447,8 @@ extern "C" int mr_f32_attention_fwd(const float* qkv, const int32_t* code, float
                                     int64_t nh, void* stream) {
     MR_CHECK_ARG(qkv && out && nseq > 0 && S > 0 && nh > 0, "mr_f32_attention_fwd: bad args");
     MR_CHECK_ARG(nseq <= 65535 && nh <= 65535, "mr_f32_attention_fwd: nseq / nh exceed the grid limits");
-    dim3 grid((unsigned)((S + AQ - 1) / AQ), (unsigned)nh, (unsigned)nseq);
-    hipLaunchKernelGGL(f32_attn_fwd_kernel, grid, dim3(AQ), 0, static_cast<hipStream_t>(stream), qkv, code, out, lse, (int)S, (int)nh);
+    dim3 grid((unsigned)((S + 63) / 64), (unsigned)nh, (unsigned)nseq);
+    hipLaunchKernelGGL(f32_attn_fwd_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), qkv, code, out, lse, (int)S, (int)nh);
     MR_CHECK_LAUNCH("mr_f32_attention_fwd");
     return MR_OK;
 }
