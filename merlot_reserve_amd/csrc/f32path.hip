@@ -23,84 +23,107 @@ __device__ __forceinline__ void store8f(float* p, const float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM
-constexpr int FBM = 128, FBN = 128, FBK = 16;
-constexpr int FLD = 144;   // LDS row stride in floats: 144 mod 32 = 16, so the 4 k-rows of one MFMA operand read hit 64 distinct banks pairs
+// Square T x T x 16 tiles, T = 128 (waves 64 x 64) or 64 (waves 32 x 32): the small tile is chosen when the large one
+// would leave most of the 256 CUs without a workgroup (zero-shot shapes: M = 1312 joint rows, 4616 ViT rows).
+constexpr int FBK = 16;
+template <int T> struct F32Geo {
+    static constexpr int LD = T + 16;          // LDS row stride in floats: (T + 16) mod 32 = 16 -> the two k-rows of a 32-lane read hit disjoint banks
+    static constexpr int EPT = T / 16;         // elements per thread and operand tile (256 threads)
+    static constexpr int NI = T / 32;          // 16 x 16 MFMA blocks per wave and dimension
+};
 
-// Loads the [128 own][16 k] tile of an operand whose k index is contiguous (A [M,K], or B stored [N,K]):
-// thread t owns row t/2 and 8 consecutive k.
+// [T own][16 k] tile of an operand whose k index is contiguous (A [M,K], or B stored [N,K])
+template <int T>
 __device__ __forceinline__ void f32_load_kcontig(const float* __restrict__ base, int64_t ld, int64_t own0, int64_t k0,
-                                                 int64_t own_n, int64_t K, int tid, bool vec, float (&r)[8]) {
-    const int64_t row = own0 + (tid >> 1);
-    const int64_t k = k0 + 8 * (tid & 1);
+                                                 int64_t own_n, int64_t K, int tid, bool vec, float (&r)[F32Geo<T>::EPT]) {
+    constexpr int E = F32Geo<T>::EPT, TPR = 16 / E;          // threads per row
+    const int64_t row = own0 + tid / TPR;
+    const int64_t k = k0 + E * (tid % TPR);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = 0.f;
+    for (int e = 0; e < E; ++e) r[e] = 0.f;
     if (row >= own_n) return;
     const float* p = base + row * ld + k;
-    if (vec && k + 8 <= K) {
-        load8f(p, r);
+    if (vec && k + E <= K) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+            r[e] = v[0]; r[e + 1] = v[1]; r[e + 2] = v[2]; r[e + 3] = v[3];
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int e = 0; e < E; ++e)
             if (k + e < K) r[e] = p[e];
     }
 }
-__device__ __forceinline__ void f32_store_kcontig(float* tile, int tid, const float (&r)[8]) {
-    const int row = tid >> 1, kb = 8 * (tid & 1);
+template <int T>
+__device__ __forceinline__ void f32_store_kcontig(float* tile, int tid, const float (&r)[F32Geo<T>::EPT]) {
+    constexpr int E = F32Geo<T>::EPT, TPR = 16 / E;
+    const int row = tid / TPR, kb = E * (tid % TPR);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) tile[(kb + e) * FLD + row] = r[e];
+    for (int e = 0; e < E; ++e) tile[(kb + e) * F32Geo<T>::LD + row] = r[e];
 }
-// Loads the [16 k][128 own] tile of an operand whose own index is contiguous (B stored [K,N], or A stored [K,M]):
-// thread t owns k = t/16 and 8 consecutive own.
+// [16 k][T own] tile of an operand whose own index is contiguous (B stored [K,N], or A stored [K,M])
+template <int T>
 __device__ __forceinline__ void f32_load_kstrided(const float* __restrict__ base, int64_t ld, int64_t own0, int64_t k0,
-                                                  int64_t own_n, int64_t K, int tid, bool vec, float (&r)[8]) {
+                                                  int64_t own_n, int64_t K, int tid, bool vec, float (&r)[F32Geo<T>::EPT]) {
+    constexpr int E = F32Geo<T>::EPT;
     const int64_t k = k0 + (tid >> 4);
-    const int64_t o = own0 + 8 * (tid & 15);
+    const int64_t o = own0 + E * (tid & 15);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = 0.f;
+    for (int e = 0; e < E; ++e) r[e] = 0.f;
     if (k >= K) return;
     const float* p = base + k * ld + o;
-    if (vec && o + 8 <= own_n) {
-        load8f(p, r);
+    if (vec && o + E <= own_n) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+            r[e] = v[0]; r[e + 1] = v[1]; r[e + 2] = v[2]; r[e + 3] = v[3];
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int e = 0; e < E; ++e)
             if (o + e < own_n) r[e] = p[e];
     }
 }
-__device__ __forceinline__ void f32_store_kstrided(float* tile, int tid, const float (&r)[8]) {
-    store8f(tile + (tid >> 4) * FLD + 8 * (tid & 15), r);
+template <int T>
+__device__ __forceinline__ void f32_store_kstrided(float* tile, int tid, const float (&r)[F32Geo<T>::EPT]) {
+    constexpr int E = F32Geo<T>::EPT;
+    float* d = tile + (tid >> 4) * F32Geo<T>::LD + E * (tid & 15);
+#pragma unroll
+    for (int e = 0; e < E; e += 4) *reinterpret_cast<f32x4*>(d + e) = f32x4{r[e], r[e + 1], r[e + 2], r[e + 3]};
 }
 
-template <bool TA, bool TB>
+template <int T, bool TA, bool TB>
 __global__ __launch_bounds__(256) void f32_gemm_kernel(const mr_gemm_args p, int tiles_n, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][FBK * FLD];   // [buffer][A|B]
+    constexpr int LD = F32Geo<T>::LD, E = F32Geo<T>::EPT, NI = F32Geo<T>::NI;
+    __shared__ __attribute__((aligned(16))) float smem[2][2][FBK * LD];   // [buffer][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, li = lane & 15;
-    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * FBM;
-    const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * FBN;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * T;
+    const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * T;
     const float* A = static_cast<const float*>(p.A);
     const float* B = static_cast<const float*>(p.B);
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float ra[8], rb[8];
+    float ra[E], rb[E];
     const int64_t nk = (p.K + FBK - 1) / FBK;
     auto loadA = [&](int64_t kt) {
-        if (TA) f32_load_kstrided(A, p.lda, m0, kt * FBK, p.M, p.K, tid, vecA, ra);
-        else    f32_load_kcontig(A, p.lda, m0, kt * FBK, p.M, p.K, tid, vecA, ra);
+        if (TA) f32_load_kstrided<T>(A, p.lda, m0, kt * FBK, p.M, p.K, tid, vecA, ra);
+        else    f32_load_kcontig<T>(A, p.lda, m0, kt * FBK, p.M, p.K, tid, vecA, ra);
     };
     auto loadB = [&](int64_t kt) {
-        if (TB) f32_load_kcontig(B, p.ldb, n0, kt * FBK, p.N, p.K, tid, vecB, rb);
-        else    f32_load_kstrided(B, p.ldb, n0, kt * FBK, p.N, p.K, tid, vecB, rb);
+        if (TB) f32_load_kcontig<T>(B, p.ldb, n0, kt * FBK, p.N, p.K, tid, vecB, rb);
+        else    f32_load_kstrided<T>(B, p.ldb, n0, kt * FBK, p.N, p.K, tid, vecB, rb);
     };
     auto storeAB = [&](int buf) {
-        if (TA) f32_store_kstrided(smem[buf][0], tid, ra); else f32_store_kcontig(smem[buf][0], tid, ra);
-        if (TB) f32_store_kcontig(smem[buf][1], tid, rb); else f32_store_kstrided(smem[buf][1], tid, rb);
+        if (TA) f32_store_kstrided<T>(smem[buf][0], tid, ra); else f32_store_kcontig<T>(smem[buf][0], tid, ra);
+        if (TB) f32_store_kcontig<T>(smem[buf][1], tid, rb); else f32_store_kstrided<T>(smem[buf][1], tid, rb);
     };
     loadA(0); loadB(0);
     storeAB(0);
@@ -113,15 +136,15 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const mr_gemm_args p, int
         const float* Bs = smem[buf][1];
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 4) {
-            float af[4], bf[4];
+            float af[NI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = As[(kk + g) * FLD + wm * 64 + i * 16 + li];
+            for (int i = 0; i < NI; ++i) af[i] = As[(kk + g) * LD + wm * (T / 2) + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = Bs[(kk + g) * FLD + wn * 64 + j * 16 + li];
+            for (int j = 0; j < NI; ++j) bf[j] = Bs[(kk + g) * LD + wn * (T / 2) + j * 16 + li];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) storeAB(buf ^ 1);     // the other buffer was last read before the previous barrier
@@ -133,16 +156,16 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const mr_gemm_args p, int
     const float* R = static_cast<const float*>(p.residual);
     float* C = static_cast<float*>(p.C);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t n = n0 + wn * 64 + j * 16 + li;
+    for (int j = 0; j < NI; ++j) {
+        const int64_t n = n0 + wn * (T / 2) + j * 16 + li;
         if (n >= p.N) continue;
         const float bv = bias != nullptr ? bias[n] : 0.f;
         const bool rot = (p.rot_tab != nullptr) && (n < p.rot_cols) && ((n & 63) < 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                const int64_t m = m0 + wm * (T / 2) + i * 16 + g * 4 + r;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bv;
                 if (rot) v *= p.rot_tab[(m % p.rot_rows) * 32 + (n & 63)];
@@ -421,14 +444,22 @@ extern "C" int mr_f32_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(a->c_dtype == MR_DT_F32, "mr_f32_gemm: c_dtype must be MR_DT_F32");
     MR_CHECK_ARG(a->c2 == nullptr && a->aux == nullptr, "mr_f32_gemm: c2 / aux epilogues are training-only (bf16 path)");
     MR_CHECK_ARG(a->rot_tab == nullptr || a->rot_rows > 0, "mr_f32_gemm: rot_rows must be positive with a rot_tab");
-    const int tiles_m = (int)((a->M + FBM - 1) / FBM), tiles_n = (int)((a->N + FBN - 1) / FBN);
     const int vecA = aligned16(a->A) && a->lda % 4 == 0, vecB = aligned16(a->B) && a->ldb % 4 == 0;
-    dim3 grid((unsigned)(tiles_m * tiles_n));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!a->transA && !a->transB) hipLaunchKernelGGL((f32_gemm_kernel<false, false>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB);
-    else if (!a->transA && a->transB) hipLaunchKernelGGL((f32_gemm_kernel<false, true>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB);
-    else if (a->transA && !a->transB) hipLaunchKernelGGL((f32_gemm_kernel<true, false>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB);
-    else hipLaunchKernelGGL((f32_gemm_kernel<true, true>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB);
+    const int64_t t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    const bool small = t128 < 512;             // fewer than two 128-tiles per CU: 64 x 64 tiles (4x the workgroups)
+    const int T = small ? 64 : 128;
+    const int tiles_m = (int)((a->M + T - 1) / T), tiles_n = (int)((a->N + T - 1) / T);
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+#define MR_F32_LAUNCH(TT)                                                                                                              \
+    do {                                                                                                                               \
+        if (!a->transA && !a->transB) hipLaunchKernelGGL((f32_gemm_kernel<TT, false, false>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB); \
+        else if (!a->transA && a->transB) hipLaunchKernelGGL((f32_gemm_kernel<TT, false, true>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB); \
+        else if (a->transA && !a->transB) hipLaunchKernelGGL((f32_gemm_kernel<TT, true, false>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB); \
+        else hipLaunchKernelGGL((f32_gemm_kernel<TT, true, true>), grid, dim3(256), 0, st, *a, tiles_n, vecA, vecB);                   \
+    } while (0)
+    if (small) MR_F32_LAUNCH(64); else MR_F32_LAUNCH(128);
+#undef MR_F32_LAUNCH
     MR_CHECK_LAUNCH("mr_f32_gemm");
     return MR_OK;
 }
