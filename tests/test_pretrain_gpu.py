@@ -350,3 +350,29 @@ def test_base_size_backward_parity(dev):
             bad.append((name, err, gn, cos))
     print(f'base-size backward parity: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]})')
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('B', [1, 3, 5])
+def test_odd_batch_sizes_step(dev, B):
+    """Record counts that are not multiples of the tile / vector sizes: one eager and two graph-replayed steps, finite
+    loss equal to the oracle's on the same batch (forward tolerance)."""
+    from merlot_reserve_amd.config import tiny_config
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from merlot_reserve_amd.trainer import Trainer
+    from oracle import ref_torch as R
+    cfg = tiny_config(seq_len=80, lang_seq_len=40)
+    tr = Trainer(cfg, B, dev, seed=2)
+    batch = make_batch(cfg, B, seed=30 + B, device=dev)
+    draws = make_draws(cfg, B, seed=30 + B)
+    params = tree_to(tr.params.work_tree(), torch.float32)
+    plan = tr.plan(batch, draws)
+    tr.train_step(batch, plan=plan)
+    got = tr.loss_info()['loss']
+    osp, oz = oracle_draws(*draws)
+    with torch.no_grad():
+        loss, _ = R.loss_fn_given_preds([R.pretrain_forward(params, cfg, oracle_batch(batch), osp, oz)])
+    assert abs(got - float(loss)) <= 2e-2 * abs(float(loss)), (got, float(loss))
+    tr.capture(batch)
+    for _ in range(2):
+        tr.train_step_graph(batch, plan)
+    assert np.isfinite(tr.loss_info()['loss']) and tr.state.step == 3
