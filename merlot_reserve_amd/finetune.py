@@ -323,7 +323,7 @@ class VCRGraphStep:
         eng.plan_frozen = True
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             eng.forward_device(self.image_in)
             eng.loss_and_grad_logits()
             eng.backward()

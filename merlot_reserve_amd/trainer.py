@@ -173,7 +173,7 @@ class Trainer:
         pool = None
         for fn in segs:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):     # RCCL's watchdog thread polls events meanwhile
                 fn()
             pool = g.pool()
             self.graphs.append(g)
