@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
+    ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL process group, collectives, segmented graphs -- with a single rank')
     args = ap.parse_args()
 
     import numpy as np
@@ -98,10 +99,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or args.force_comm:
         import torch.distributed as dist
         from merlot_reserve_amd.dist import Comm
-        dist.init_process_group('nccl', device_id=dev)
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29555')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         comm = Comm()
 
     if args.resadapt:
@@ -114,7 +120,7 @@ def main():
     batches = [make_batch(config, B, seed=1234 + rank + 1000 * i, device=dev) for i in range(2)]
 
     def barrier():
-        if world > 1:
+        if comm is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,7 +145,7 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if comm is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -197,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if comm is not None:
         dist.destroy_process_group()
 
 

@@ -143,7 +143,10 @@ class Trainer:
             a0, a1 = tr['audio_encoder']
             v0, v1 = tr['vision_encoder']
             assert a1 == v0 and v1 == self.params.total
-            self.buckets = [self.params.grad[:a0], self.params.grad[a0:a1], self.params.grad[v0:v1]]
+            # two gradient buckets: [scales, head, span, joint, token] -- reduced while the audio and vision towers' backward
+            # runs (both towers concurrently, on the two streams, as in the single-rank step) -- and [audio, vision]
+            self.buckets = [self.params.grad[:a0], self.params.grad[a0:v1]]
+            self.bucket_ranges = [(0, a0), (a0, v1)]
 
     def plan(self, batch, draws=None):
         if draws is None:
@@ -166,8 +169,7 @@ class Trainer:
             b = self.buckets
             segs += [lambda: eng.loss_and_grad_outputs(self.E_all, self.dE_all),
                      lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward_stage_joint(), ops.nan_to_num_(b[0])),
-                     lambda: (eng.backward_stage_audio(), ops.nan_to_num_(b[1])),
-                     lambda: (eng.backward_stage_vision(), ops.nan_to_num_(b[2]))]
+                     lambda: (self._backward_audio_vision(), ops.nan_to_num_(b[1]))]
         else:
             segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), self._backward_and_update())]
         pool = None
@@ -197,6 +199,15 @@ class Trainer:
         st.apply_range(*self.ranges[2])
         main.wait_stream(eng.side_stream)
 
+    def _backward_audio_vision(self):
+        """The audio tower's backward on the side stream beside the vision tower's on the main stream (fork / join)."""
+        eng = self.engine
+        main = torch.cuda.current_stream()
+        eng.side_stream.wait_stream(main)
+        eng._on_side(eng.backward_stage_audio)
+        eng.backward_stage_vision()
+        main.wait_stream(eng.side_stream)
+
     def train_step_graph(self, batch, plan):
         eng = self.engine
         self.state.prepare_step()
@@ -209,7 +220,7 @@ class Trainer:
             self.graphs[1].replay()
             self.comm.scatter_grad(self.dE_all, self.dE_red)
             works = []
-            for k in range(3):       # bucket k is all-reduced (pretrain_model.py:329) while stage k+1 runs
+            for k in range(2):       # bucket 0 is all-reduced (pretrain_model.py:329) while the audio / vision towers' backward runs
                 self.graphs[2 + k].replay()
                 works.append(self.comm.allreduce_mean_async(self.buckets[k]))
             self._update_buckets(works)
@@ -224,7 +235,7 @@ class Trainer:
         for k, w in enumerate(works):
             if w is not None:
                 w.wait()
-            self.state.apply_range(*self.ranges[k])
+            self.state.apply_range(*self.bucket_ranges[k])
 
     def train_step(self, batch, plan=None, draws=None):
         eng = self.engine
@@ -241,7 +252,7 @@ class Trainer:
             eng.loss_and_grad_outputs()
         if self.use_comm:
             works = []
-            for k, stage in enumerate((eng.backward_stage_joint, eng.backward_stage_audio, eng.backward_stage_vision)):
+            for k, stage in enumerate((eng.backward_stage_joint, self._backward_audio_vision)):
                 stage()
                 ops.nan_to_num_(self.buckets[k])                            # pretrain_model.py:328, before the pmean
                 works.append(self.comm.allreduce_mean_async(self.buckets[k]))   # :329 (bf16, like the reference)
