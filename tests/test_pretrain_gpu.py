@@ -251,9 +251,10 @@ def test_training_reduces_the_contrastive_loss(dev):
     assert tr.state.step == 101
 
 
-def test_base_size_forward_parity(dev):
-    """Full-size check (BASELINE config 2's model, one record): the fp32 program against the fp32 oracle on the host
-    cores (1e-3), and the bf16 training program against the fp32 program on the same weights rounded to bf16 (2e-2)."""
+@pytest.mark.parametrize('model_name', ['base', 'large'])
+def test_base_size_forward_parity(dev, model_name):
+    """Full-size check (BASELINE config 2's / config 3's model, one record): the fp32 program against the fp32 oracle on the
+    host cores (1e-3), and the bf16 training program against the fp32 program on the same weights rounded to bf16 (2e-2)."""
     import os
     from merlot_reserve_amd.config import Dims, load_config
     from merlot_reserve_amd.engine import PretrainEngine
@@ -261,7 +262,7 @@ def test_base_size_forward_parity(dev):
     from merlot_reserve_amd.planner import build_plan
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from oracle import ref_torch as R
-    cfg = load_config('base')
+    cfg = load_config(model_name)
     B = 1
     store = ParamStore(cfg, dev, seed=0, with_optimizer=False)
     store.load_tree(tree_to(store.work_tree(), torch.float32))          # master := bf16-representable values (both programs read the same numbers)
@@ -293,7 +294,7 @@ def test_base_size_forward_parity(dev):
         e = relerr(out32[k][k2], preds[k][k2])
         assert e <= 1e-3, f'fp32 program vs oracle, {k}/{k2}: {e:.3e}'
     assert abs(loss32 - float(loss)) <= 1e-3 * abs(float(loss))
-    print(f'base-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
+    print(f'{model_name}-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
 
 
 def test_base_size_backward_parity(dev):
