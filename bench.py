@@ -5,7 +5,8 @@
 
 One "step" = one full pretraining step (plan + forward + contrastive loss + backward + gradient all-reduce + fused
 bf16-Adam update) on B records (= 2B video-segment groups of 8 frames) per GPU of synthetic data already resident in
-HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU, RCCL ("nccl") over xGMI, weak scaling.
+HBM.  N > 1: one rank per GPU under torch.distributed.run (started by the driver, or by this script itself when it is
+invoked bare), collectives on the library's RCCL communicator over xGMI inside the step's hipGraph, weak scaling.
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of its
 launches / their HIP-event durations, measured in an instrumented pass of the same steps right after the timed region;
 `cpu_baseline` times the oracle (a CPU port of the reference's step) on a bounded sample, rank 0, N=1 only.
@@ -71,6 +72,21 @@ def cpu_baseline(config, threads=None):
                       f'layers): {dt:.1f} s measured, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh ranks under torch.distributed.run as a
+    CHILD process (this process has not touched the GPU and never execs), pass rank 0's JSON line through, return its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -81,9 +97,13 @@ def main():
     ap.add_argument('--resadapt', action='store_true', help='resolution-adaptation grid 18x32 (BASELINE config 4; joint length 1312)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying hipGraphs')
-    ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL process group, collectives, segmented graphs -- with a single rank')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the hipGraph')
+    ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL communicator, collectives inside the graph -- with a single rank')
+    ap.add_argument('--comm', default='native', choices=['native', 'torch'], help="native: the library's RCCL communicator (captured into the hipGraph); torch: torch.distributed nccl (eager step)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_self_launch(args, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -95,20 +115,33 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    comm = None
+    comm, comm_kind, dist = None, None, None
     if world > 1 or args.force_comm:
         import torch.distributed as dist
-        from merlot_reserve_amd.dist import Comm
-        if world == 1:
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29555')
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-        comm = Comm()
+        from merlot_reserve_amd.dist import Comm, NativeComm
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29555')
+        # control plane (rendezvous, barriers, the max over ranks of the timed region): gloo, no GPU resources
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        if args.comm == 'native':
+            ok = 1
+            try:
+                comm = NativeComm.from_torch_distributed(dev)
+            except Exception as e:                                   # every rank must take the same branch below
+                print(f'[rank {rank}] native RCCL communicator unavailable ({e}); falling back to torch.distributed nccl', file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+        if comm is None:
+            comm = Comm(dist.new_group(backend='nccl', device_id=dev))
+        comm_kind = comm.backend
 
     if args.resadapt:
         from merlot_reserve_amd.config import resadapt_config
@@ -120,9 +153,12 @@ def main():
     batches = [make_batch(config, B, seed=1234 + rank + 1000 * i, device=dev) for i in range(2)]
 
     def barrier():
-        if comm is not None:
+        torch.cuda.synchronize()
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    use_graph = not args.no_graph and (comm is None or comm.capturable)
 
     def run(nsteps, graph=True):
         plan = trainer.plan(batches[0])
@@ -135,7 +171,6 @@ def main():
             if i + 1 < nsteps:
                 plan = trainer.plan(batches[(i + 1) % 2])     # host-side planning overlaps the GPU's step
 
-    use_graph = not args.no_graph
     run(1, graph=False)                                        # eager step: allocates every buffer
     if use_graph:
         trainer.capture(batches[0])
@@ -145,16 +180,17 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if comm is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = trainer.loss_info()['loss']
+    loss = trainer.loss_info()['loss']                         # mean over ranks (a collective when world > 1)
 
-    roof = None
+    roof, breakdown = None, None
     if not args.no_roofline:
+        nprof = min(args.steps, 3)
         ops.GEMM_PROFILE = []
-        run(min(args.steps, 3), graph=False)
+        run(nprof, graph=False)
         torch.cuda.synchronize()
         ms = sum(r[0].elapsed_time(r[1]) for r in ops.GEMM_PROFILE)
         fl = sum(r[2] for r in ops.GEMM_PROFILE)
@@ -162,28 +198,40 @@ def main():
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
         # the same launches with the side stream disabled: each GEMM then has the GPU to itself (in the step two towers
-        # run concurrently, so a launch's duration above includes the CUs it yields to the other stream)
+        # run concurrently, so a launch's duration above includes the CUs it yields to the other stream); this pass also
+        # times EVERY launch by kernel family
         os.environ['MR_NO_SIDE_STREAM'] = '1'
-        ops.GEMM_PROFILE = []
-        run(min(args.steps, 3), graph=False)
+        ops.GEMM_PROFILE, ops.FAMILY_PROFILE = [], {}
+        run(nprof, graph=False)
         torch.cuda.synchronize()
         ms_x = sum(r[0].elapsed_time(r[1]) for r in ops.GEMM_PROFILE)
         fl_x = sum(r[2] for r in ops.GEMM_PROFILE)
-        ops.GEMM_PROFILE = None
+        breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in ops.FAMILY_PROFILE.items()}
+        launches = {k: len(v) // nprof for k, v in ops.FAMILY_PROFILE.items()}
+        ops.GEMM_PROFILE, ops.FAMILY_PROFILE = None, None
         del os.environ['MR_NO_SIDE_STREAM']
+        breakdown = {'ms_per_step': breakdown, 'launches_per_step': launches, 'sum_ms': round(sum(breakdown.values()), 3),
+                     'note': 'exclusive HIP-event duration of every launch, by kernel family, in an eager pass with the side stream off; '
+                             'the graph-replayed step overlaps the towers on two streams and the optimizer / reductions on a third, '
+                             'so ms_per_step <= sum_ms'}
         ach_x = fl_x / (ms_x * 1e-3) / 1e12
-        traffic = None                # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')   # counters cannot be read from inside this process
-        if os.path.exists(pmc):
+        traffic, traffic_src = None, None       # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
+        for cand in ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
+            pmc = os.path.join(ROOT, 'profiles', cand)
+            if not os.path.exists(pmc):
+                continue
             p = json.load(open(pmc))
             if p['workload'] == {'model': args.model, 'records_per_gpu': B} and not args.resadapt:
                 g = [v for k, v in p['kernels'].items() if 'gemm' in k]
                 traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
+                traffic_src = cand
+                break
         # `achieved` = the launches timed one at a time (side stream off): that is the kernel's own duration and what rocprofv3's
         # per-kernel average of the graph-replayed step shows (profiles/); `achieved_concurrent` = the same launches timed while
         # the other tower's kernels share the GPU on the second stream (durations then include the CUs yielded to them)
         roof = {'bound': 'mfma', 'kernel': 'g256::gemm256_kernel<*> (+ gemm_bf16_kernel for small shapes)', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per GEMM launch (PMC, profiles/r01_pmc_hbm_traffic.json)', 'launches': n,
+                'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic,
+                'traffic_unit': f'HBM-side bytes per GEMM launch (PMC, profiles/{traffic_src})', 'launches': n,
                 'avg_launch_us': ms_x * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
 
     if rank == 0:
@@ -196,14 +244,22 @@ def main():
             'config': {'workload': f'{args.model} pretrain step, {B} records (= {2 * B} video-segment groups x 8 frames '
                                    f'{config["model"]["output_grid"][0] * 16}x{config["model"]["output_grid"][1] * 16} + audio + text) per GPU',
                        'records_per_gpu': B, 'parallelism': f'dp{world}', 'final_loss': loss,
+                       'comm': comm_kind, 'rccl_ranks': None if comm is None else comm.world,
+                       'gradient_buckets': [str(b[0]) for b in trainer.buckets],
+                       'exposed_gradient_fraction': (trainer.buckets[-1][2] - trainer.buckets[-1][1]) / trainer.params.total,
+                       'hipgraph': bool(use_graph),
                        'step_tflop_algorithmic': step_flops / 1e12,
                        'step_mfma_frac': step_flops / (dt / args.steps) / MFMA_BF16_PEAK},
-            'roofline': roof,
+            'roofline': roof, 'breakdown': breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(config)
         print(json.dumps(out), flush=True)
     if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -173,25 +173,32 @@ int mr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
 /* ---- unit_normalize * exp(min(log_scale, ln 100)/2)  (M:570-578, P:239-257) ----
  * x [rows, H] bf16 -> y bf16; log_scale: pointer to ONE bf16 (the working copy of contrastive_scales[i]).
- * inv_norm [rows] fp32 saved.  bwd returns dx and ADDS the temperature gradient into dlog_scale (fp32 scalar). */
+ * inv_norm [rows] fp32 saved.  bwd returns dx and the temperature gradient: dlog_scale[0] (fp32) = (accumulate ? old : 0)
+ * + this call's sum, formed from one partial per block of 4 rows (`partials`: (rows + 3) / 4 floats of caller scratch)
+ * in a fixed order -- bitwise reproducible, no float atomics. */
 int mr_unit_norm_scale_fwd(const void* x, int64_t ldx, const void* log_scale, void* y, int64_t ldy, float* inv_norm,
                            int64_t rows, int64_t H, void* stream);
 int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* log_scale, const float* inv_norm, const void* dy,
-                           int64_t lddy, void* dx, int64_t lddx, float* dlog_scale, int64_t rows, int64_t H,
-                           void* stream);
+                           int64_t lddy, void* dx, int64_t lddx, float* dlog_scale, int32_t accumulate, float* partials,
+                           int64_t rows, int64_t H, void* stream);
 
 /* ---- contrastive loss pieces (P:276-295) ----
  * logits [L, V] fp32 (from mr_gemm); numer[l] = logits[l, own_off + l]; lse over the V columns (fp32).
  * loss_out[0] += coef * sum_l (lse[l] - numer[l]);  when src != NULL, per-source sums / counts are added to
- * diag[0..5] (three sums then three counts, P:296-300).  dlogits (in place) = coef * (softmax - onehot(own)).
+ * diag[0..5] are SET to the per-source sums / counts (three sums then three counts, P:296-300).  dlogits (in place) =
+ * coef * (softmax - onehot(own)).  row_scratch: L floats of caller scratch (per-row lse - numer; the sums over rows are
+ * taken from it in a fixed order: bitwise reproducible, no float atomics).
  */
 int mr_contrastive_lse(float* logits, int64_t ldl, int64_t L, int64_t V, int64_t own_off, float coef,
-                       const int32_t* src, float* loss_out, float* diag, void* stream);
+                       const int32_t* src, float* loss_out, float* diag, float* row_scratch, void* stream);
 /* bf16 copy of an fp32 array */
 int mr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* hi = bf16(x), lo = bf16(x - hi): 16-bit-mantissa split of dL/dlogits, so that the two bf16 MFMA GEMMs on hi and lo
  * reproduce an fp32-operand product (the rows of dL/dlogits sum to zero; 8-bit rounding would break that cancellation) */
 int mr_split_f32_to_bf16_hilo(const float* src, void* hi, void* lo, int64_t n, void* stream);
+/* the same for a [rows, cols] matrix with row stride lds (elements) into two bf16 matrices with row stride ldo */
+int mr_split_f32_to_bf16_hilo_rows(const float* src, int64_t lds, void* hi, void* lo, int64_t ldo, int64_t rows, int64_t cols,
+                                   void* stream);
 
 /* ---- optimizer: nan_to_num + bf16-state Adam + weight decay + schedule + apply (P:328, O:54-114, 180-195) ----
  * Flat buffers of n elements (n % 2048 == 0): master fp32 params, bf16 grads, bf16 mu, bf16 cube-coded nu.
@@ -252,6 +259,32 @@ int mr_f32_unit_norm_scale_fwd(const float* x, int64_t ldx, const float* log_sca
                                int64_t H, void* stream);
 int mr_f32_fill_rows(const float* vec, float* dst, int64_t ldd, int64_t ngroups, int64_t grp_stride, int64_t off,
                      int64_t H, void* stream);
+
+/* ---- data-parallel collectives over RCCL / xGMI (one process per GPU) ------------------------------------------------
+ * Replace the XLA collectives of the pmap'ed step: jax.lax.all_gather of the packed contrastive embeddings (P:290) and its
+ * transpose in backward (a reduce-scatter), jax.lax.pmean of the bf16 gradient pytree (P:329) and of the fp32 metrics
+ * (P:336).  A communicator belongs to the process's CURRENT device at mr_comm_init time; every call is asynchronous on the
+ * given stream, never synchronises, and may be captured into a hipGraph together with the kernels around it.
+ * RCCL (librccl.so.1) is resolved at run time from the copy already in the process; calls fail with MR_ELAUNCH and a
+ * message if it is absent.  Counts are in elements.
+ */
+#define MR_COMM_UNIQUE_ID_BYTES 128
+typedef struct mr_comm mr_comm;
+/* rank 0 creates the id (ncclGetUniqueId) and hands its 128 bytes to every rank out of band */
+int mr_comm_unique_id(void* id_out);
+/* collective over all ranks: each calls it with the same id, its own rank, on its own device */
+int mr_comm_init(int32_t rank, int32_t world, const void* unique_id, mr_comm** out);
+int mr_comm_destroy(mr_comm* comm);
+int32_t mr_comm_rank(const mr_comm* comm);
+int32_t mr_comm_world(const mr_comm* comm);
+/* buf[n] bf16 <- mean over ranks, in place (bf16 like pmean on the bf16 gradients, P:323-329) */
+int mr_allreduce_mean_bf16(mr_comm* comm, void* buf, int64_t n, void* stream);
+/* buf[n] fp32 <- mean over ranks (loss_info, P:336) */
+int mr_allreduce_mean_f32(mr_comm* comm, float* buf, int64_t n, void* stream);
+/* recv[world * n_per_rank] bf16: block r = rank r's send[n_per_rank]  (rank-major, as all_gather(...).reshape(-1, H)) */
+int mr_allgather(mr_comm* comm, const void* send, void* recv, int64_t n_per_rank, void* stream);
+/* recv[n_per_rank] bf16 = sum over ranks of their send[rank * n_per_rank ...]  (transpose of mr_allgather) */
+int mr_reducescatter_sum(mr_comm* comm, const void* send, void* recv, int64_t n_per_rank, void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,8 +56,9 @@ PROTOTYPES = {
     'mr_sum_rows_strided': (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
     'mr_add_bf16': (i32, [vp, vp, vp, i64, vp]),
     'mr_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, vp, i64, i64, vp]),
-    'mr_unit_norm_scale_bwd': (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i64, vp]),
-    'mr_contrastive_lse': (i32, [vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
+    'mr_unit_norm_scale_bwd': (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i32, vp, i64, i64, vp]),
+    'mr_contrastive_lse': (i32, [vp, i64, i64, i64, i64, f32, vp, vp, vp, vp, vp]),
+    'mr_split_f32_to_bf16_hilo_rows': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_cast_f32_to_bf16': (i32, [vp, vp, i64, vp]),
     'mr_split_f32_to_bf16_hilo': (i32, [vp, vp, vp, i64, vp]),
     'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
@@ -74,6 +75,15 @@ PROTOTYPES = {
     'mr_f32_rows_mean_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_f32_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_f32_fill_rows': (i32, [vp, vp, i64, i64, i64, i64, i64, vp]),
+    'mr_comm_unique_id': (i32, [vp]),
+    'mr_comm_init': (i32, [i32, i32, vp, C.POINTER(vp)]),
+    'mr_comm_destroy': (i32, [vp]),
+    'mr_comm_rank': (i32, [vp]),
+    'mr_comm_world': (i32, [vp]),
+    'mr_allreduce_mean_bf16': (i32, [vp, vp, i64, vp]),
+    'mr_allreduce_mean_f32': (i32, [vp, vp, i64, vp]),
+    'mr_allgather': (i32, [vp, vp, vp, i64, vp]),
+    'mr_reducescatter_sum': (i32, [vp, vp, vp, i64, vp]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmreserve_hip.so')
-SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
 
 
 def _needs_build():
@@ -34,7 +34,7 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
     if verbose:
         print(f'built {LIB}', file=sys.stderr)

@@ -265,6 +265,19 @@ __global__ void split_hilo_kernel(const float* __restrict__ src, __bf16* __restr
     }
 }
 
+// the same split for a [rows, cols] fp32 matrix (row stride lds) into two bf16 matrices with row stride ldo
+__global__ void split_hilo_rows_kernel(const float* __restrict__ src, int64_t lds, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                       int64_t ldo, int64_t rows, int64_t cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const float x = src[r * lds + c];
+        const __bf16 h = (__bf16)x;
+        hi[r * ldo + c] = h;
+        lo[r * ldo + c] = (__bf16)(x - (float)h);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- unit-normalise * temperature
 constexpr float LN100 = 4.605170185988092f;
 
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(256) void unit_norm_bwd_kernel(const __bf16* __rest
                                                             const __bf16* __restrict__ log_scale,
                                                             const float* __restrict__ inv_norm, const __bf16* __restrict__ dy,
                                                             int64_t lddy, __bf16* __restrict__ dx, int64_t lddx,
-                                                            float* __restrict__ dlog_scale, int64_t rows, int H) {
+                                                            float* __restrict__ dls_partials, int64_t rows, int H) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
@@ -327,18 +340,32 @@ __global__ __launch_bounds__(256) void unit_norm_bwd_kernel(const __bf16* __rest
     }
     if (lane == 0) red[wave] = (row < rows) ? ndn : 0.f;
     __syncthreads();
-    if (threadIdx.x == 0 && ls < LN100) {
-        // d/dls [n * exp(ls/2)] = n * temp / 2  ->  dls = (temp/2) * sum n*dy
-        atomicAdd(dlog_scale, 0.5f * temp * (red[0] + red[1] + red[2] + red[3]));
+    // d/dls [n * exp(ls/2)] = n * temp / 2  ->  dls = (temp/2) * sum n*dy; the clip (P:239) passes gradient only below ln 100.
+    // One partial per block, summed in a fixed order by mr_reduce_f32_ordered: bitwise reproducible (no float atomics).
+    if (threadIdx.x == 0) dls_partials[blockIdx.x] = (ls < LN100) ? 0.5f * temp * (red[0] + red[1] + red[2] + red[3]) : 0.f;
+}
+
+// dst[0] (+)= sum of src[0..n) in a FIXED order: one block, thread t sums elements t, t + 256, ... then a fixed tree.
+__global__ __launch_bounds__(256) void reduce_f32_ordered_kernel(const float* __restrict__ src, int64_t n, float scale,
+                                                                 float* __restrict__ dst, int accumulate) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) a += src[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) dst[0] = (accumulate ? dst[0] : 0.f) + scale * red[0];
 }
 
 // ---------------------------------------------------------------------------------------------- contrastive LSE
-// pretrain_model.py:276-300 for one direction of one objective: loss += coef * sum_l (lse_l - logits[l, own_off + l]),
-// logits overwritten by dL/dlogits = coef * (softmax - onehot).
+// pretrain_model.py:276-300 for one direction of one objective: row_out[l] = lse_l - logits[l, own_off + l],
+// logits overwritten by dL/dlogits = coef * (softmax - onehot).  The loss (and the per-source diagnostics) are summed from
+// row_out in a fixed order by contrastive_reduce_kernel: bitwise reproducible (no float atomics).
 __global__ __launch_bounds__(256) void contrastive_lse_kernel(float* __restrict__ logits, int64_t ldl, int64_t L, int64_t V,
-                                                              int64_t own_off, float coef, const int32_t* __restrict__ src,
-                                                              float* __restrict__ loss_out, float* __restrict__ diag) {
+                                                              int64_t own_off, float coef, float* __restrict__ row_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= L) return;
@@ -357,11 +384,38 @@ __global__ __launch_bounds__(256) void contrastive_lse_kernel(float* __restrict_
         if (c == own_off + row) g -= 1.0f;
         x[c] = coef * g;
     }
-    if (lane == 0) {
-        atomicAdd(loss_out, coef * (lse - numer));
+    if (lane == 0) row_out[row] = lse - numer;
+}
+
+// loss_out[0] += coef * sum_l row[l];  diag[s] = sum over rows with source s of row[l], diag[3 + s] = their count (P:296-300)
+__global__ __launch_bounds__(256) void contrastive_reduce_kernel(const float* __restrict__ row, int64_t L, float coef,
+                                                                 const int32_t* __restrict__ src, float* __restrict__ loss_out,
+                                                                 float* __restrict__ diag) {
+    __shared__ float red[7][256];
+    float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = threadIdx.x; i < L; i += 256) {
+        const float v = row[i];
+        a[0] += v;
+        if (src != nullptr) {
+            const int s = src[i];
+            if (s >= 0 && s < 3) { a[1 + s] += v; a[4 + s] += 1.0f; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] += coef * red[0][0];
         if (src != nullptr && diag != nullptr) {
-            const int s = src[row];
-            if (s >= 0 && s < 3) { atomicAdd(diag + s, lse - numer); atomicAdd(diag + 3 + s, 1.0f); }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) diag[k] = red[1 + k][0];
         }
     }
 }
@@ -525,6 +579,17 @@ extern "C" int mr_split_f32_to_bf16_hilo(const float* src, void* hi, void* lo, i
     return MR_OK;
 }
 
+extern "C" int mr_split_f32_to_bf16_hilo_rows(const float* src, int64_t lds, void* hi, void* lo, int64_t ldo, int64_t rows,
+                                              int64_t cols, void* stream) {
+    MR_CHECK_ARG(src && hi && lo && rows > 0 && cols > 0 && lds >= cols && ldo >= cols, "mr_split_f32_to_bf16_hilo_rows: bad args");
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_hilo_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds,
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), ldo, rows, cols);
+    MR_CHECK_LAUNCH("mr_split_f32_to_bf16_hilo_rows");
+    return MR_OK;
+}
+
 extern "C" int mr_unit_norm_scale_fwd(const void* x, int64_t ldx, const void* log_scale, void* y, int64_t ldy, float* inv_norm,
                                       int64_t rows, int64_t H, void* stream) {
     MR_CHECK_ARG(x && log_scale && y && inv_norm && rows > 0 && H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0,
@@ -537,22 +602,27 @@ extern "C" int mr_unit_norm_scale_fwd(const void* x, int64_t ldx, const void* lo
 }
 
 extern "C" int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* log_scale, const float* inv_norm, const void* dy,
-                                      int64_t lddy, void* dx, int64_t lddx, float* dlog_scale, int64_t rows, int64_t H,
-                                      void* stream) {
-    MR_CHECK_ARG(x && log_scale && inv_norm && dy && dx && dlog_scale && rows > 0 && H % 8 == 0 && ldx % 8 == 0 &&
+                                      int64_t lddy, void* dx, int64_t lddx, float* dlog_scale, int32_t accumulate,
+                                      float* partials, int64_t rows, int64_t H, void* stream) {
+    MR_CHECK_ARG(x && log_scale && inv_norm && dy && dx && dlog_scale && partials && rows > 0 && H % 8 == 0 && ldx % 8 == 0 &&
                      lddy % 8 == 0 && lddx % 8 == 0, "mr_unit_norm_scale_bwd: bad args");
-    hipLaunchKernelGGL(unit_norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    const int64_t nblk = (rows + 3) / 4;                 // = the number of floats `partials` must hold
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(unit_norm_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
                        static_cast<const __bf16*>(x), ldx, static_cast<const __bf16*>(log_scale), inv_norm,
-                       static_cast<const __bf16*>(dy), lddy, static_cast<__bf16*>(dx), lddx, dlog_scale, rows, (int)H);
+                       static_cast<const __bf16*>(dy), lddy, static_cast<__bf16*>(dx), lddx, partials, rows, (int)H);
+    hipLaunchKernelGGL(reduce_f32_ordered_kernel, dim3(1), dim3(256), 0, st, partials, nblk, 1.0f, dlog_scale, (int)accumulate);
     MR_CHECK_LAUNCH("mr_unit_norm_scale_bwd");
     return MR_OK;
 }
 
 extern "C" int mr_contrastive_lse(float* logits, int64_t ldl, int64_t L, int64_t V, int64_t own_off, float coef,
-                                  const int32_t* src, float* loss_out, float* diag, void* stream) {
-    MR_CHECK_ARG(logits && loss_out && L > 0 && V > 0 && own_off >= 0 && own_off + L <= V, "mr_contrastive_lse: bad args");
-    hipLaunchKernelGGL(contrastive_lse_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       logits, ldl, L, V, own_off, coef, src, loss_out, diag);
+                                  const int32_t* src, float* loss_out, float* diag, float* row_scratch, void* stream) {
+    MR_CHECK_ARG(logits && loss_out && row_scratch && L > 0 && V > 0 && own_off >= 0 && own_off + L <= V, "mr_contrastive_lse: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(contrastive_lse_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, st, logits, ldl, L, V, own_off, coef,
+                       row_scratch);
+    hipLaunchKernelGGL(contrastive_reduce_kernel, dim3(1), dim3(256), 0, st, row_scratch, L, coef, src, loss_out, diag);
     MR_CHECK_LAUNCH("mr_contrastive_lse");
     return MR_OK;
 }

@@ -1,14 +1,26 @@
-"""Data-parallel collectives of the pretraining step: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
-ROCm; "gloo" for the CPU tests).  Three exchanges per step:
+"""Data-parallel collectives of the pretraining step: one process per GPU.  Four exchanges per step:
   gather_embeddings  all-gather of the packed contrastive embeddings, rank-major  (pretrain_model.py:290)
   scatter_grad       its transpose: reduce-scatter(sum) of dL/dE_all back to the owning rank
-  allreduce_mean     mean of the bf16 gradient buffer over ranks                    (pretrain_model.py:329)
+  allreduce_mean     mean of a bf16 gradient bucket over ranks                      (pretrain_model.py:329)
+  allreduce_mean_f32 mean of the fp32 metrics                                       (pretrain_model.py:336)
+
+Two transports with the same methods; every method enqueues on torch's CURRENT stream and orders itself after the work
+already on it:
+  NativeComm  the library's own RCCL communicator (mr_comm_* of include/mreserve_hip.h) over xGMI.  Its calls are plain
+              stream-ordered launches, so they are captured into the step's hipGraph with the kernels around them:
+              what bench.py uses on the GPUs.
+  Comm        torch.distributed ("gloo" for the CPU tests and for two test processes sharing one GPU; "nccl" as a
+              fallback).  Not capturable: the step then runs eagerly.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
 
 class Comm:
+    capturable = False
+
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
@@ -39,10 +51,77 @@ class Comm:
             flat.copy_((tmp / self.world).to(flat.dtype))
         return flat
 
-    def allreduce_mean_async(self, flat):
-        """Non-blocking form for gradient buckets: returns a handle with .wait() (nccl: runs on RCCL's stream after the
-        producing kernels, overlapping the compute stream), or None when the backend completed it synchronously."""
-        if self.backend == 'nccl':
-            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        self.allreduce_mean(flat)
-        return None
+    def allreduce_mean_f32(self, t):
+        return self.allreduce_mean(t)
+
+    def close(self):
+        pass
+
+
+class NativeComm:
+    """RCCL communicator owned by libmreserve_hip.so (one per process, bound to the current device)."""
+    capturable = True
+    backend = 'rccl-native'
+
+    def __init__(self, rank=0, world=1, unique_id=None):
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        if unique_id is None:
+            assert world == 1, 'world > 1: rank 0 creates the id (NativeComm.new_unique_id) and every rank passes the same bytes'
+            unique_id = self.new_unique_id()
+        assert len(unique_id) == 128
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(lib.mr_comm_init(rank, world, buf, C.byref(h)), 'mr_comm_init')
+        self._h = h
+        assert lib.mr_comm_world(h) == world and lib.mr_comm_rank(h) == rank
+
+    @staticmethod
+    def new_unique_id():
+        from . import _lib
+        buf = (C.c_char * 128)()
+        _lib.check(_lib.load().mr_comm_unique_id(buf), 'mr_comm_unique_id')
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, device, group=None):
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast to every rank."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group, device=torch.device(device) if dist.get_backend(group) == 'nccl' else None)
+        return cls(rank, world, box[0])
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def gather_embeddings(self, E, E_all):
+        assert E.is_contiguous() and E_all.is_contiguous() and E.dtype == torch.bfloat16 and E_all.numel() == self.world * E.numel()
+        self._lib.check(self._lib.load().mr_allgather(self._h, E.data_ptr(), E_all.data_ptr(), E.numel(), self._stream()), 'mr_allgather')
+        return E_all
+
+    def scatter_grad(self, dE_all, out):
+        assert out.is_contiguous() and dE_all.is_contiguous() and out.dtype == torch.bfloat16 and dE_all.numel() == self.world * out.numel()
+        self._lib.check(self._lib.load().mr_reducescatter_sum(self._h, dE_all.data_ptr(), out.data_ptr(), out.numel(), self._stream()),
+                        'mr_reducescatter_sum')
+        return out
+
+    def allreduce_mean(self, flat):
+        assert flat.is_contiguous()
+        if flat.dtype == torch.float32:
+            return self.allreduce_mean_f32(flat)
+        assert flat.dtype == torch.bfloat16
+        self._lib.check(self._lib.load().mr_allreduce_mean_bf16(self._h, flat.data_ptr(), flat.numel(), self._stream()), 'mr_allreduce_mean_bf16')
+        return flat
+
+    def allreduce_mean_f32(self, t):
+        assert t.is_contiguous() and t.dtype == torch.float32
+        self._lib.check(self._lib.load().mr_allreduce_mean_f32(self._h, t.data_ptr(), t.numel(), self._stream()), 'mr_allreduce_mean_f32')
+        return t
+
+    def close(self):
+        if self._h is not None:
+            self._lib.load().mr_comm_destroy(self._h)
+            self._h = None

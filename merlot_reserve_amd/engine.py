@@ -69,6 +69,14 @@ class TowerEngine:
         sc.Dpatch = z(Ps, H)
         return sc
 
+    # GEMMs of this engine: split-K partials go to the scratch set being issued on (`self.cur`: main / side stream), which
+    # belongs to THIS engine -- no module-level workspace (two engines, or a captured graph and a later engine, never share)
+    def gemm(self, a, b, out, **kw):
+        return ops.gemm(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
+
+    def gemm_args(self, a, b, out, **kw):
+        return ops.gemm_args(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
+
     def _on_side(self, fn):
         """Issue fn()'s kernels on the side stream (forked from / joined to the current stream by the caller)."""
         if self.fwd_only:
@@ -76,15 +84,14 @@ class TowerEngine:
                 return fn()
             with torch.cuda.stream(self.side_stream):
                 return fn()
-        main_ws = ops.GEMM_WORKSPACE
-        self.cur, ops.GEMM_WORKSPACE = self.sc_side, self.sc_side.gemm_ws
+        self.cur = self.sc_side
         try:
             if os.environ.get('MR_NO_SIDE_STREAM') == '1':       # (A/B switch) same work, issued in line
                 return fn()
             with torch.cuda.stream(self.side_stream):
                 return fn()
         finally:
-            self.cur, ops.GEMM_WORKSPACE = self.sc_main, main_ws
+            self.cur = self.sc_main
 
     def _unpad_csr(self, nseq, S):
         rows = (np.arange(nseq)[:, None] * S + 1 + np.arange(S - 1)[None]).reshape(-1).astype(np.int32)
@@ -93,21 +100,43 @@ class TowerEngine:
 
     # ------------------------------------------------------------------------------------------ plan upload
     def set_plan(self, plan):
-        """Copy the host plan into persistent device buffers (same addresses every step: graph-capturable)."""
-        for k, v in plan.items():
-            if not isinstance(v, np.ndarray):
-                continue
-            t = torch.from_numpy(np.ascontiguousarray(v))
-            cap = self._plan_caps.get(k, 0)
-            if k not in self.plan_dev or t.numel() > cap:
-                assert not self.plan_frozen, f'plan buffer {k} would be reallocated after graph capture'
-                # index lists are bounded by the number of joint + span positions; everything else has a fixed size
-                newcap = self._idx_capacity() if k.endswith('_idx') else t.numel()
-                newcap = max(newcap, t.numel())
-                self.plan_dev[k] = torch.zeros(newcap, dtype=t.dtype, device=self.dev)
-                self._plan_caps[k] = newcap
-            self.plan_dev[k][:t.numel()].copy_(t.reshape(-1), non_blocking=True)
-            self._plan_views[k] = self.plan_dev[k][:t.numel()].view(t.shape)
+        """Copy the host plan into ONE persistent device buffer (same addresses every step: graph-capturable) through a ring
+        of two pinned host buffers and ONE asynchronous H2D copy per step.  A pinned buffer is rewritten only after the copy
+        that last read it has completed (an event per buffer), so the host may plan step t+1 while the GPU runs step t and
+        the copy engine never reads memory the host has since reused.  (Pageable sources made every copy a staged,
+        stream-serialising one.)"""
+        arrs = {k: np.ascontiguousarray(v) for k, v in plan.items() if isinstance(v, np.ndarray)}
+        need_layout = any(k not in self._plan_caps or a.nbytes > self._plan_caps[k] for k, a in arrs.items())
+        if need_layout:
+            assert not self.plan_frozen, 'plan buffers would be reallocated after graph capture'
+            # index lists are bounded by the number of joint + span positions; everything else has a fixed size
+            off = 0
+            self._plan_off, self._plan_caps = {}, {}
+            for k, a in arrs.items():
+                cap = max(self._idx_capacity() * a.itemsize if k.endswith('_idx') else a.nbytes, a.nbytes)
+                cap = (cap + 255) // 256 * 256
+                self._plan_off[k], self._plan_caps[k] = off, cap
+                off += cap
+            self.plan_dev = torch.zeros(off, dtype=torch.uint8, device=self.dev)
+            pin = self.dev.type == 'cuda'
+            self._plan_host = [torch.zeros(off, dtype=torch.uint8, pin_memory=pin) for _ in range(2)]
+            self._plan_ev = [None, None]
+            self._plan_turn = 0
+        i = self._plan_turn
+        self._plan_turn ^= 1
+        if self._plan_ev[i] is not None:
+            self._plan_ev[i].synchronize()
+        host = self._plan_host[i].numpy()
+        for k, a in arrs.items():
+            o = self._plan_off[k]
+            host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        self.plan_dev.copy_(self._plan_host[i], non_blocking=True)
+        if self.dev.type == 'cuda':
+            self._plan_ev[i] = torch.cuda.Event()
+            self._plan_ev[i].record()
+        for k, a in arrs.items():
+            o = self._plan_off[k]
+            self._plan_views[k] = self.plan_dev[o:o + a.nbytes].view(torch.from_numpy(a[:0].reshape(-1)).dtype).view(a.shape)
         self.plan = plan
 
     def _pl(self, k):
@@ -133,19 +162,21 @@ class TowerEngine:
             n = self._names(prefix, l)
             x = st.X[l]
             ops.layernorm_fwd(x, W[n['g1']], W[n['b1']], st.ln1[l], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1])
-            ops.gemm(st.ln1[l], W[n['wqkv']], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
+            self.gemm(st.ln1[l], W[n['wqkv']], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
             ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
-            ops.gemm(st.att[l], W[n['wo']], st.xmid[l], residual=x)
+            self.gemm(st.att[l], W[n['wo']], st.xmid[l], residual=x)
             ops.layernorm_fwd(st.xmid[l], W[n['g2']], W[n['b2']], st.ln2[l], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1])
-            ops.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
-            ops.gemm(st.hact[l], W[n['w2']], st.X[l + 1], residual=st.xmid[l])
+            self.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
+            self.gemm(st.hact[l], W[n['w2']], st.X[l + 1], residual=st.xmid[l])
         k = 2 * st.L + 1
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
-    def encoder_backward(self, st, prefix, rot, code, D):
+    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None):
         """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (one of D / two scratch
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
-        gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K)."""
+        gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K).
+        layer_done(l): called once layer l's backward is enqueued, i.e. every parameter gradient of layers >= l is final on
+        the issuing stream (the data-parallel trainer reduces gradient buckets from there while backward continues)."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
         T_a, T_q, T_h = self.cur.T_a[:M], self.cur.T_q[:M], self.cur.T_h[:M]
         Dcur, Dmid, Dnext = D, self.cur.T_d1[:M], self.cur.T_d2[:M]
@@ -155,23 +186,25 @@ class TowerEngine:
         jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
-            ops.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
-            ops.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
+            self.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
+            self.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
                               G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
-            ops.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
+            self.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
             ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh)
             ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
             ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
-            ops.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
-            ops.gemm_grouped([ops.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
-                              ops.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
-                              ops.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
-                              ops.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
+            self.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
+            ops.gemm_grouped([self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
+                              self.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
+                              self.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
+                              self.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
             ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
                               G[n['g1']], G[n['b1']], self.cur.ln_ws2, dx_add=Dmid, jobs=jobs)   # Dnext = d X[l]
             if jobs is not None:
                 ops.reduce_partials(jobs)          # the layer's 2 LayerNorm + 2 bias gradients: one launch
+            if layer_done is not None:
+                layer_done(l)
             Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
         ops.layernorm_bwd(Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
                           G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.cur.ln_ws)
@@ -185,41 +218,42 @@ class TowerEngine:
         W, nh = self.W, st.H // 64
         ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
         self.encoder_forward(st, prefix_t, rot, None)
-        ops.gemm(self._cls_view(st.xf, st.nseq, st.S), W[f'{prefix_t}/cls_proj/kernel'], out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
+        self.gemm(self._cls_view(st.xf, st.nseq, st.S), W[f'{prefix_t}/cls_proj/kernel'], out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
         ops.rows_mean_fwd(st.xf, pool_rows, qin)
-        ops.gemm(qin, W[f'{prefix_pool}/query/kernel'], q, bias=W[f'{prefix_pool}/query/bias'])
-        ops.gemm(st.xf, W[f'{prefix_pool}/key/kernel'], k, bias=W[f'{prefix_pool}/key/bias'])
-        ops.gemm(st.xf, W[f'{prefix_pool}/value/kernel'], v, bias=W[f'{prefix_pool}/value/bias'])
+        self.gemm(qin, W[f'{prefix_pool}/query/kernel'], q, bias=W[f'{prefix_pool}/query/bias'])
+        self.gemm(st.xf, W[f'{prefix_pool}/key/kernel'], k, bias=W[f'{prefix_pool}/key/bias'])
+        self.gemm(st.xf, W[f'{prefix_pool}/value/kernel'], v, bias=W[f'{prefix_pool}/value/bias'])
         ops.poolattn_fwd(q, k, v, pool_rows, po, probs, nh)
-        ops.gemm(po, W[f'{prefix_pool}/out/kernel'], out_seq, bias=W[f'{prefix_pool}/out/bias'])
+        self.gemm(po, W[f'{prefix_pool}/out/kernel'], out_seq, bias=W[f'{prefix_pool}/out/bias'])
 
-    def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D):
+    def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D,
+                                  layer_done=None):
         """d_seq: grad wrt the pooled sequence output; d_cls: grad wrt the cls output.  Returns D = grad wrt st.xin."""
         W, G, nh, M = self.p.w, self.p.g, st.H // 64, st.M
         Gn = qin.shape[0]
         d_po, d_q, d_qin = self.cur.d_pool_po[:Gn], self.cur.d_pool_q[:Gn], self.cur.d_pool_qin[:Gn]
         d_k, d_v = self.cur.d_k[:M], self.cur.d_v[:M]
         ops.colsum(d_seq, G[f'{prefix_pool}/out/bias'], self.cur.cs_ws)
-        ops.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
-        ops.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
+        self.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
+        self.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
         ops.poolattn_bwd(q, k, v, pool_rows, probs, d_po, d_q, d_k, d_v, nh)
         ops.colsum(d_q, G[f'{prefix_pool}/query/bias'], self.cur.cs_ws)
-        ops.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
-        ops.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
+        self.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
+        self.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
         ops.colsum(d_k, G[f'{prefix_pool}/key/bias'], self.cur.cs_ws)
-        ops.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
-        ops.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
+        self.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
+        self.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
         ops.colsum(d_v, G[f'{prefix_pool}/value/bias'], self.cur.cs_ws)
-        ops.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
-        ops.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
+        self.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
+        self.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
         ops.rows_mean_bwd(d_qin, pool_rows, D)
         # cls head
         cls_in = self._cls_view(st.xf, st.nseq, st.S)
         ops.colsum(d_cls, G[f'{prefix_t}/cls_proj/bias'], self.cur.cs_ws)
-        ops.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
+        self.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
         Dc = self._cls_view(D, st.nseq, st.S)
-        ops.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
-        D = self.encoder_backward(st, prefix_t, rot, None, D)
+        self.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
+        D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
 
@@ -279,20 +313,49 @@ class PretrainEngine(TowerEngine):
         self.loss_acc = f(3)
         self.diag = f(2, 6)
         self.dls = f(3)
+        self.dls_part = f((self.R + 3) // 4 + 8)
         # objectives: (name, x section, y sections (gathered across ranks), scale index)
         self.objectives = [('imgs_to_audio', 'i2a_x', ('i2a_y',), 0), ('text_to_audio', 't2a_x', ('t2a_y', 't2a_ye'), 1),
                            ('stuff_to_span', 's2s_x', ('s2s_y',), 2)]
-        self.logit_bufs = {}
-        for name, xs, ys, _ in self.objectives:
-            nx = self.sec[xs][1]
-            ny = sum(self.sec[y][1] for y in ys)
-            ny0 = self.sec[ys[0]][1]
-            for direction, (L_, V_) in (('xy', (nx, world * ny)), ('yx', (ny0, world * nx))):
-                ldv = (V_ + 7) // 8 * 8
-                self.logit_bufs[(name, direction)] = (f(L_, ldv), z(L_, ldv), z(L_, ldv), V_)
+        # One contrastive problem per (objective, direction) (P:276-295): queries = a local section, keys = the matching
+        # section(s) of EVERY rank, rank-major (all_gather(...).reshape(-1, H), P:290).  The gathered embeddings E_all
+        # [world, R, H] are re-packed once per step into Kcat, where each problem's keys are contiguous rows (so logits,
+        # d(query) and d(key) are ONE GEMM each for any world size) and appear twice, for the hi / lo split of dL/dlogits:
+        #   rows [kb, kb + ldv): key c of the problem at row kb + c (zero rows for c >= V = world * nk), [kb + ldv, kb + 2 ldv): again.
+        self.cprob = []
+        kb = 0
+        for oi, (name, xs, ys, _) in enumerate(self.objectives):
+            xo, nx = self.sec[xs]
+            yo, ny, ny0 = self.sec[ys[0]][0], sum(self.sec[y][1] for y in ys), self.sec[ys[0]][1]
+            for di, (q_off, Lq, k_off, nk) in enumerate(((xo, nx, yo, ny), (yo, ny0, xo, nx))):
+                V = world * nk
+                ldv = (V + 7) // 8 * 8
+                self.cprob.append(dict(oi=oi, di=di, name=name, q_off=q_off, Lq=Lq, k_off=k_off, nk=nk, V=V, ldv=ldv, kb=kb,
+                                       logits=f(Lq, ldv), dl=None if self.fwd_only else z(Lq, 2 * ldv)))
+                kb += 2 * ldv
+        self.Kcat = z(kb, H)
+        self.lse_rows = f(max(p['Lq'] for p in self.cprob))
+        # static index lists of the re-pack (a gather from E_all's rows) and of its transpose (dE_all row <- DK hi + lo rows)
+        ip, ix = [0], []
+        src_of = {}
+        for p in self.cprob:
+            for half in range(2):
+                for c in range(p['ldv']):
+                    if c < p['V']:
+                        r, j = divmod(c, p['nk'])
+                        ix.append(r * self.R + p['k_off'] + j)
+                        if half == 0:
+                            src_of[r * self.R + p['k_off'] + j] = (p['kb'] + c, p['kb'] + p['ldv'] + c)
+                    ip.append(len(ix))
+        self.kpack = (torch.tensor(ip, dtype=I32, device=dev), torch.tensor(ix if ix else [0], dtype=I32, device=dev))
+        assert sorted(src_of) == list(range(world * self.R)), 'every gathered row is a key of exactly one problem'
+        if not self.fwd_only:
+            self.DK = z(kb, H)
+            self.kunpack = (torch.arange(0, 2 * world * self.R + 1, 2, dtype=I32, device=dev),
+                            torch.tensor([v for e in range(world * self.R) for v in src_of[e]], dtype=I32, device=dev))
 
         self.side_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
-        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
+        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = None, {}, {}, False
         self.cur = None
         if self.fwd_only:
             return
@@ -305,7 +368,6 @@ class PretrainEngine(TowerEngine):
         self.sc_main = self._make_scratch(Mmax, max(self.Gv, self.Ga), max(d.Nv * d.hw, d.Na * d.a_len), H, d.nh)   # also serves audio when issued in line
         self.sc_side = self._make_scratch(self.ta.M, self.Ga, d.Na * d.a_len, H, d.nh)
         self.cur = self.sc_main
-        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
         self.dXpool = z(self.n_pool, H)
         self.d_hj = z(self.tj.M, H)
         self.d_acls_g, self.d_a_cls = z(d.Na, H), z(d.Na, H)
@@ -343,7 +405,7 @@ class PretrainEngine(TowerEngine):
                 a_view = self.a_in[:, :d.a_patch * 65]
             else:
                 a_view = audio
-            ops.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
+            self.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
             self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                           self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
                                           self.a_probs, self.audio_seq, self.a_cls)
@@ -352,7 +414,7 @@ class PretrainEngine(TowerEngine):
         self._on_side(audio_fwd)
         # vision tower (modeling.py:379-430)
         images = self._images2d = batch['images'].reshape(d.Nv * d.hw, d.pp3)
-        ops.gemm(images, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self.gemm(images, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                       self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                       self.v_probs, self.imgs_seq, self.v_cls)
@@ -364,14 +426,14 @@ class PretrainEngine(TowerEngine):
             ops.segment_sum([emb], self._pl('span_gather_indptr'), self._pl('span_gather_idx'), ts.xin)
             ops.fill_rows(W['span_encoder/transformer/cls'], ts.xin, ts.nseq, ts.S, 0)
             self.encoder_forward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'))
-            ops.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
+            self.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
                      bias=W['span_encoder/transformer/cls_proj/bias'])
         self.side_stream.wait_stream(main)
         self._on_side(span_fwd)
         # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
         self.encoder_forward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'))
-        ops.gemm(tj.xf, W['head/kernel'], self.hj, bias=W['head/bias'])
+        self.gemm(tj.xf, W['head/kernel'], self.hj, bias=W['head/bias'])
         ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)
         ops.segment_sum([self.a_cls], self._pl('acls_indptr'), self._pl('acls_idx'), self.acls_g)
         main.wait_stream(self.side_stream)
@@ -398,47 +460,40 @@ class PretrainEngine(TowerEngine):
     def loss_and_grad_outputs(self, E_all=None, dE_all=None):
         """loss_fn_given_preds (pretrain_model.py:262-303) for this rank and dL/dE.
         world > 1: E_all [world,R,H] is the rank-major all-gather of every rank's E (:290); the gradient wrt this rank's
-        queries accumulates in self.dE, the gradient wrt EVERY rank's keys in dE_all [world,R,H] (zeroed here), which
-        the caller reduce-scatters (sum) and adds to self.dE before backward().
+        queries goes to self.dE, the gradient wrt EVERY rank's keys to dE_all [world,R,H] (every row written), which the
+        caller reduce-scatters (sum) and adds to self.dE before backward().  world == 1: both land in self.dE.
+        Per (objective, direction): one logits GEMM, the fp32 LSE, and -- dL/dlogits split into bf16 hi + lo side by side so
+        that the products keep 16 mantissa bits (its rows sum to zero) with fp32 accumulation over BOTH halves -- one GEMM
+        for d(queries) and one for d(keys); 30 launches + 2 re-packs per step whatever the world size.
         Returns the fp32 device vector loss_acc[3] (per-objective losses of this rank)."""
         world, rank, H = self.world, self.rank, self.d.H
         if world == 1:
-            E_all, dE_all = self.E[None], self.dE[None]
+            E_all = self.E[None]
         else:
             assert E_all is not None and dE_all is not None and E_all.shape[0] == world
-            dE_all.zero_()
+        ops.segment_sum([E_all.view(world * self.R, H)], self.kpack[0], self.kpack[1], self.Kcat)
         self.dE.zero_()
         self.loss_acc.zero_()
         self.diag.zero_()
-        for oi, (name, xs, ys, _) in enumerate(self.objectives):
-            xo, nx = self.sec[xs]
-            yo, ny = self.sec[ys[0]][0], sum(self.sec[k][1] for k in ys)
-            ny0 = self.sec[ys[0]][1]
-            x_loc = self.E[xo:xo + nx]
-            y_loc0 = self.E[yo:yo + ny0]
-            for di, direction in enumerate(('xy', 'yx')):
-                logits, dl_hi, dl_lo, V = self.logit_bufs[(name, direction)]
-                if direction == 'xy':
-                    q_loc, q_off, k_off, nk = x_loc, xo, yo, ny
-                else:
-                    q_loc, q_off, k_off, nk = y_loc0, yo, xo, nx
-                Lq = q_loc.shape[0]
-                for r in range(world):                                         # rank-major columns (:290)
-                    ops.gemm(q_loc, E_all[r, k_off:k_off + nk], logits[:, r * nk:(r + 1) * nk], transB=True)
-                src = self._pl('t2sp_src') if name == 'stuff_to_span' else None
-                ops.contrastive_lse(logits[:, :V], rank * nk, 0.5 / Lq, src, self.loss_acc[oi:oi + 1],
-                                    self.diag[di] if src is not None else None)
-                if self.fwd_only:
-                    continue
-                ops.split_hilo(logits, dl_hi, dl_lo)                           # rows of dlogits sum to 0: keep 16 bits
-                dq = self.dE[q_off:q_off + Lq]
-                for r in range(world):
-                    keys = E_all[r, k_off:k_off + nk]
-                    dk = dE_all[r, k_off:k_off + nk]
-                    for dlb in (dl_lo, dl_hi):
-                        blk = dlb[:, r * nk:(r + 1) * nk]
-                        ops.gemm(blk, keys, dq, residual=dq)                   # d(query side) += dlogits . keys
-                        ops.gemm(blk, q_loc, dk, transA=True, residual=dk)     # d(key side)   += dlogits^T . queries
+        for p in self.cprob:
+            q = self.E[p['q_off']:p['q_off'] + p['Lq']]
+            kb, V, ldv = p['kb'], p['V'], p['ldv']
+            logits = p['logits']
+            self.gemm(q, self.Kcat[kb:kb + V], logits, transB=True)               # rank-major columns (:290)
+            is_s2s = p['name'] == 'stuff_to_span'
+            ops.contrastive_lse(logits[:, :V], rank * p['nk'], 0.5 / p['Lq'], self._pl('t2sp_src') if is_s2s else None,
+                                self.loss_acc[p['oi']:p['oi'] + 1], self.diag[p['di']] if is_s2s else None, self.lse_rows)
+            if self.fwd_only:
+                continue
+            dl = p['dl']                                                           # [Lq, hi(ldv) | lo(ldv)]; pad columns stay 0
+            ops.split_hilo_rows(logits[:, :V], dl[:, :V], dl[:, ldv:ldv + V])
+            self.gemm(dl, self.Kcat[kb:kb + 2 * ldv], self.dE[p['q_off']:p['q_off'] + p['Lq']])     # d(query side) = dlogits . keys
+            self.gemm(dl, q, self.DK[kb:kb + 2 * ldv], transA=True)               # d(key side)   = dlogits^T . queries (hi rows, lo rows)
+        if not self.fwd_only:
+            if world == 1:
+                ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], self.dE, accumulate=True)
+            else:
+                ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], dE_all.view(world * self.R, H))
         return self.loss_acc
 
     # ------------------------------------------------------------------------------------------ backward
@@ -466,7 +521,7 @@ class PretrainEngine(TowerEngine):
         for (src, names, si), dst in zip(self._norm_sections(), dsts):
             o, n = self.sec[names[0]][0], sum(self.sec[k][1] for k in names)
             ops.unit_norm_scale_bwd(src, W['contrastive_scales'][si:si + 1], self.inv_norm[o:o + n], self.dE[o:o + n], dst,
-                                    self.dls[si:si + 1])
+                                    self.dls[si:si + 1], self.dls_part, accumulate=True)
         ops.cast_f32_to_bf16(self.dls, G['contrastive_scales'])
 
         def span_bwd():
@@ -475,8 +530,8 @@ class PretrainEngine(TowerEngine):
             Ds.zero_()
             cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
             ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cur.cs_ws)
-            ops.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
-            ops.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
+            self.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
+            self.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
             Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
             ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
             if Ds.data_ptr() != self.Ds.data_ptr():            # the joint tower reuses the rotating scratch: keep a copy
@@ -490,9 +545,9 @@ class PretrainEngine(TowerEngine):
         # joint tower
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
         ops.colsum(self.d_hj, G['head/bias'], self.cur.cs_ws)
-        ops.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
+        self.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
         Dj = self.Dj
-        ops.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
+        self.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
         Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
         main.wait_stream(self.side_stream)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
@@ -510,17 +565,17 @@ class PretrainEngine(TowerEngine):
         Dp = self.cur.Dpatch[:d.Na * d.a_len]
         ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
         ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cur.cs_ws)
-        ops.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
-    def backward_stage_vision(self):
+        self.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
+    def backward_stage_vision(self, layer_done=None):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
         tv = self.tv
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                             self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
-                                            self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv)
+                                            self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv, layer_done=layer_done)
         Dp = self.cur.Dpatch[:d.Nv * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
         ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
-        ops.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
+        self.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
 
     def loss_info(self):
         """Host dict like the reference's loss_info (pretrain_model.py:263-303) from the device accumulators."""

@@ -124,9 +124,8 @@ class VCREngine(TowerEngine):
         self.sc_main = self._make_scratch(Mmax, G, B * d.hw, H, d.nh)
         self.sc_side = self.sc_main                   # single-stream program: the two towers are strictly sequential
         self.cur = self.sc_main
-        ops.GEMM_WORKSPACE = self.sc_main.gemm_ws
         self.side_stream = None
-        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = {}, {}, {}, False
+        self.plan_dev, self._plan_caps, self._plan_views, self.plan_frozen = None, {}, {}, False
 
     def _idx_capacity(self):
         return self.tj.M + 64
@@ -142,13 +141,13 @@ class VCREngine(TowerEngine):
     def forward_device(self, image):
         d, W, tv, tj = self.d, self.W, self.tv, self.tj
         self._images2d = image.reshape(d.B * d.hw, d.pp3)
-        ops.gemm(self._images2d, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self.gemm(self._images2d, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
                                       self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.imgs_seq, self.v_cls)
         ops.segment_sum([W['token_encoder/Embed_0/embedding'], self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
         self.encoder_forward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'))
         ops.segment_sum([tj.xf], self._pl('pool_indptr'), self._pl('pool_idx'), self.pooled_h)
-        ops.gemm(self.pooled_h, W['proj/kernel'], self.logits, transB=True)          # Dense(1): [n, H] x [1, H]^T -> column 0
+        self.gemm(self.pooled_h, W['proj/kernel'], self.logits, transB=True)          # Dense(1): [n, H] x [1, H]^T -> column 0
         return self.logits[:, 0].view(d.B, 2, d.A)
 
     def loss_and_grad_logits(self):
@@ -165,8 +164,8 @@ class VCREngine(TowerEngine):
     def backward_stage_joint(self):
         d, W, G, tj = self.d, self.W, self.p.g, self.tj
         dl = self.dlogits[:, :1]
-        ops.gemm(dl, self.pooled_h, G['proj/kernel'], transA=True)                   # d proj [1, H] = dlogits^T . pooled_h
-        ops.gemm(dl, W['proj/kernel'], self.d_pooled)                                # d pooled_h = dlogits . proj^T
+        self.gemm(dl, self.pooled_h, G['proj/kernel'], transA=True)                   # d proj [1, H] = dlogits^T . pooled_h
+        self.gemm(dl, W['proj/kernel'], self.d_pooled)                                # d pooled_h = dlogits . proj^T
         ops.segment_sum([self.d_pooled], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.Dj)   # zero except the pooled rows
         Dj = self.encoder_backward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'), self.Dj)
         ops.segment_sum([Dj], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
@@ -180,7 +179,7 @@ class VCREngine(TowerEngine):
         Dp = self.cur.Dpatch[:d.B * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
         ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
-        ops.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
+        self.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
 
     def loss_info(self):
         la = self.loss_acc.tolist()
@@ -289,15 +288,18 @@ def finetune_train_step(state, batch, loss_fn=None, tx_fns=None, scan_minibatch=
     if comm is not None:
         v0, v1 = p.tower_ranges['vision_encoder']
         assert v1 == p.total
+        main = torch.cuda.current_stream()
+        if getattr(eng, 'comm_stream', None) is None:
+            eng.comm_stream = torch.cuda.Stream(device=eng.dev)
         eng.backward_stage_joint()
-        ops.nan_to_num_(p.grad[:v0])
-        w0 = comm.allreduce_mean_async(p.grad[:v0])              # overlaps the vision tower's backward
+        eng.comm_stream.wait_stream(main)
+        with torch.cuda.stream(eng.comm_stream):                 # overlaps the vision tower's backward
+            ops.nan_to_num_(p.grad[:v0])
+            comm.allreduce_mean(p.grad[:v0])
         eng.backward_stage_vision()
         ops.nan_to_num_(p.grad[v0:])
-        w1 = comm.allreduce_mean_async(p.grad[v0:])
-        for w in (w0, w1):
-            if w is not None:
-                w.wait()
+        comm.allreduce_mean(p.grad[v0:])
+        main.wait_stream(eng.comm_stream)
     else:
         eng.backward()
     state.apply_gradients()

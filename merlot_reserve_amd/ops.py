@@ -29,13 +29,32 @@ def _ld(t):
 # Optional per-launch timing of the dominant kernel (bench.py): a list that receives (start_event, end_event, flops)
 # for every mr_gemm launch, recorded with HIP events on the stream the kernel is launched on.
 GEMM_PROFILE = None
-# fp32 scratch for split-K (set once by the engine; None disables split-K)
-GEMM_WORKSPACE = None
+# Optional per-launch timing of EVERY op by kernel family (bench.py's breakdown): a dict family -> list of (start, end)
+# HIP events recorded on the stream the op is launched on.
+FAMILY_PROFILE = None
+
+
+def _timed(family):
+    def deco(fn):
+        def wrapper(*a, **k):
+            if FAMILY_PROFILE is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            FAMILY_PROFILE.setdefault(family, []).append((e0, e1))
+            return r
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
 
 
 def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
-              residual=None, aux=None, row_map=None):
-    """Builds the mr_gemm_args of out[M,N] = op(a) @ op(b) (see gemm())."""
+              residual=None, aux=None, row_map=None, ws=None):
+    """Builds the mr_gemm_args of out[M,N] = op(a) @ op(b) (see gemm()).  ws: the CALLER's fp32 scratch for split-K
+    partials (None disables split-K); it is per engine and per stream -- there is no module-level workspace, so two
+    engines (or a captured graph and a later engine) can never share or outlive each other's scratch."""
     M, K = (a.shape[1], a.shape[0]) if transA else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if transB else (b.shape[0], b.shape[1])
     assert K == Kb, f'gemm: K mismatch {K} vs {Kb}'
@@ -67,13 +86,15 @@ def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, ro
     else:
         g.out_grp = g.out_grp_stride = g.out_grp_off = 0
         assert out.shape[0] >= M and out.shape[1] >= N
-    if GEMM_WORKSPACE is not None:
-        g.workspace, g.workspace_bytes = GEMM_WORKSPACE.data_ptr(), GEMM_WORKSPACE.numel() * 4
+    if ws is not None:
+        assert ws.dtype == F32 and ws.device == a.device
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     else:
         g.workspace, g.workspace_bytes = None, 0
     return g
 
 
+@_timed('gemm')
 def gemm(a, b, out, **kw):
     """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
     (or [N,K] if transB).  row_map = (grp, grp_stride, grp_off) remaps output rows (out must be big enough)."""
@@ -94,6 +115,7 @@ def gemm(a, b, out, **kw):
     return out
 
 
+@_timed('gemm')
 def gemm_grouped(arg_list):
     """Several independent GEMMs (built with gemm_args) in one persistent launch when they qualify."""
     lib = _lib.load()
@@ -108,6 +130,7 @@ def gemm_grouped(arg_list):
     check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 
 
+@_timed('layernorm+reductions')
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
     rows, H = x.shape
     if x.dtype == F32:
@@ -123,6 +146,7 @@ def layernorm_bwd_workspace(H, device):
     return torch.empty(_lib.load().mr_layernorm_bwd_workspace(H) // 4, dtype=F32, device=device)
 
 
+@_timed('layernorm+reductions')
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_dx=False, dx_add=None, jobs=None):
     """dx = LN backward (+ dx_add; add_to_dx=True is shorthand for dx_add=dx).  With `jobs` (a list) the dgamma/dbeta
     reduction is deferred: a job is appended for reduce_partials() and `partials` must stay untouched until then."""
@@ -144,6 +168,7 @@ def colsum_workspace(N, device):
     return torch.empty(_lib.load().mr_colsum_workspace(N) // 4, dtype=F32, device=device)
 
 
+@_timed('layernorm+reductions')
 def colsum(x, out, partials, jobs=None):
     """out[n] = sum_m x[m, n]; with `jobs` the final reduction is deferred to reduce_partials() (see layernorm_bwd)."""
     rows, N = x.shape
@@ -155,6 +180,7 @@ def colsum(x, out, partials, jobs=None):
     return out
 
 
+@_timed('layernorm+reductions')
 def reduce_partials(jobs):
     """Runs the deferred column reductions (<= 8 per launch) and clears the list."""
     while jobs:
@@ -164,6 +190,7 @@ def reduce_partials(jobs):
         check(_lib.load().mr_reduce_partials(arr, len(chunk), _stream()), 'mr_reduce_partials')
 
 
+@_timed('attention')
 def attention_fwd(qkv, code, out, lse, nseq, S, nh):
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (nseq * S, 3 * nh * 64)
     if qkv.dtype == F32:
@@ -175,6 +202,7 @@ def attention_fwd(qkv, code, out, lse, nseq, S, nh):
     return out
 
 
+@_timed('attention')
 def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh):
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     rr = 0 if rot_tab is None else rot_tab.numel() // 32
@@ -184,6 +212,7 @@ def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh):
     return dqkv
 
 
+@_timed('rowops')
 def poolattn_fwd(q, k, v, key_rows, out, probs, nh):
     G, R = key_rows.shape
     assert _ld(k) == _ld(v)
@@ -196,6 +225,7 @@ def poolattn_fwd(q, k, v, key_rows, out, probs, nh):
     return out
 
 
+@_timed('rowops')
 def poolattn_bwd(q, k, v, key_rows, probs, dout, dq, dk, dv, nh):
     G, R = key_rows.shape
     assert _ld(k) == _ld(v) == _ld(dk) == _ld(dv)
@@ -204,6 +234,7 @@ def poolattn_bwd(q, k, v, key_rows, probs, dout, dq, dk, dv, nh):
           'mr_poolattn_bwd')
 
 
+@_timed('rowops')
 def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
     """srcs: list of 1..3 row tables; indices address their row-wise concatenation."""
     s = list(srcs) + [None] * (3 - len(srcs))
@@ -224,6 +255,7 @@ def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
     return dst
 
 
+@_timed('rowops')
 def rows_mean_fwd(src, rows, dst):
     G, R = rows.shape
     if src.dtype == F32:
@@ -235,12 +267,14 @@ def rows_mean_fwd(src, rows, dst):
     return dst
 
 
+@_timed('rowops')
 def rows_mean_bwd(ddst, rows, dsrc):
     G, R = rows.shape
     check(_lib.load().mr_rows_mean_bwd(ddst.data_ptr(), rows.data_ptr(), dsrc.data_ptr(), _ld(dsrc), G, R, ddst.shape[1],
                                        _stream()), 'mr_rows_mean_bwd')
 
 
+@_timed('rowops')
 def pad_cols(src, dst):
     assert src.is_contiguous() and dst.is_contiguous()
     check(_lib.load().mr_pad_cols(src.data_ptr(), src.shape[1], dst.data_ptr(), dst.shape[1], src.shape[0], _stream()),
@@ -248,6 +282,7 @@ def pad_cols(src, dst):
     return dst
 
 
+@_timed('rowops')
 def fill_rows(vec, dst, ngroups, grp_stride, off):
     if dst.dtype == F32:
         check(_lib.load().mr_f32_fill_rows(vec.data_ptr(), dst.data_ptr(), _ld(dst), ngroups, grp_stride, off, dst.shape[1],
@@ -257,18 +292,21 @@ def fill_rows(vec, dst, ngroups, grp_stride, off):
           'mr_fill_rows')
 
 
+@_timed('rowops')
 def sum_rows_strided(src, ngroups, grp_stride, off, out):
     check(_lib.load().mr_sum_rows_strided(src.data_ptr(), _ld(src), ngroups, grp_stride, off, src.shape[1], out.data_ptr(),
                                           _stream()), 'mr_sum_rows_strided')
     return out
 
 
+@_timed('rowops')
 def add_(a, b, y=None):
     y = a if y is None else y
     check(_lib.load().mr_add_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), 'mr_add_bf16')
     return y
 
 
+@_timed('rowops')
 def unit_norm_scale_fwd(x, log_scale, y, inv_norm=None):
     """y = unit_normalize(x) * exp(min(log_scale, ln 100) / 2); fp32 path: log_scale None = plain unit_normalize."""
     rows, H = x.shape
@@ -281,56 +319,79 @@ def unit_norm_scale_fwd(x, log_scale, y, inv_norm=None):
     return y
 
 
-def unit_norm_scale_bwd(x, log_scale, inv_norm, dy, dx, dlog_scale):
+@_timed('rowops')
+def unit_norm_scale_bwd(x, log_scale, inv_norm, dy, dx, dlog_scale, partials, accumulate=False):
+    """dlog_scale[0] = (accumulate ? old : 0) + this call's temperature gradient; partials: >= (rows + 3) // 4 fp32 scratch."""
     rows, H = x.shape
+    assert partials.dtype == F32 and partials.numel() >= (rows + 3) // 4
     check(_lib.load().mr_unit_norm_scale_bwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), inv_norm.data_ptr(), dy.data_ptr(),
-                                             _ld(dy), dx.data_ptr(), _ld(dx), dlog_scale.data_ptr(), rows, H, _stream()),
-          'mr_unit_norm_scale_bwd')
+                                             _ld(dy), dx.data_ptr(), _ld(dx), dlog_scale.data_ptr(), int(accumulate),
+                                             partials.data_ptr(), rows, H, _stream()), 'mr_unit_norm_scale_bwd')
     return dx
 
 
-def contrastive_lse(logits, own_off, coef, src, loss_out, diag):
+@_timed('rowops')
+def contrastive_lse(logits, own_off, coef, src, loss_out, diag, row_scratch):
+    """loss_out[0] += coef * sum_l (lse_l - logits[l, own_off + l]); logits <- dL/dlogits; row_scratch: >= L fp32."""
     L, V = logits.shape
+    assert row_scratch.dtype == F32 and row_scratch.numel() >= L
     check(_lib.load().mr_contrastive_lse(logits.data_ptr(), _ld(logits), L, V, own_off, coef, _ptr(src), loss_out.data_ptr(),
-                                         _ptr(diag), _stream()), 'mr_contrastive_lse')
+                                         _ptr(diag), row_scratch.data_ptr(), _stream()), 'mr_contrastive_lse')
 
 
+@_timed('rowops')
 def cast_f32_to_bf16(src, dst):
     check(_lib.load().mr_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), 'mr_cast_f32_to_bf16')
     return dst
 
 
+@_timed('rowops')
 def split_hilo(src, hi, lo):
     check(_lib.load().mr_split_f32_to_bf16_hilo(src.data_ptr(), hi.data_ptr(), lo.data_ptr(), src.numel(), _stream()),
           'mr_split_f32_to_bf16_hilo')
 
 
+@_timed('rowops')
+def split_hilo_rows(src, hi, lo):
+    """src [rows, cols] fp32 -> hi, lo [rows, cols] bf16 views (any row strides): x = hi + lo to 16 mantissa bits."""
+    rows, cols = src.shape
+    assert hi.shape == lo.shape == src.shape and _ld(hi) == _ld(lo)
+    check(_lib.load().mr_split_f32_to_bf16_hilo_rows(src.data_ptr(), _ld(src), hi.data_ptr(), lo.data_ptr(), _ld(hi), rows, cols,
+                                                     _stream()), 'mr_split_f32_to_bf16_hilo_rows')
+
+
+@_timed('optimizer')
 def adam_bf16_update(master, work, grad, mu, nu, decay_flags, b1, b2, eps, weight_decay, sched, neg_lr, bc1=1.0, bc2=1.0):
     check(_lib.load().mr_adam_bf16_update(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
                                           decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay, sched, neg_lr,
                                           bc1, bc2, _stream()), 'mr_adam_bf16_update')
 
 
+@_timed('optimizer')
 def nan_to_num_(g):
     check(_lib.load().mr_nan_to_num_bf16(g.data_ptr(), g.numel(), _stream()), 'mr_nan_to_num_bf16')
 
 
+@_timed('optimizer')
 def cast_params(master, work):
     check(_lib.load().mr_cast_f32_to_bf16_params(master.data_ptr(), work.data_ptr(), master.numel(), _stream()),
           'mr_cast_f32_to_bf16_params')
 
 
+@_timed('optimizer')
 def adam_bf16_update_finetune(master, work, grad, mu, nu, orig, decay_flags, b1, b2, eps, weight_decay, sched, neg_lr, bc1, bc2):
     check(_lib.load().mr_adam_bf16_update_finetune(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
                                                    orig.data_ptr(), decay_flags.data_ptr(), master.numel(), b1, b2, eps,
                                                    weight_decay, sched, neg_lr, bc1, bc2, _stream()), 'mr_adam_bf16_update_finetune')
 
 
+@_timed('rowops')
 def softmax_xent(logits, row_stride, class_stride, labels, rows, C, coef, loss_out, correct_out=None, dlogits=None):
     check(_lib.load().mr_softmax_xent(logits.data_ptr(), row_stride, class_stride, labels.data_ptr(), rows, C, coef,
                                       loss_out.data_ptr(), _ptr(correct_out), _ptr(dlogits), _stream()), 'mr_softmax_xent')
 
 
+@_timed('optimizer')
 def adam_bf16_update_dev(master, work, grad, mu, nu, orig, decay_flags, b1, b2, eps, weight_decay, hyper):
     """Adam chain on (a sub-range of) the flat buffers with the per-step scalars in the device vector `hyper` [4]."""
     check(_lib.load().mr_adam_bf16_update_dev(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),

@@ -149,11 +149,6 @@ def train_step(state, batch, use_bfloat16_grads=True, split_from_here=None, gumb
     tr = state._model._ensure(batch)
     draws = None if split_from_here is None else (split_from_here, gumbel_z)
     tr.train_step(batch, draws=draws)
-    info = tr.loss_info()
-    if tr.use_comm and tr.world > 1:
-        keys = sorted(info)
-        t = torch.tensor([info[k] for k in keys], dtype=torch.float32, device=tr.device)
-        tr.comm.allreduce_mean(t)
-        info = dict(zip(keys, t.tolist()))
+    info = tr.loss_info(reduce=True)           # mean over ranks (P:336)
     info.pop('loss', None)
     return state, info

@@ -1,10 +1,15 @@
 """train_step (pretrain/pretrain_model.py:306-340) + construct_train_state (pretrain/optimization.py:158-195) on top
-of the engine: one process per GPU; data parallelism = RCCL over xGMI through torch.distributed ("nccl" backend).
+of the engine: one process per GPU; data parallelism = RCCL over xGMI (merlot_reserve_amd/dist.py).
 
 Per step and rank:  plan (host) -> forward -> all-gather of the packed contrastive embeddings -> loss + dL/dE ->
-reduce-scatter of dL/dE_all -> backward (tower gradient buckets are all-reduced (mean, bf16, like pmean at :329) on a side
-stream as soon as the tower's backward finishes) -> fused nan_to_num + bf16 Adam + decay + schedule + apply.
+reduce-scatter of dL/dE_all -> backward, during which every finished gradient BUCKET (five for the stock models) is
+handed to a third stream: nan_to_num -> all-reduce(mean, bf16, like pmean at :329) -> fused bf16 Adam + decay + schedule +
+apply on that range of the flat buffers, while the main / side streams continue with the rest of backward.  With the
+library's RCCL communicator (dist.NativeComm) the collectives are ordinary stream-ordered launches, so the whole step,
+collectives included, is ONE hipGraph.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -60,12 +65,23 @@ class TrainState:
     # ---- the same update in pieces: per-step scalars in a device vector (so the launches can sit inside a hipGraph) and
     # one launch per finished range of the flat gradient buffer, overlapped with the rest of backward (trainer.Trainer)
     def prepare_step(self):
+        """Write this step's scalars into the device vector the captured Adam launches read: a ring of two pinned host
+        vectors, each rewritten only after the copy that last read it has completed, so the host may run ahead of the stream."""
+        dev = self.params.device
         if getattr(self, 'hyper', None) is None:
-            self.hyper = torch.zeros(4, dtype=torch.float32, device=self.params.device)
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._hyper_host = [torch.zeros(4, dtype=torch.float32, pin_memory=dev.type == 'cuda') for _ in range(2)]
+            self._hyper_ev, self._hyper_turn = [None, None], 0
+        i = self._hyper_turn
+        self._hyper_turn ^= 1
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()
         sched, neg_lr, bc1, bc2 = self._scalars()
-        # a fresh pageable source every step (like the plan's index lists): the runtime stages it before returning, so the
-        # host may run ahead of the stream without a later step's scalars overwriting an earlier step's pending copy
-        self.hyper.copy_(torch.tensor([sched, neg_lr, 1.0 / bc1, 1.0 / bc2], dtype=torch.float32), non_blocking=True)
+        self._hyper_host[i].copy_(torch.tensor([sched, neg_lr, 1.0 / bc1, 1.0 / bc2], dtype=torch.float32))
+        self.hyper.copy_(self._hyper_host[i], non_blocking=True)
+        if dev.type == 'cuda':
+            self._hyper_ev[i] = torch.cuda.Event()
+            self._hyper_ev[i].record()
 
     def apply_range(self, lo, hi):
         oc, p = self.opt_config, self.params
@@ -121,32 +137,44 @@ class Trainer:
         self.state = construct_train_state(config['optimizer'], self.params)
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
         self.comm = comm
-        tr_ = self.params.tower_ranges
-        a0_, a1_ = tr_['audio_encoder']
-        v0_, v1_ = tr_['vision_encoder']
-        assert a1_ == v0_ and v1_ == self.params.total
-        # the three ranges of the flat buffers whose gradients become final one backward stage after the other
-        self.ranges = [(0, a0_), (a0_, a1_), (v0_, v1_)]
-        # the collective path runs whenever a Comm is given -- also with a single rank, which is how the RCCL calls
+        # the collective path runs whenever a comm is given -- also with a single rank, which is how the RCCL calls
         # themselves are exercised on a 1-GPU box (tests/test_dist_gpu.py)
         assert world == 1 or comm is not None
         self.use_comm = comm is not None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self.graph = None
+        self._make_buckets()
         if self.use_comm:
             assert comm.world == world and comm.rank == rank
-            assert (B * self.engine.d.ntrg) % 8 == 0, 'world > 1 needs 8-aligned contrastive blocks (even B for the stock configs)'
             R, H = self.engine.R, self.engine.d.H
             z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)
             self.E_all, self.dE_all, self.dE_red = z(world, R, H), z(world, R, H), z(R, H)
-            # gradient buckets = the three backward stages' ranges of the flat buffer (params.py lays towers out in
-            # the order backward finishes them)
-            tr = self.params.tower_ranges
-            a0, a1 = tr['audio_encoder']
-            v0, v1 = tr['vision_encoder']
-            assert a1 == v0 and v1 == self.params.total
-            # two gradient buckets: [scales, head, span, joint, token] -- reduced while the audio and vision towers' backward
-            # runs (both towers concurrently, on the two streams, as in the single-rank step) -- and [audio, vision]
-            self.buckets = [self.params.grad[:a0], self.params.grad[a0:v1]]
-            self.bucket_ranges = [(0, a0), (a0, v1)]
+            self.metrics = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+    def _make_buckets(self):
+        """Gradient buckets = ranges of the flat buffers in the order backward makes them final (params.py lays the towers
+        out in that order, and a tower's layers in ascending order, which backward walks downwards):
+          'joint'   [scales, head, span, joint, token]        final after backward_stage_joint
+          'audio'   the audio tower                            final when the side stream's audio backward ends
+          ('vision', l)  vision layers >= l (+ final_ln, cls_proj, attention pool), down to the previous cut
+          'vision_end'   the rest of the vision tower (first layers, pre_ln, cls, patch embedding)
+        The vision tower (the last to finish) is cut at 2/3 and 1/3 of its depth, so only ~1/3 of its gradients -- < 10 % of
+        all gradient bytes for base and large -- is reduced after the last backward kernel."""
+        tr, offs, Lv = self.params.tower_ranges, self.params.offsets, self.engine.d.Lv
+        a0, a1 = tr['audio_encoder']
+        v0, v1 = tr['vision_encoder']
+        assert a1 == v0 and v1 == self.params.total
+        cuts = sorted({l for l in (Lv - Lv // 3, Lv - 2 * (Lv // 3)) if 0 < l < Lv}, reverse=True)
+        lo_of = lambda l: offs[f'vision_encoder/transformer/layer_{l:02d}/pre_attn_ln/scale'][0]
+        self.buckets = [('joint', 0, a0), ('audio', a0, a1)]
+        hi = v1
+        for l in cuts:
+            self.buckets.append((('vision', l), lo_of(l), hi))
+            hi = lo_of(l)
+        self.buckets.append(('vision_end', v0, hi))
+        self.vision_cuts = cuts
+        assert all(lo % 2048 == 0 and hi_ % 2048 == 0 and lo < hi_ for _, lo, hi_ in self.buckets)
+        assert sum(hi_ - lo for _, lo, hi_ in self.buckets) == self.params.total
 
     def plan(self, batch, draws=None):
         if draws is None:
@@ -154,95 +182,9 @@ class Trainer:
             draws = make_draws(self.config, self.B, seed=seed)
         return build_plan(batch, self.engine.d, draws[0], draws[1])
 
-    # ---- hipGraph path: the step is a fixed launch sequence over fixed buffers; capture it once, replay per step ----
-    def capture(self, batch):
-        """Capture forward / loss / backward into hipGraphs (split at the collectives when world > 1, which stay eager).
-        Call after at least one eager train_step (buffers and plan capacities exist)."""
-        eng, d = self.engine, self.engine.d
-        self.images_in = torch.zeros_like(batch['images'])
-        self.audio_in = torch.zeros_like(batch['audio_clips'])
-        eng.plan_frozen = True
-        torch.cuda.synchronize()
-        self.graphs = []
-        segs = [lambda: eng.forward_device(self.images_in, self.audio_in)]
-        if self.use_comm:
-            b = self.buckets
-            segs += [lambda: eng.loss_and_grad_outputs(self.E_all, self.dE_all),
-                     lambda: (ops.add_(eng.dE.view(-1), self.dE_red.view(-1)), eng.backward_stage_joint(), ops.nan_to_num_(b[0])),
-                     lambda: (self._backward_audio_vision(), ops.nan_to_num_(b[1]))]
-        else:
-            segs = [lambda: (eng.forward_device(self.images_in, self.audio_in), eng.loss_and_grad_outputs(), self._backward_and_update())]
-        pool = None
-        for fn in segs:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):     # RCCL's watchdog thread polls events meanwhile
-                fn()
-            pool = g.pool()
-            self.graphs.append(g)
-
-    def _backward_and_update(self):
-        """Single-rank backward with the optimizer folded in: each range of the flat buffers is updated as soon as its
-        gradients are final -- [scales, head, span, joint, token] on the side stream ahead of the audio tower's backward,
-        the audio range behind it (both beside the vision tower's backward on the main stream), the vision range last --
-        so only the last launch (27 % of the parameters) is exposed.  A later stage never reads an earlier range's weights."""
-        eng, st = self.engine, self.state
-        eng.backward_stage_joint()
-        main = torch.cuda.current_stream()
-        eng.side_stream.wait_stream(main)
-
-        def side_work():
-            st.apply_range(*self.ranges[0])
-            eng.backward_stage_audio()
-            st.apply_range(*self.ranges[1])
-        eng._on_side(side_work)
-        eng.backward_stage_vision()
-        st.apply_range(*self.ranges[2])
-        main.wait_stream(eng.side_stream)
-
-    def _backward_audio_vision(self):
-        """The audio tower's backward on the side stream beside the vision tower's on the main stream (fork / join)."""
+    # ---- the step as a launch sequence (eager, or captured once into a hipGraph and replayed) ----
+    def _loss_and_exchange(self):
         eng = self.engine
-        main = torch.cuda.current_stream()
-        eng.side_stream.wait_stream(main)
-        eng._on_side(eng.backward_stage_audio)
-        eng.backward_stage_vision()
-        main.wait_stream(eng.side_stream)
-
-    def train_step_graph(self, batch, plan):
-        eng = self.engine
-        self.state.prepare_step()
-        self.images_in.copy_(batch['images'], non_blocking=True)
-        self.audio_in.copy_(batch['audio_clips'], non_blocking=True)
-        eng.set_plan(plan)
-        if self.use_comm:
-            self.graphs[0].replay()
-            self.comm.gather_embeddings(eng.E, self.E_all)
-            self.graphs[1].replay()
-            self.comm.scatter_grad(self.dE_all, self.dE_red)
-            works = []
-            for k in range(2):       # bucket 0 is all-reduced (pretrain_model.py:329) while the audio / vision towers' backward runs
-                self.graphs[2 + k].replay()
-                works.append(self.comm.allreduce_mean_async(self.buckets[k]))
-            self._update_buckets(works)
-        else:
-            self.graphs[0].replay()
-        self.state.finish_step()
-        return eng.loss_acc
-
-    def _update_buckets(self, works):
-        """Every backward stage is already enqueued: wait for each bucket's all-reduce in turn and update its range while
-        the later buckets are still being reduced."""
-        for k, w in enumerate(works):
-            if w is not None:
-                w.wait()
-            self.state.apply_range(*self.bucket_ranges[k])
-
-    def train_step(self, batch, plan=None, draws=None):
-        eng = self.engine
-        if plan is None:
-            plan = self.plan(batch, draws)
-        self.state.prepare_step()
-        eng.forward(batch, plan=plan)
         if self.use_comm:
             self.comm.gather_embeddings(eng.E, self.E_all)                  # pretrain_model.py:290
             eng.loss_and_grad_outputs(self.E_all, self.dE_all)
@@ -250,17 +192,110 @@ class Trainer:
             ops.add_(eng.dE.view(-1), self.dE_red.view(-1))
         else:
             eng.loss_and_grad_outputs()
-        if self.use_comm:
-            works = []
-            for k, stage in enumerate((eng.backward_stage_joint, self._backward_audio_vision)):
-                stage()
-                ops.nan_to_num_(self.buckets[k])                            # pretrain_model.py:328, before the pmean
-                works.append(self.comm.allreduce_mean_async(self.buckets[k]))   # :329 (bf16, like the reference)
-            self._update_buckets(works)
-        else:
-            self._backward_and_update()
+
+    def _finish_bucket(self, key, producer, update):
+        """The bucket's gradients are final on stream `producer`: on the comm stream, behind them, nan_to_num + all-reduce
+        (pretrain_model.py:328-329) and the optimizer update of that range, while the producer goes on with backward.
+        Buckets are enqueued in ONE program order on ONE stream, the same on every rank, as RCCL requires."""
+        _, lo, hi = next(b for b in self.buckets if b[0] == key)
+        self.bucket_log.append(key)
+        cs = self.comm_stream
+        cs.wait_stream(producer)
+        with torch.cuda.stream(cs):
+            g = self.params.grad[lo:hi]
+            if self.use_comm:
+                ops.nan_to_num_(g)
+                self.comm.allreduce_mean(g)
+            if update:
+                self.state.apply_range(lo, hi)
+
+    def _backward_reduce_update(self, update=True):
+        eng = self.engine
+        main = torch.cuda.current_stream()
+        self.bucket_log = []
+        eng.backward_stage_joint()
+        self._finish_bucket('joint', main, update)
+        eng.side_stream.wait_stream(main)
+        eng._on_side(eng.backward_stage_audio)
+        audio_stream = main if os.environ.get('MR_NO_SIDE_STREAM') == '1' else eng.side_stream     # (A/B switch: issued in line)
+        pending = ['audio']                     # enqueued behind the first vision bucket: audio rarely ends before it
+
+        def layer_done(l):
+            if l in self.vision_cuts:
+                self._finish_bucket(('vision', l), main, update)
+                if pending:
+                    self._finish_bucket(pending.pop(), audio_stream, update)
+        eng.backward_stage_vision(layer_done=layer_done)
+        if pending:
+            self._finish_bucket(pending.pop(), audio_stream, update)
+        self._finish_bucket('vision_end', main, update)
+        main.wait_stream(eng.side_stream)
+        main.wait_stream(self.comm_stream)
+
+    def _program(self, images, audio):
+        self.engine.forward_device(images, audio)
+        self._loss_and_exchange()
+        self._backward_reduce_update(update=True)
+
+    # ---- pieces, for tests and for the reference-API adapter (eager) ----
+    def forward_and_loss(self, batch, plan=None, draws=None):
+        eng = self.engine
+        eng.forward(batch, plan=plan if plan is not None else self.plan(batch, draws))
+        self._loss_and_exchange()
+        return eng.loss_acc
+
+    def backward_and_reduce(self, update=True):
+        """Backward from the engine's current dE, bucket by bucket all-reduced; update=False leaves the averaged gradients in
+        params.grad and the parameters untouched."""
+        if update:
+            self.state.prepare_step()
+        self._backward_reduce_update(update=update)
+        if update:
+            self.state.finish_step()
+
+    def train_step(self, batch, plan=None, draws=None):
+        eng = self.engine
+        if plan is None:
+            plan = self.plan(batch, draws)
+        self.state.prepare_step()
+        eng.set_plan(plan)
+        self._program(batch['images'], batch['audio_clips'])
         self.state.finish_step()
         return eng.loss_acc
 
-    def loss_info(self):
-        return self.engine.loss_info()
+    # ---- hipGraph path: the step is a fixed launch sequence over fixed buffers; capture it once, replay per step ----
+    def capture(self, batch):
+        """Capture the WHOLE step -- forward, collectives, loss, backward, bucket reductions, optimizer -- into one hipGraph.
+        Call after at least one eager train_step (buffers, plan capacities and the communicator's lazy state exist).
+        A torch.distributed comm cannot be captured (its collectives are host-scheduled): such a trainer steps eagerly."""
+        assert not self.use_comm or self.comm.capturable, 'only the library RCCL communicator (dist.NativeComm) can be captured'
+        eng = self.engine
+        self.images_in = torch.zeros_like(batch['images'])
+        self.audio_in = torch.zeros_like(batch['audio_clips'])
+        eng.plan_frozen = True
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):      # other threads (RCCL proxies, torch's watchdog) may call HIP meanwhile
+            self._program(self.images_in, self.audio_in)
+        self.graph = g
+
+    def train_step_graph(self, batch, plan):
+        eng = self.engine
+        self.state.prepare_step()
+        self.images_in.copy_(batch['images'], non_blocking=True)
+        self.audio_in.copy_(batch['audio_clips'], non_blocking=True)
+        eng.set_plan(plan)
+        self.graph.replay()
+        self.state.finish_step()
+        return eng.loss_acc
+
+    def loss_info(self, reduce=True):
+        """Host dict of the last step's losses.  With a comm and reduce=True it is the mean over ranks, like the reference's
+        pmean of loss_info (pretrain_model.py:336) -- a COLLECTIVE: every rank must call it."""
+        info = self.engine.loss_info()
+        if self.use_comm and reduce and self.world > 1:
+            keys = sorted(info)
+            self.metrics[:len(keys)].copy_(torch.tensor([info[k] for k in keys], dtype=torch.float32))
+            self.comm.allreduce_mean_f32(self.metrics)
+            info = dict(zip(keys, self.metrics[:len(keys)].tolist()))
+        return info

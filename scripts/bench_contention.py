@@ -9,7 +9,7 @@ _lib.load()
 occ = C.CDLL(os.path.join(ROOT, 'scripts', 'micro', 'liboccupier.so'))
 occ.occupy.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p]
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
-ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+WS = torch.zeros(32 * 1024 * 1024, device=dev)
 side = torch.cuda.Stream()
 shapes = [(15424, 3072, 768), (15424, 768, 3072), (15424, 2304, 768)]
 for nb in [int(x) for x in sys.argv[1:]] or [0, 16, 32, 64]:
@@ -17,7 +17,7 @@ for nb in [int(x) for x in sys.argv[1:]] or [0, 16, 32, 64]:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16); b = torch.randn(k, n, device=dev).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
         for _ in range(3):
-            ops.gemm(a, b, c)
+            ops.gemm(a, b, c, ws=WS)
         torch.cuda.synchronize()
         if nb:
             occ.occupy(nb, 3000.0, sink.data_ptr(), side.cuda_stream)      # holds nb CUs for 3 ms
@@ -25,7 +25,7 @@ for nb in [int(x) for x in sys.argv[1:]] or [0, 16, 32, 64]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.gemm(a, b, c)
+            ops.gemm(a, b, c, ws=WS)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 100

@@ -3,7 +3,7 @@ import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
-ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+WS = torch.zeros(32 * 1024 * 1024, device=dev)
 M = 15424
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 shapes = [  # name, M, N, K, ta, tb
@@ -22,11 +22,11 @@ for name, m, n, k, ta, tb in shapes:
 for rnd in range(3):
     for name, (a, b, c, ta, tb, fl) in bufs.items():
         for _ in range(2):
-            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb))
+            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), ws=WS)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb))
+            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), ws=WS)
         e1.record()
         torch.cuda.synchronize()
         res.setdefault(name, []).append(fl * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12)

@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
-ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+WS = torch.zeros(32 * 1024 * 1024, device=dev)
 M = 15424
 H = int(os.environ.get('H', 768))
 shapes = [('fwd qkv', M, 3 * H, H, 0, 0), ('fwd proj', M, H, H, 0, 0), ('fwd mlp1', M, 4 * H, H, 0, 0), ('fwd mlp2', M, H, 4 * H, 0, 0),
@@ -22,13 +22,13 @@ for name, m, n, k, ta, tb in shapes:
         c = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
         sets.append((a, b, c))
     for a, b, c in sets:
-        ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb))
+        ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), ws=WS)
     best = 0
     for rnd in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for a, b, c in sets:
-            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb))
+            ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), ws=WS)
         e1.record()
         torch.cuda.synchronize()
         best = max(best, 2.0 * m * n * k * nset / (e0.elapsed_time(e1) * 1e-3) / 1e12)

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
-ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+WS = torch.zeros(32 * 1024 * 1024, device=dev)
 M, H = 15424, 768
 def run(name, m, n, k, tb, variants):
     per = (m * k + k * n + 3 * m * n) * 2
@@ -23,7 +23,7 @@ def run(name, m, n, k, tb, variants):
             k2 = {}
             for key, val in kw.items():
                 k2[key] = {'bias': bias, 'c2': c2, 'aux': x, 'residual': x, 'rot_tab': tab}.get(key, val) if val is True else val
-            ops.gemm(a, b, c, transB=bool(tb), **k2)
+            ops.gemm(a, b, c, transB=bool(tb), **k2, ws=WS)
         for s_ in sets:
             call(*s_)
         best = 1e9

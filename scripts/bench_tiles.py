@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops, _lib
 dev = torch.device('cuda:0')
-ops.GEMM_WORKSPACE = torch.zeros(64 * 1024 * 1024, device=dev)
+WS = torch.zeros(64 * 1024 * 1024, device=dev)
 specs = sys.argv[1:] or ['15424,768,768,0,0', '15424,768,768,0,1', '15424,768,3072,0,0', '15424,768,3072,0,1', '15424,768,2304,0,1',
                          '15424,3072,768,0,0', '15424,3072,768,0,1', '15424,2304,768,0,0', '5952,768,3072,0,1', '5952,768,768,0,0',
                          '5952,3072,768,0,0', '15424,1024,1024,0,0', '15424,1024,4096,0,1']
@@ -23,7 +23,7 @@ for spec in specs:
                 flush.add_(1.0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), residual=res if with_res else None)
+                ops.gemm(a, b, c, transA=bool(ta), transB=bool(tb), residual=res if with_res else None, ws=WS)
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
-ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+WS = torch.zeros(32 * 1024 * 1024, device=dev)
 samples = []
 stop = False
 def watch():
@@ -23,7 +23,7 @@ a = torch.randn(m, k, device=dev).to(torch.bfloat16); b = torch.randn(k, n, devi
 t0 = time.time()
 while time.time() - t0 < 4.0:
     for _ in range(50):
-        ops.gemm(a, b, c)
+        ops.gemm(a, b, c, ws=WS)
     torch.cuda.synchronize()
 t1 = time.time()
 time.sleep(1.0)

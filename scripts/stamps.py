@@ -3,15 +3,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
 ws = torch.zeros(32 * 1024 * 1024, device=dev)
-ops.GEMM_WORKSPACE = ws
+WS = ws
 m, n, k = [int(x) for x in sys.argv[1:4]]
 a = torch.randn(m, k, device=dev).to(torch.bfloat16); b = torch.randn(k, n, device=dev).to(torch.bfloat16)
 c = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
 bias = torch.randn(n, device=dev).to(torch.bfloat16)
 for _ in range(3):
-    ops.gemm(a, b, c, bias=bias)
+    ops.gemm(a, b, c, bias=bias, ws=WS)
 torch.cuda.synchronize(); ws.zero_(); torch.cuda.synchronize()
-ops.gemm(a, b, c, bias=bias)
+ops.gemm(a, b, c, bias=bias, ws=WS)
 torch.cuda.synchronize()
 st = ws.view(torch.int64)[:256 * 64 * 4].view(256, 64, 4).cpu()
 items = (st[:, :, 0] != 0).sum(1)

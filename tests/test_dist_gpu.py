@@ -1,7 +1,11 @@
-"""The data-parallel train step end to end with world_size 2: two processes (gloo) sharing the one GPU of the test box.
-Validates what the driver's multi-GPU bench runs (same Trainer code path, graph-replayed segments with the three
-collectives between them) except the RCCL transport itself: ranks see different batches, must report finite losses,
-and must hold IDENTICAL parameters after the averaged-gradient updates; the hipGraph path must match the eager path."""
+"""The data-parallel train step end to end.
+* world_size 2: two processes (gloo) sharing the one GPU of the test box -- the same Trainer program the multi-GPU bench
+  runs (all-gather of embeddings, reduce-scatter of their gradient, bucketed nan_to_num / all-reduce(mean) / optimizer on a
+  third stream during backward), eager because a torch.distributed comm cannot be captured: ranks see different batches,
+  must report finite losses, hold IDENTICAL parameters after the averaged-gradient updates, enqueue the buckets in the
+  documented order, and their reduced gradients must equal the mean of the oracle's per-rank gradients.
+* the RCCL transport itself: the library's communicator (mr_comm_*, dist.NativeComm) with one rank -- RCCL refuses two ranks
+  on one device --, eager and captured into ONE hipGraph together with the kernels."""
 import os
 
 import pytest
@@ -12,43 +16,42 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _cfg():
+    from merlot_reserve_amd.config import tiny_config
+    cfg = tiny_config(seq_len=80, lang_seq_len=40)
+    cfg['model']['vit_num_layers'] = 3          # two cuts inside the vision tower -> five gradient buckets, like base / large
+    cfg['optimizer'].update(num_warmup_steps=1, learning_rate=1e-3)
+    return cfg
+
+
+EXPECTED_BUCKETS = ['joint', ('vision', 2), 'audio', ('vision', 1), 'vision_end']
+
+
 def _worker(rank, world, port, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from merlot_reserve_amd.config import tiny_config
     from merlot_reserve_amd.dist import Comm
     from merlot_reserve_amd.synthetic import make_batch
     from merlot_reserve_amd.trainer import Trainer
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
-    cfg = tiny_config(seq_len=80, lang_seq_len=40)
-    cfg['optimizer'].update(num_warmup_steps=1, learning_rate=1e-3)
-    B = 8                                   # B * ntrg must be a multiple of 8 for world > 1
-    out = {}
-    for mode in ('eager', 'graph'):
-        tr = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=Comm())
-        batches = [make_batch(cfg, B, seed=100 + rank + 10 * i, device=dev) for i in range(3)]
-        losses = []
-        tr.train_step(batches[0], plan=tr.plan(batches[0]))
-        losses.append(tr.loss_info()['loss'])
-        if mode == 'graph':
-            tr.capture(batches[0])
-        for b in batches[1:]:
-            plan = tr.plan(b)
-            if mode == 'graph':
-                tr.train_step_graph(b, plan)
-            else:
-                tr.train_step(b, plan=plan)
-            losses.append(tr.loss_info()['loss'])
-        torch.cuda.synchronize()
-        master = tr.params.master.detach().cpu()
-        gathered = [torch.zeros_like(master) for _ in range(world)]
-        dist.all_gather(gathered, master)
-        out[mode] = (losses, bool(torch.equal(gathered[0], gathered[1])), master)
-    same = torch.allclose(out['eager'][2], out['graph'][2], rtol=0, atol=0)
-    ret[rank] = dict(eager=out['eager'][0], graph=out['graph'][0], replicas_equal=out['eager'][1] and out['graph'][1],
-                     graph_equals_eager=bool(same), finite=all(map(lambda v: v == v and abs(v) < 1e9, out['eager'][0] + out['graph'][0])))
+    cfg = _cfg()
+    B = 3                                   # odd: no alignment requirement on the per-rank contrastive blocks
+    tr = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=Comm())
+    batches = [make_batch(cfg, B, seed=100 + rank + 10 * i, device=dev) for i in range(3)]
+    local, reduced = [], []
+    for b in batches:
+        tr.train_step(b, plan=tr.plan(b))
+        local.append(tr.loss_info(reduce=False)['loss'])
+        reduced.append(tr.loss_info()['loss'])                  # collective: mean over ranks (pretrain_model.py:336)
+    torch.cuda.synchronize()
+    master = tr.params.master.detach().cpu()
+    gathered = [torch.zeros_like(master) for _ in range(world)]
+    dist.all_gather(gathered, master)
+    ret[rank] = dict(local=local, reduced=reduced, replicas_equal=bool(torch.equal(gathered[0], gathered[1])),
+                     finite=all(v == v and abs(v) < 1e9 for v in local + reduced), buckets=list(tr.bucket_log),
+                     step=tr.state.step)
     dist.destroy_process_group()
 
 
@@ -59,29 +62,95 @@ def test_two_rank_train_step_on_one_gpu(dev):
     port = 29600 + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
-    print(r0['eager'], r0['graph'], r1['eager'])
-    assert r0['finite'] and r1['finite']
+    print(r0['local'], r1['local'], r0['reduced'])
+    assert r0['finite'] and r1['finite'] and r0['step'] == r1['step'] == 3
     assert r0['replicas_equal'] and r1['replicas_equal'], 'ranks diverged: gradient averaging is broken'
-    assert r0['graph_equals_eager'] and r1['graph_equals_eager'], 'hipGraph replay differs from eager execution'
-    assert r0['eager'] != r1['eager'], 'ranks saw different batches, so per-rank losses must differ'
+    assert r0['local'] != r1['local'], 'ranks saw different batches, so per-rank losses must differ'
+    assert r0['reduced'] == r1['reduced'], 'loss_info must be averaged over ranks'
+    for a, b, m in zip(r0['local'], r1['local'], r0['reduced']):
+        assert abs(m - 0.5 * (a + b)) < 1e-5 * abs(m)
+    assert r0['buckets'] == r1['buckets'] == EXPECTED_BUCKETS, r0['buckets']
 
 
-def _nccl_single_rank(_i, port, ret):
+def _grad_worker(rank, world, port, ret):
+    """Both ranks: forward on their own batch, an injected per-rank upstream gradient dE_r (the loss gradient itself is
+    checked on well-conditioned embeddings in tests/test_pretrain_gpu.py), then the Trainer's backward + bucketed
+    nan_to_num / all-reduce(mean) WITHOUT the optimizer update, so params.grad holds what pmean returns
+    (pretrain/pretrain_model.py:328-329); compared with the mean over ranks of the oracle's autograd gradients."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from merlot_reserve_amd.dist import Comm
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from merlot_reserve_amd.trainer import Trainer
+    from oracle import ref_torch as R
+    from tests.test_pretrain_gpu import SECTIONS
+    from tests.util import oracle_batch, oracle_draws, tree_to
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-    from merlot_reserve_amd.config import tiny_config
-    from merlot_reserve_amd.dist import Comm
+    cfg = _cfg()
+    B = 3                                   # odd: the multi-rank path must not need 8-aligned contrastive blocks
+    tr = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=Comm())
+    batches = [make_batch(cfg, B, seed=200 + r, device=dev) for r in range(world)]
+    draws = [make_draws(cfg, B, seed=200 + r) for r in range(world)]
+    dEs = [(torch.randn(tr.engine.R, tr.engine.d.H, generator=torch.Generator().manual_seed(300 + r)) * 1e-2).to(torch.bfloat16)
+           for r in range(world)]
+    tr.forward_and_loss(batches[rank], tr.plan(batches[rank], draws[rank]))
+    tr.engine.dE.copy_(dEs[rank].to(dev))
+    tr.backward_and_reduce(update=False)
+    torch.cuda.synchronize()
+    gt = tr.params.grad_tree()
+    params = R.tree_map(lambda t: t.clone().requires_grad_(True), tree_to(tr.params.work_tree(), torch.float32))
+    total = 0.0
+    for r in range(world):
+        osp, oz = oracle_draws(*draws[r])
+        preds = R.pretrain_forward(params, cfg, oracle_batch(batches[r]), osp, oz)
+        for k, k2, name in SECTIONS:
+            o, n = tr.engine.sec[name]
+            total = total + (preds[k][k2] * dEs[r][o:o + n].float()).sum()
+    (total / world).backward()
+    leaves = [(n, t.grad if t.grad is not None else torch.zeros_like(t)) for n, t in R.tree_leaves(params)]
+    gmax = max(float(g.norm()) for _, g in leaves)
+    bad = []
+    for name, g in leaves:
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn, err = float(g.norm()), float((mine.double() - g.double()).norm())
+        cos = float((mine.double().flatten() @ g.double().flatten()) / (mine.double().norm() * g.double().norm() + 1e-30))
+        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+            bad.append((name, err, gn, cos))
+    flat = tr.params.grad.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ret[rank] = dict(bad=bad[:10], nleaves=len(leaves), replicas_equal=bool(torch.equal(gathered[0], gathered[1])))
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduced_gradients_match_oracle_mean(dev):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, 29900 + (os.getpid() % 1000), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r]['replicas_equal'], 'ranks hold different reduced gradients'
+        assert not ret[r]['bad'], ret[r]['bad']
+        assert ret[r]['nleaves'] > 50
+
+
+def _native_single_rank(_i, ret):
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    from merlot_reserve_amd.dist import NativeComm
     from merlot_reserve_amd.synthetic import make_batch
     from merlot_reserve_amd.trainer import Trainer
-    cfg = tiny_config(seq_len=80, lang_seq_len=40)
-    cfg['optimizer'].update(num_warmup_steps=1, learning_rate=1e-3)
-    B = 8
+    cfg = _cfg()
+    B = 3
     batches = [make_batch(cfg, B, seed=100 + 10 * i, device=dev) for i in range(3)]
     res = {}
-    for name, comm, graph in (('plain', None, False), ('rccl_eager', Comm(), False), ('rccl_graph', Comm(), True)):
+    for name, mk, graph in (('plain', lambda: None, False), ('plain_graph', lambda: None, True),
+                            ('rccl_eager', NativeComm, False), ('rccl_graph', NativeComm, True)):
+        comm = mk()
         tr = Trainer(cfg, B, dev, rank=0, world=1, seed=0, comm=comm)
         tr.train_step(batches[0], plan=tr.plan(batches[0]))
         losses = [tr.loss_info()['loss']]
@@ -92,25 +161,44 @@ def _nccl_single_rank(_i, port, ret):
             tr.train_step_graph(b, plan) if graph else tr.train_step(b, plan=plan)
             losses.append(tr.loss_info()['loss'])
         torch.cuda.synchronize()
-        res[name] = (losses, tr.params.master.detach().cpu())
+        res[name] = (losses, tr.params.master.detach().cpu(), list(tr.bucket_log))
+        if comm is not None:
+            comm.close()
     ret['losses'] = {k: v[0] for k, v in res.items()}
+    ret['buckets'] = res['rccl_graph'][2]
     ret['eager_equals_graph'] = bool(torch.equal(res['rccl_eager'][1], res['rccl_graph'][1]))
-    d = (res['plain'][1] - res['rccl_eager'][1]).abs().max().item()
-    ret['max_param_diff_vs_plain'] = d
-    dist.destroy_process_group()
+    ret['plain_eager_equals_graph'] = bool(torch.equal(res['plain'][1], res['plain_graph'][1]))
+    ret['max_param_diff_vs_plain'] = (res['plain'][1] - res['rccl_eager'][1]).abs().max().item()
+    # the collectives on their own: one rank, so gather = copy, reduce-scatter = copy, mean = identity
+    comm = NativeComm()
+    E = torch.randn(10, 64, device=dev).to(torch.bfloat16)
+    E_all, out = torch.zeros(1, 10, 64, dtype=torch.bfloat16, device=dev), torch.zeros(10, 64, dtype=torch.bfloat16, device=dev)
+    comm.gather_embeddings(E, E_all)
+    comm.scatter_grad(E_all, out)
+    flat, m = E.clone().view(-1), torch.arange(8, dtype=torch.float32, device=dev)
+    comm.allreduce_mean(flat)
+    comm.allreduce_mean_f32(m)
+    torch.cuda.synchronize()
+    ret['collectives_identity'] = bool(torch.equal(E_all[0], E) and torch.equal(out, E) and torch.equal(flat, E.view(-1))
+                                       and torch.equal(m.cpu(), torch.arange(8, dtype=torch.float32)))
+    comm.close()
 
 
 def test_rccl_collectives_single_rank(dev):
-    """The Trainer's collective path (all-gather of embeddings, reduce-scatter of their gradient, async bf16 AVG
-    all-reduce per gradient bucket, graph segments between them) on the REAL nccl/RCCL backend with one rank: the
-    transport calls, dtypes and stream ordering the multi-GPU bench uses, which gloo cannot cover."""
+    """The library's RCCL communicator (mr_comm_init / mr_allgather / mr_reducescatter_sum / mr_allreduce_mean_*: the calls,
+    dtypes and stream ordering the multi-GPU bench uses, which gloo cannot cover) with one rank: each collective alone, the
+    eager step, and the step captured -- collectives included -- into ONE hipGraph, which must reproduce the eager step
+    bit for bit."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_nccl_single_rank, args=(29700 + (os.getpid() % 1000), ret), nprocs=1, join=True)
+    mp.spawn(_native_single_rank, args=(ret,), nprocs=1, join=True)
     print(dict(ret))
     L = ret['losses']
     assert all(v == v and abs(v) < 1e9 for k in L for v in L[k])
-    assert ret['eager_equals_graph'], 'graph-segmented RCCL step differs from the eager RCCL step'
+    assert ret['collectives_identity']
+    assert ret['plain_eager_equals_graph'], 'hipGraph replay differs from eager execution'
+    assert ret['eager_equals_graph'], 'the captured RCCL step differs from the eager RCCL step'
+    assert ret['buckets'] == EXPECTED_BUCKETS
     # one rank: the gathered loss / averaged gradients equal the local ones up to the bf16 round trip of dE
     assert abs(L['plain'][-1] - L['rccl_eager'][-1]) < 2e-2 * abs(L['plain'][-1])
 

@@ -213,7 +213,10 @@ def ref_attention(qkv, code, nseq, S, nh):
 
 
 ATTN_CASES = [(3, 241, 2, False), (5, 31, 2, False), (2, 640, 3, True), (7, 16, 2, True), (2, 64, 1, False),
-              (1, 130, 12, True)]
+              (1, 130, 12, True),
+              # resolution-adaptation shapes (pretrain/train_fixres.py:78-90) at the large model's 16 heads: joint S = 1312
+              # (masked) and ViT S = 577 -- the regime where the reference recomputes attention (modeling.py:202,231)
+              (2, 1312, 16, True), (2, 577, 16, False)]
 
 
 @pytest.mark.parametrize('nseq,S,nh,masked', ATTN_CASES)
@@ -387,13 +390,17 @@ def test_unit_norm_scale(dev, ls):
     dy = rnd((rows, H), dev, seed=2)
     ref.backward(dy.float())
     dx = torch.zeros_like(x)
-    dls = torch.zeros(1, device=dev)
-    ops.unit_norm_scale_bwd(x, lsb, inv, dy, dx, dls)
+    dls = torch.full((1,), 123.0, device=dev)
+    part = torch.zeros((rows + 3) // 4, device=dev)
+    ops.unit_norm_scale_bwd(x, lsb, inv, dy, dx, dls, part)            # accumulate = False overwrites
     assert_close(dx, xr.grad, 6e-3, 'unit_norm dx')
     if ls < math.log(100.0):
         assert abs(dls.item() - lr.grad.item()) <= 2e-2 * abs(lr.grad.item()) + 1e-3
     else:
         assert dls.item() == 0.0
+    first = dls.clone()
+    ops.unit_norm_scale_bwd(x, lsb, inv, dy, dx, dls, part, accumulate=True)
+    assert dls.item() == 2 * first.item()                               # fixed-order sums: bitwise reproducible
 
 
 def test_contrastive_lse(dev):
@@ -410,7 +417,11 @@ def test_contrastive_lse(dev):
     loss = torch.zeros(1, device=dev)
     diag = torch.zeros(6, device=dev)
     work = logits.clone()
-    ops.contrastive_lse(work, off, coef, src, loss, diag)
+    rows = torch.zeros(L, device=dev)
+    ops.contrastive_lse(work, off, coef, src, loss, diag, rows)
+    loss2, diag2 = torch.zeros(1, device=dev), torch.zeros(6, device=dev)
+    ops.contrastive_lse(logits.clone(), off, coef, src, loss2, diag2, rows)
+    assert torch.equal(loss, loss2) and torch.equal(diag, diag2)        # no float atomics: bitwise reproducible
     assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item()) + 1e-6
     assert relerr(work, lr.grad) < 1e-4
     for i in range(3):
@@ -485,11 +496,11 @@ def tile_n(request):
 @pytest.mark.parametrize('M,N,K,ta,tb', GEMM256_CASES)
 def test_gemm256(dev, tile_n, M, N, K, ta, tb):
     from merlot_reserve_amd import ops
-    ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
+    ws = torch.zeros(32 * 1024 * 1024, device=dev)          # split-K partials (caller-owned, per call)
     a = rnd((K, M) if ta else (M, K), dev, seed=1)
     b = rnd((N, K) if tb else (K, N), dev, seed=2)
     out = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
-    ops.gemm(a, b, out, transA=ta, transB=tb)
+    ops.gemm(a, b, out, transA=ta, transB=tb, ws=ws)
     A = a.float().T if ta else a.float()
     B = b.float().T if tb else b.float()
     assert_close(out, A @ B, 3e-3, f'gemm256 {M}x{N}x{K} ta={ta} tb={tb}')
@@ -537,7 +548,6 @@ def test_gemm256_epilogues(dev, tile_n):
 def test_gemm_grouped(dev, group_tile):
     """Four wgrad-shaped problems in one persistent launch == four separate GEMMs (both tile widths of the shared launch)."""
     from merlot_reserve_amd import _lib, ops
-    ops.GEMM_WORKSPACE = torch.zeros(32 * 1024 * 1024, device=dev)
     _lib.check(_lib.load().mr_set_option(b'gemm_group_tile_n', group_tile), 'mr_set_option')
     Mtok, H = 1500, 512
     xs = [rnd((Mtok, 4 * H), dev, seed=1), rnd((Mtok, H), dev, seed=2), rnd((Mtok, H), dev, seed=3), rnd((Mtok, H), dev, seed=4)]

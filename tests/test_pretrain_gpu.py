@@ -251,29 +251,45 @@ def test_training_reduces_the_contrastive_loss(dev):
     assert tr.state.step == 101
 
 
-@pytest.mark.parametrize('model_name', ['base', 'large'])
-def test_base_size_forward_parity(dev, model_name):
-    """Full-size check (BASELINE config 2's / config 3's model, one record): the fp32 program against the fp32 oracle on the
+def _full_size_config(case):
+    """BASELINE configs 2-4 at full width and sequence length.  `*_resadapt` = pretrain/train_fixres.py:78-90 (grid 18x32:
+    ViT S = 577, joint S = 1312 -- at hidden 1024 the regime where the reference switches to jax.checkpoint attention,
+    mreserve/modeling.py:202,231).  `depth` caps the layers per tower (only for the large resadapt BACKWARD check, whose
+    full-depth autograd on the host would need ~60 GB); widths, heads, sequence lengths and batch structure stay."""
+    from merlot_reserve_amd.config import load_config, resadapt_config
+    name, _, variant = case.partition('_')
+    cfg = resadapt_config(name, grid=(18, 32)) if variant.startswith('resadapt') else load_config(name)
+    if variant.endswith('shallow'):
+        cfg['model'].update(vit_num_layers=3, joint_num_layers=3, audio_num_layers=2, span_num_layers=1)
+    return cfg
+
+
+@pytest.mark.parametrize('case', ['base', 'large', 'base_resadapt', 'large_resadapt'])
+def test_full_size_forward_parity(dev, case):
+    """Full-size check (BASELINE config 2 / 3 / 4 models, one record): the fp32 program against the fp32 oracle on the
     host cores (1e-3), and the bf16 training program against the fp32 program on the same weights rounded to bf16 (2e-2)."""
     import os
-    from merlot_reserve_amd.config import Dims, load_config
+    from merlot_reserve_amd.config import Dims
     from merlot_reserve_amd.engine import PretrainEngine
     from merlot_reserve_amd.params import ParamStore
     from merlot_reserve_amd.planner import build_plan
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from oracle import ref_torch as R
-    cfg = load_config(model_name)
+    cfg = _full_size_config(case)
     B = 1
     store = ParamStore(cfg, dev, seed=0, with_optimizer=False)
     store.load_tree(tree_to(store.work_tree(), torch.float32))          # master := bf16-representable values (both programs read the same numbers)
     batch16 = make_batch(cfg, B, seed=5, device=dev)
     batch32 = dict(batch16, images=batch16['images'].float(), audio_clips=batch16['audio_clips'].float())
     splits, z = make_draws(cfg, B, seed=5)
-    plan = build_plan(batch16, Dims(cfg, B), splits, z)
+    d = Dims(cfg, B)
+    if 'resadapt' in case:
+        assert (d.Sv, d.Sj) == (577, 1312)
+    plan = build_plan(batch16, d, splits, z)
     e32 = PretrainEngine(cfg, B, store, dev, dtype=torch.float32)
     e32.forward(batch32, plan=plan)
     e32.loss_and_grad_outputs()
-    out32 = {k: {k2: v.clone() for k2, v in d.items()} for k, d in e32.outputs().items()}
+    out32 = {k: {k2: v.clone() for k2, v in d_.items()} for k, d_ in e32.outputs().items()}
     loss32 = e32.loss_info()['loss']
     del e32
     torch.cuda.empty_cache()
@@ -294,22 +310,23 @@ def test_base_size_forward_parity(dev, model_name):
         e = relerr(out32[k][k2], preds[k][k2])
         assert e <= 1e-3, f'fp32 program vs oracle, {k}/{k2}: {e:.3e}'
     assert abs(loss32 - float(loss)) <= 1e-3 * abs(float(loss))
-    print(f'{model_name}-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
+    print(f'{case}-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
 
 
-def test_base_size_backward_parity(dev):
-    """Every parameter gradient of the FULL base model (one record) for an injected upstream gradient dE against autograd of
-    the oracle on the host cores: same tolerance as the tiny-configuration test (|d| <= 8e-2 |g| + 1.5e-2 max|g|, cos >=
-    0.995 on every leaf that carries gradient).  Exercises the 256-row GEMM tiles, grouped weight gradients and the long
-    sequences (241 / 640) that the tiny configuration cannot."""
+@pytest.mark.parametrize('case', ['base', 'large', 'base_resadapt', 'large_resadapt_shallow'])
+def test_full_size_backward_parity(dev, case):
+    """Every parameter gradient of the FULL-width model (one record) for an injected upstream gradient dE against autograd
+    of the oracle on the host cores: same tolerance as the tiny-configuration test (|d| <= 8e-2 |g| + 1.5e-2 max|g|, cos >=
+    0.995 on every leaf that carries gradient).  base / large: the 256-row GEMM tiles, grouped weight gradients (256 x 256
+    tiles for large, nh = 16) and sequences of 241 / 640; *_resadapt: the flash backward at S = 577 / 1312."""
     import os
-    from merlot_reserve_amd.config import Dims, load_config
+    from merlot_reserve_amd.config import Dims
     from merlot_reserve_amd.engine import PretrainEngine
     from merlot_reserve_amd.params import ParamStore
     from merlot_reserve_amd.planner import build_plan
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from oracle import ref_torch as R
-    cfg = load_config('base')
+    cfg = _full_size_config(case)
     B = 1
     store = ParamStore(cfg, dev, seed=0, with_optimizer=False)
     g = torch.Generator().manual_seed(2)
@@ -337,6 +354,7 @@ def test_base_size_backward_parity(dev):
     total.backward()
     gt = store.grad_tree()
     leaves = [(name, t.grad if t.grad is not None else torch.zeros_like(t)) for name, t in R.tree_leaves(params)]
+    del preds, total
     gmax = max(float(gr.norm()) for _, gr in leaves)
     bad, worst = [], (0.0, '')
     for name, gr in leaves:
@@ -349,7 +367,7 @@ def test_base_size_backward_parity(dev):
             worst = max(worst, (err / gn, name))
         if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
             bad.append((name, err, gn, cos))
-    print(f'base-size backward parity: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]})')
+    print(f'{case} backward parity: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]})')
     assert not bad, bad[:10]
 
 

@@ -151,20 +151,23 @@ def test_graph_replay_matches_eager(dev):
     assert model_a.engine.loss_info() == model_b.engine.loss_info()
 
 
-def test_vcr_base_size_forward_backward(dev):
-    """The VCR step at the reference's shapes (base model, image grid 18x32 -> ViT S = 577, answers [B, 2, 4, 144], joint
-    [8B, 288]; B = 1): logits and every gradient leaf (injected dL/dlogits) against the oracle on the host cores."""
+@pytest.mark.parametrize('model_name', ['base', 'large'])
+def test_vcr_full_size_forward_backward(dev, model_name):
+    """The VCR step at the reference's shapes (base / large model -- BASELINE config 5 is the large one --, image grid 18x32
+    -> ViT S = 577, answers [B, 2, 4, 144], joint [8B, 288]; B = 1): logits and every gradient leaf (injected dL/dlogits)
+    against the oracle on the host cores."""
     import os
     from merlot_reserve_amd import finetune as F
     from merlot_reserve_amd.config import load_config
-    cfg = load_config('base')
+    cfg = load_config(model_name)
+    H = cfg['model']['hidden_size']
     cfg['model']['output_grid'] = [18, 32]
     cfg['data'].update(lang_seq_len=144, num_answers=4)
     model = F.MerlotReserveVCR.from_config(cfg, device=dev, seed=0)
     batch = F.make_vcr_batch(cfg, 1, seed=0, device=dev)
     params = model.init_from_dummy_batch(batch)
     g = torch.Generator().manual_seed(1)
-    params['proj']['kernel'] = torch.randn(768, 1, generator=g) * 0.3
+    params['proj']['kernel'] = torch.randn(H, 1, generator=g) * 0.3
     logits = model.apply({'params': params}, batch)
     eng, store = model.engine, model.params_store
     eng.loss_and_grad_logits()
@@ -191,5 +194,5 @@ def test_vcr_base_size_forward_backward(dev):
         cos = float((mine.double().flatten() @ gr.double().flatten()) / (mine.double().norm() * gr.double().norm() + 1e-30))
         if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
             bad.append((name, err, gn, cos))
-    print(f'VCR base-size parity: logits rel err {e:.2e}, {len(leaves)} gradient leaves checked')
+    print(f'VCR {model_name}-size parity: logits rel err {e:.2e}, {len(leaves)} gradient leaves checked')
     assert not bad, bad[:10]
