@@ -208,6 +208,7 @@ def main():
         fl_x = sum(r[2] for r in ops.GEMM_PROFILE)
         breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in ops.FAMILY_PROFILE.items()}
         launches = {k: len(v) // nprof for k, v in ops.FAMILY_PROFILE.items()}
+        breakdown['gemm'], launches['gemm'] = round(ms_x / nprof, 3), len(ops.GEMM_PROFILE) // nprof
         ops.GEMM_PROFILE, ops.FAMILY_PROFILE = None, None
         del os.environ['MR_NO_SIDE_STREAM']
         breakdown = {'ms_per_step': breakdown, 'launches_per_step': launches, 'sum_ms': round(sum(breakdown.values()), 3),

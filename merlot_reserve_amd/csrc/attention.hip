@@ -15,11 +15,32 @@
 //
 // Pipeline: a wave owns 16*QB queries (keys in the dK/dV kernel); the K/V (Q/dO) tiles of the inner loop are double
 // buffered in LDS: the next tile's global loads are issued into registers before the current tile is multiplied and
-// written to the other buffer afterwards -- one barrier per tile, global latency under the MFMAs.  Softmax runs in the
-// exp2 domain (scores pre-multiplied by log2 e); the additive -1e10 bias and tile tails are folded into a staged
-// per-key code tile (-2 = beyond the sequence).
+// written to the other buffer afterwards -- one barrier per tile, global latency under the MFMAs.
+//
+// Per-score vector work of the BACKWARD kernels (~10 vector instructions per score against 1/16 of an MFMA):
+//   * the 1/8 of "query / sqrt(depth)" is folded into the Q (dQ) or K (dK/dV) fragments once per workgroup --
+//     exact in bf16 -- so the MFMA result IS the reference's score;
+//   * p = exp2(fma(s, log2 e, -m log2 e)): one FMA + one exponential per score;
+//   * the additive bias is one compare + add + select against a staged per-key pair (code, bias-if-not-allowed);
+//   * delta = rowsum(dO * O) is computed by the dQ kernel from the fragments it holds anyway (no separate pass).
+// The reference's bias for a disallowed pair is -1e10 (modeling.py:353-356), whose only observable effects in fp32 are
+// (a) weight exactly 0 for a disallowed key of a row that has an allowed key and (b) a UNIFORM softmax over all S keys for
+// a row with no allowed key (a PAD query: every score rounds to the same -1e10).  Both are kept exactly with the bias
+// constant -2^33 in the backward kernels (bias * log2 e is exact; a PAD row is recognised by its LSE < PAD_LSE and given
+// P = 1/S); the forward keeps the literal -1e10 (in the exp2 domain), for which every score of a PAD row is the same number.
 #include <stdlib.h>
 #include "mr_common.h"
+
+// timing-only diagnostic builds (scripts/build_diag.sh; wrong results): -DMR_ATTN_DIAG_NOLOAD keeps re-using the first K / V
+// tile (no global loads, no LDS refills in the loop); -DMR_ATTN_OCC=n sets the waves per SIMD the register allocator targets
+#ifndef MR_ATTN_OCC
+#define MR_ATTN_OCC 2
+#endif
+#ifdef MR_ATTN_DIAG_NOLOAD
+#define MR_ATTN_MORE(cond) false
+#else
+#define MR_ATTN_MORE(cond) (cond)
+#endif
 
 namespace {
 
@@ -27,9 +48,10 @@ constexpr int TK = 64;        // inner tile (keys in fwd / dQ, queries in dK/dV)
 constexpr int LDR = 72;       // row-read-only tile stride (elements): 144 B
 constexpr int LDV = 80;       // tiles that are tr-read: 160 B rows (8 rows x 32 B tile the 64 banks)
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-constexpr float SCALE2 = 0.125f * LOG2E;           // 1/sqrt(64) in the exp2 domain
-constexpr float NEG_BIG2 = -1e10f * LOG2E;         // the reference's -1e10 bias, exp2 domain
-constexpr int CODE_NONE = -2;                      // key / query beyond the sequence
+constexpr float NEG_BIAS = -8589934592.0f;         // -2^33: stands in for the reference's -1e10 bias (see above)
+constexpr float PAD_LSE = 0.25f * NEG_BIAS;        // an LSE below this marks a row with no allowed key
+constexpr int CODE_NONE = -2;                      // key beyond the sequence
+constexpr int CODE_PADQ = -3;                      // query with no allowed key (PAD, or beyond the sequence): matches no key code
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -75,12 +97,24 @@ __device__ __forceinline__ void tile_store(__bf16* tile, int tld, int tid, const
     }
 }
 
-// exp2-domain score with the bias semantics of modeling.py:353-356; ck == CODE_NONE: key does not exist
-template <bool MASKED>
-__device__ __forceinline__ float biased2(float raw, int cq, int ck) {
-    float s = raw * SCALE2;
-    if (MASKED && !(cq == ck && cq >= 0)) s += NEG_BIG2;
-    return (ck == CODE_NONE) ? -INFINITY : s;
+// per-key metadata of tile position k: its code and the bias a query with a DIFFERENT code adds to the score
+__device__ __forceinline__ void key_meta(int64_t k, int64_t S, const int32_t* __restrict__ code_seq, bool masked, int& c, float& nb) {
+    if (k < S) { c = masked ? code_seq[k] : 0; nb = NEG_BIAS; }
+    else { c = CODE_NONE; nb = -INFINITY; }
+}
+
+// fragment * 2^-3: the query / sqrt(depth) of flax's dot_product_attention_weights (exact in bf16)
+__device__ __forceinline__ bf16x8 scale_eighth(u32x4 raw) {
+    bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * 0.125f);
+    return v;
+}
+
+// s[r] = allowed ? s[r] : s[r] + nk[r]   (allowed = the key's code equals the query's; see the header for the constants)
+__device__ __forceinline__ void add_bias(f32x4& s, const i32x4& ck, const f32x4& nk, int cq) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = (ck[r] == cq) ? s[r] : s[r] + nk[r];
 }
 
 // XCD-aware block order.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, so with the plain
@@ -100,9 +134,22 @@ __device__ __forceinline__ AttnBlock attn_block(int nblk, int nh) {
     return a;
 }
 
+// ---- forward: scores in the exp2 domain (pre-multiplied by log2 e / 8) with the reference's literal -1e10 bias.  (A forward
+// with the backward kernels' cheaper per-score sequence -- 1/8 folded into Q, FMA + exp2, compare/add/select bias, rescale
+// only when a maximum moved -- measured the same on the masked joint sequences and 9-30 % SLOWER on the short unmasked ones,
+// where its extra registers cost a wave per SIMD: kept as it was.)
+constexpr float SCALE2 = 0.125f * LOG2E;           // 1/sqrt(64) in the exp2 domain
+constexpr float NEG_BIG2 = -1e10f * LOG2E;         // the reference's -1e10 bias, exp2 domain
+template <bool MASKED>
+__device__ __forceinline__ float biased2(float raw, int cq, int ck) {
+    float s = raw * SCALE2;
+    if (MASKED && !(cq == ck && cq >= 0)) s += NEG_BIG2;
+    return (ck == CODE_NONE) ? -INFINITY : s;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int QB, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                           __bf16* __restrict__ out, float* __restrict__ lse,
                                                           int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDR];
@@ -154,8 +201,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restri
 
     const int nt = (int)((S + TK - 1) / TK);
     for (int t = 0; t < nt; ++t) {
+#ifdef MR_ATTN_DIAG_NOLOAD
+        const int b = 0;
+#else
         const int b = t & 1;
-        if (t + 1 < nt) {      // next tile: global -> registers, in flight during this tile's MFMAs
+#endif
+        if (MR_ATTN_MORE(t + 1 < nt)) {      // next tile: global -> registers, in flight during this tile's MFMAs
             tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
             tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
             if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
@@ -214,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restri
                 for (int qb = 0; qb < QB; ++qb)
                     ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][t2], ot[qb][db], 0, 0, 0);
             }
-        if (t + 1 < nt) {      // the other buffer was last read one iteration ago, behind that iteration's barrier
+        if (MR_ATTN_MORE(t + 1 < nt)) {      // the other buffer was last read one iteration ago, behind that iteration's barrier
             tile_store(Ks[b ^ 1], LDR, tid, kr);
             tile_store(Vs[b ^ 1], LDV, tid, vr);
             if (tid < TK) Cs[b ^ 1][tid] = cr;
@@ -241,66 +292,67 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const __bf16* __restri
     }
 }
 
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-__global__ void attn_delta_kernel(const __bf16* __restrict__ o, const __bf16* __restrict__ dout, float* __restrict__ delta,
-                                  int64_t rows, int64_t S, int64_t nh) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int64_t H = nh * 64, seq = row / S, s = row % S;
-    for (int64_t c = lane; c < H / 8; c += 64) {
-        float a[8], b[8];
-        unpack8(*reinterpret_cast<const u32x4*>(o + row * H + 8 * c), a);
-        unpack8(*reinterpret_cast<const u32x4*>(dout + row * H + 8 * c), b);
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += a[e] * b[e];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if ((lane & 7) == 0) delta[(seq * nh + c / 8) * S + s] = acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ dQ
+// ------------------------------------------------------------------------------------------------ dQ (+ delta = rowsum(dO * O))
 template <int QB, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
-                                                             const __bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             const float* __restrict__ delta, __bf16* __restrict__ dqkv,
-                                                             const float* __restrict__ rot_tab, int64_t rot_rows,
-                                                             int64_t S, int64_t nh) {
+__global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+                                                             const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ delta,
+                                                             __bf16* __restrict__ dqkv, const float* __restrict__ rot_tab,
+                                                             int64_t rot_rows, int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDV];   // row reads (S^T) and tr reads (dQ^T)
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDR];   // row reads (dP^T)
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
+    __shared__ __attribute__((aligned(16))) float Ns[2][TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
     const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
+    const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
 
     bf16x8 qf[QB][2], dof[QB][2];
     int64_t qi[QB];
     int cq[QB];
-    float lse2[QB], del[QB];
+    float nlse2[QB], del[QB];
+    bool padq[QB];
+    bool any_pad = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         qi[qb] = q0 + (wave * QB + qb) * 16 + i;
         const bool ok = qi[qb] < S;
+        float dsum = 0.f;
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
-            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u}, x = {0u, 0u, 0u, 0u};
             if (ok) {
                 v = *reinterpret_cast<const u32x4*>(base + qi[qb] * ld + h * 64 + dd * 32 + g * 8);
                 w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
+                x = *reinterpret_cast<const u32x4*>(o + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
             }
-            qf[qb][dd] = __builtin_bit_cast(bf16x8, v);
+            qf[qb][dd] = scale_eighth(v);             // the TRUE q also for PAD rows: the reference differentiates through them
             dof[qb][dd] = __builtin_bit_cast(bf16x8, w);
+            float a[8], bb[8];
+            unpack8(w, a);
+            unpack8(x, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum += a[e] * bb[e];
         }
-        cq[qb] = (MASKED && ok) ? code[seq * S + qi[qb]] : 0;
-        lse2[qb] = ok ? lse[(seq * nh + h) * S + qi[qb]] * LOG2E : 0.f;
-        del[qb] = ok ? delta[(seq * nh + h) * S + qi[qb]] : 0.f;
+        dsum += __shfl_xor(dsum, 16, 64);             // the 4 lanes of a query hold 16 of its 64 dims each
+        dsum += __shfl_xor(dsum, 32, 64);
+        del[qb] = dsum;
+        if (ok && g == 0) delta[(seq * nh + h) * S + qi[qb]] = dsum;        // for the dK / dV kernel, launched behind this one
+        int c = ok ? (MASKED ? code_seq[qi[qb]] : 0) : CODE_PADQ;
+        if (c < 0) c = CODE_PADQ;
+        cq[qb] = c;
+        const float L = ok ? lse[(seq * nh + h) * S + qi[qb]] : INFINITY;   // beyond the sequence: p = exp2(-inf) = 0
+        // a query row with no allowed key (PAD): the softmax is uniform over the S keys and its LSE is not representable:
+        // take P = 1/S instead of exp(s - lse)
+        padq[qb] = MASKED && ok && L < PAD_LSE;
+        any_pad = any_pad || padq[qb];
+        nlse2[qb] = -L * LOG2E;
     }
+    const bool wave_pad = MASKED && __any(any_pad);
     f32x4 dq[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -309,45 +361,58 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
 
     const __bf16* Kg = base + H + h * 64;
     const __bf16* Vg = base + 2 * H + h * 64;
-    auto key_code = [&](int64_t k) -> int { return (k < S) ? (MASKED ? code[seq * S + k] : 0) : CODE_NONE; };
     TileRegs kr, vr;
     int cr = 0;
+    float nr = 0.f;
     tile_load(Kg, ld, 0, S, tid, kr);
     tile_load(Vg, ld, 0, S, tid, vr);
-    if (tid < TK) cr = key_code(tid);
+    if (tid < TK) key_meta(tid, S, code_seq, MASKED, cr, nr);
     tile_store(Ks[0], LDV, tid, kr);
     tile_store(Vs[0], LDR, tid, vr);
-    if (tid < TK) Cs[0][tid] = cr;
+    if (tid < TK) { Cs[0][tid] = cr; Ns[0][tid] = nr; }
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
+    const bool ragged = (S & (TK - 1)) != 0;
     for (int t = 0; t < nt; ++t) {
+#ifdef MR_ATTN_DIAG_NOLOAD
+        const int b = 0;
+#else
         const int b = t & 1;
-        if (t + 1 < nt) {
+#endif
+        if (MR_ATTN_MORE(t + 1 < nt)) {
             tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
             tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
-            if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
+            if (tid < TK) key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
         }
+        const bool need_bias = MASKED || (ragged && t == nt - 1);
         f32x4 ds[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const bf16x8 k0 = row_frag(Ks[b], LDV, kb * 16, 0, lane), k1 = row_frag(Ks[b], LDV, kb * 16, 1, lane);
             const bf16x8 v0 = row_frag(Vs[b], LDR, kb * 16, 0, lane), v1 = row_frag(Vs[b], LDR, kb * 16, 1, lane);
-            const i32x4 ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+            i32x4 ck = {0, 0, 0, 0};
+            f32x4 nk = {0.f, 0.f, 0.f, 0.f};
+            if (need_bias) {
+                ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+                nk = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
+            }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], st, 0, 0, 0);
                 f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp, 0, 0, 0);
+                if (need_bias) add_bias(st, ck, nk, cq[qb]);
+                f32x4 pv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(biased2<MASKED>(st[r], cq[qb], ck[r]) - lse2[qb]);
-                    // a query row with no allowed key (PAD): every score is exactly -1e10, the softmax is uniform over the
-                    // S keys, and its LSE (-1e10 + ln S) is not representable in fp32: take P = 1/S instead of exp(s - lse)
-                    if (MASKED && lse2[qb] < 0.5f * NEG_BIG2) pv = (ck[r] == CODE_NONE) ? 0.f : inv_S;
-                    ds[qb][kb][r] = pv * (dp[r] - del[qb]);
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, nlse2[qb]));
+                if (wave_pad) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = padq[qb] ? ((ck[r] == CODE_NONE) ? 0.f : inv_S) : pv[r];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[qb][kb][r] = pv[r] * (dp[r] - del[qb]);
             }
         }
         bf16x8 dsf[QB][2];
@@ -365,10 +430,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
                 for (int qb = 0; qb < QB; ++qb)
                     dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][t2], dq[qb][db], 0, 0, 0);
             }
-        if (t + 1 < nt) {
+        if (MR_ATTN_MORE(t + 1 < nt)) {
             tile_store(Ks[b ^ 1], LDV, tid, kr);
             tile_store(Vs[b ^ 1], LDR, tid, vr);
-            if (tid < TK) Cs[b ^ 1][tid] = cr;
+            if (tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
         }
         __syncthreads();
     }
@@ -392,26 +457,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const __bf16* __res
 // ------------------------------------------------------------------------------------------------ dK, dV
 // Block owns 64*KB keys (wave: 16*KB).  Here scores are NOT transposed (S = Q . K^T: column = key on the lane, 4 queries
 // per 16-query block in the registers), so P and dS are the B operands of dV^T = dO^T . P and dK^T = Q^T . dS.
+// Per query of the streamed tile the staging threads provide: -lse * log2 e (-inf beyond the sequence: p = 0), delta, the
+// code (CODE_PADQ for a row without allowed key) and, for such rows, the uniform weight 1/S.
 template <int KB, bool MASKED>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                               const __bf16* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, __bf16* __restrict__ dqkv,
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
                                                               int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TK * LDV];    // row reads (S) and tr reads (dK^T)
     __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TK * LDV];    // dO: row reads (dP) and tr reads (dV^T)
-    __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK];
+    __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
+    __shared__ int32_t Fs[2];                                          // tile has a row without allowed key
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
     const int64_t seq = ab_.seq, h = ab_.h, kbase = ab_.blk * (64 * KB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
+    const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
 
     bf16x8 kf[KB][2], vf[KB][2];
     int64_t ki[KB];
     int ck[KB];
+    float nkl[KB], unil[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         ki[kb] = kbase + (wave * KB + kb) * 16 + i;
@@ -423,10 +493,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
                 v = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
                 w = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
             }
-            kf[kb][dd] = __builtin_bit_cast(bf16x8, v);
+            kf[kb][dd] = scale_eighth(v);             // (q . k) / 8 = q . (k / 8): exact
             vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
         }
-        ck[kb] = ok ? (MASKED ? code[seq * S + ki[kb]] : 0) : CODE_NONE;
+        ck[kb] = ok ? (MASKED ? code_seq[ki[kb]] : 0) : CODE_NONE;
+        nkl[kb] = ok ? NEG_BIAS : -INFINITY;
+        unil[kb] = ok ? 1.0f : 0.0f;
     }
     f32x4 dk[KB][4], dv[KB][4];
 #pragma unroll
@@ -439,14 +511,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
     const float* Lg = lse + (seq * nh + h) * S;
     const float* Eg = delta + (seq * nh + h) * S;
     TileRegs qr, dr;
-    float lr = 0.f, er = 0.f;
-    int cr = 0;
-    auto side_load = [&](int64_t q0) {
+    float lr = 0.f, er = 0.f, ur = 0.f;
+    int cr = 0, fr = 0;
+    auto side_load = [&](int64_t q0) {        // wave 0 (tid < TK) stages the 64 queries' scalars
         if (tid < TK) {
             const bool ok = q0 + tid < S;
-            lr = ok ? Lg[q0 + tid] * LOG2E : 0.f;
+            const float L = ok ? Lg[q0 + tid] : INFINITY;
+            const bool pad = MASKED && ok && L < PAD_LSE;
+            lr = -L * LOG2E;
             er = ok ? Eg[q0 + tid] : 0.f;
-            cr = ok ? (MASKED ? code[seq * S + q0 + tid] : 0) : CODE_NONE;
+            int c = ok ? (MASKED ? code_seq[q0 + tid] : 0) : CODE_PADQ;
+            cr = (c < 0) ? CODE_PADQ : c;
+            ur = pad ? inv_S : 0.f;
+            fr = MASKED ? (int)__any(pad) : 0;
         }
     };
     tile_load(Qg, ld, 0, S, tid, qr);
@@ -454,63 +531,86 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const __bf16* __re
     side_load(0);
     tile_store(Qs[0], LDV, tid, qr);
     tile_store(Ds[0], LDV, tid, dr);
-    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; }
+    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; Us[0][tid] = ur; if (tid == 0) Fs[0] = fr; }
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
     for (int t = 0; t < nt; ++t) {
+#ifdef MR_ATTN_DIAG_NOLOAD
+        const int b = 0;
+#else
         const int b = t & 1;
-        if (t + 1 < nt) {
+#endif
+        if (MR_ATTN_MORE(t + 1 < nt)) {
             tile_load(Qg, ld, (int64_t)(t + 1) * TK, S, tid, qr);
             tile_load(Dg, H, (int64_t)(t + 1) * TK, S, tid, dr);
             side_load((int64_t)(t + 1) * TK);
         }
-        f32x4 pp[KB][4], ds[KB][4];
+        const bool tile_pad = MASKED && Fs[b] != 0;
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            const bf16x8 q0f = row_frag(Qs[b], LDV, qb * 16, 0, lane), q1f = row_frag(Qs[b], LDV, qb * 16, 1, lane);
-            const bf16x8 d0f = row_frag(Ds[b], LDV, qb * 16, 0, lane), d1f = row_frag(Ds[b], LDV, qb * 16, 1, lane);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
-            const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
-            const i32x4 c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x4 pp[KB][2], ds[KB][2];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
-                f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qb = 2 * t2 + q2;
+                const bf16x8 q0f = row_frag(Qs[b], LDV, qb * 16, 0, lane), q1f = row_frag(Qs[b], LDV, qb * 16, 1, lane);
+                const bf16x8 d0f = row_frag(Ds[b], LDV, qb * 16, 0, lane), d1f = row_frag(Ds[b], LDV, qb * 16, 1, lane);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
+                i32x4 c4 = {0, 0, 0, 0};
+                if (MASKED) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+                f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
+                if (tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // query side code c4[r] (CODE_NONE: query beyond S -> p = 0), key side ck[kb]
-                    float s = st[r] * SCALE2;
-                    if (MASKED && !(c4[r] == ck[kb] && ck[kb] >= 0)) s += NEG_BIG2;
-                    float pv = (c4[r] == CODE_NONE || ck[kb] == CODE_NONE) ? 0.f : __builtin_amdgcn_exp2f(s - l4[r]);
-                    if (MASKED && l4[r] < 0.5f * NEG_BIG2 && c4[r] != CODE_NONE && ck[kb] != CODE_NONE) pv = inv_S;   // PAD query row: uniform
-                    pp[kb][qb][r] = pv;
-                    ds[kb][qb][r] = pv * (dp[r] - e4[r]);
+                for (int kb = 0; kb < KB; ++kb) {
+                    f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
+                    f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
+                    f32x4 pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // allowed = same code (a PAD key's -1 and a missing key's -2 equal no query code; unmasked: codes are 0,
+                        // missing keys -2, missing queries have l4 = -inf)
+                        const float s = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E, l4[r]));
+                    }
+                    if (tile_pad) {       // rows without allowed key: uniform over the existing keys
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = (u4[r] > 0.f) ? u4[r] * unil[kb] : pv[r];
+                    }
+                    pp[kb][q2] = pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[kb][q2][r] = pv[r] * (dp[r] - e4[r]);
                 }
             }
-        }
+            // this half-tile's P and dS (32 queries) go straight into dV^T / dK^T: only one half's fragments are ever live
+            bf16x8 pf[KB], dsf[KB];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int kb = 0; kb < KB; ++kb) {
+                pf[kb] = pack_acc_pair(pp[kb][0], pp[kb][1]);
+                dsf[kb] = pack_acc_pair(ds[kb][0], ds[kb][1]);
+            }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const bf16x8 dot = tr_frag(Ds[b], LDV, 32 * t2, 16 * db, lane);
                 const bf16x8 qt = tr_frag(Qs[b], LDV, 32 * t2, 16 * db, lane);
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pack_acc_pair(pp[kb][2 * t2], pp[kb][2 * t2 + 1]), dv[kb][db], 0, 0, 0);
-                    dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pack_acc_pair(ds[kb][2 * t2], ds[kb][2 * t2 + 1]), dk[kb][db], 0, 0, 0);
+                    dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], dv[kb][db], 0, 0, 0);
+                    dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[kb][db], 0, 0, 0);
                 }
             }
-        if (t + 1 < nt) {
+        }
+        if (MR_ATTN_MORE(t + 1 < nt)) {
             tile_store(Qs[b ^ 1], LDV, tid, qr);
             tile_store(Ds[b ^ 1], LDV, tid, dr);
-            if (tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; }
+            if (tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) Fs[b ^ 1] = fr; }
         }
         __syncthreads();
     }
-    // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores
+    // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores.  dK: the 1/8 folded into kf was on the OTHER operand
+    // of S = q . (k/8), so d(score)/dk = q / 8 still has to be applied here.
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (ki[kb] < S) {
@@ -568,16 +668,14 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     MR_CHECK_ARG(nseq <= 65535 && nh <= 65535, "mr_attention_bwd: nseq / nh exceed grid limits");
     MR_CHECK_ARG(!rot_tab || rot_rows > 0, "mr_attention_bwd: rot_rows must be > 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t rows = nseq * S;
     const __bf16* q = static_cast<const __bf16*>(qkv);
     const __bf16* d = static_cast<const __bf16*>(dout);
     __bf16* g = static_cast<__bf16*>(dqkv);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                       static_cast<const __bf16*>(out), d, delta, rows, S, nh);
+    const __bf16* oo = static_cast<const __bf16*>(out);       // delta = rowsum(dO * O) is computed by the dQ kernel (for itself and for dK / dV)
     const bool two = S > attn_qb_threshold();
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, oo, d, lse, delta, g, \
                            rot_tab, rot_rows, S, nh);                                                                         \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
                            rot_tab, rot_rows, S, nh);                                                                         \

@@ -536,6 +536,46 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     #pragma unroll
                     for (int j = 0; j < NJ; ++j) pbias[j] = u32x2{0u, 0u};
                 }
+                // 256 / 192-wide tiles (no registers to park epilogue operands in during the k-loop): the WHOLE residual / aux
+                // tile is requested here, before the first row block is finished, in the 16-byte layout of the widened stores
+                // (the fragment registers are dead by now) -- one exposed load latency per tile instead of one per 16-row
+                // block: 8-byte loads issued and awaited row block by row block cost the aux GEMM 27 %, the residual ones
+                // 10-22 %.  Likewise the "rotary" scales, one row block ahead.  (Specialised modes only: the generic mode keeps
+                // every flag dynamic and would hold all of these live at once.)
+                constexpr bool LATE_X = !EARLY && (MODE == 3 || MODE == 4);
+                constexpr bool LATE_R = !EARLY && MODE == 1 && BN == 192;     // 256-wide: 2 x 8 scale vectors beside 128 accumulators spill
+                constexpr int LXD = (BN == 256) ? 2 : 4;        // row blocks in flight (256-wide: 2, or the tile's 128 accumulators spill)
+                u32x4 lx[LATE_X ? LXD : 1][LATE_X ? NJ / 2 : 1];
+                auto lx_fetch = [&](int i, u32x4 (&dst)[LATE_X ? NJ / 2 : 1]) {
+                    if constexpr (LATE_X) {
+                        const int gm = wrow0 + i * 16 + li;
+                        const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
+    #pragma unroll
+                        for (int jp = 0; jp < NJ / 2; ++jp) {
+                            const int gn = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                            dst[jp] = *reinterpret_cast<const u32x4*>((gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy);
+                        }
+                    }
+                };
+                if constexpr (LATE_X) {
+    #pragma unroll
+                    for (int i = 0; i < LXD; ++i) lx_fetch(i, lx[i]);
+                }
+                f32x4 rotv[LATE_R ? 2 : 1][LATE_R ? NJ : 1];
+                auto rot_fetch = [&](int i, f32x4 (&dst)[LATE_R ? NJ : 1]) {
+                    if constexpr (LATE_R) {
+                        const int gm = wrow0 + i * 16 + li;
+                        const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+    #pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int gn0 = wcol0 + j * 16 + g * 4;      // the lane's 4 columns lie inside one head's first or second 32 dims
+                            const bool on = (gn0 & 63) < 32 && gn0 < e_rot_cols;
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(on ? (const void*)(e_rot + (int64_t)rr * 32 + (gn0 & 63)) : (const void*)e_rot);
+                            dst[j] = on ? t : f32x4{1.f, 1.f, 1.f, 1.f};
+                        }
+                    }
+                };
+                if constexpr (LATE_R) rot_fetch(0, rotv[0]);
                 auto finish_pre = [&](int i, int j) -> f32x4 {
                     f32x4 v = acc[i][j];
                     if (!EARLY) {
@@ -546,11 +586,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                         }
                         // "rotary" scale for ANY tile width (a 192-wide tile gives a wave 1.5 heads): the lane's 4 columns start
                         // at a multiple of 4, so they lie inside one head's first or second 32 dims
-                        const int gn0 = wcol0 + j * 16 + g * 4;
-                        if (f_rot && (gn0 & 63) < 32 && gn0 < e_rot_cols) {
-                            const int gm = wrow0 + i * 16 + li;
-                            const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
-                            v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (gn0 & 63));
+                        if constexpr (LATE_R) {
+                            v *= rotv[i & 1][j];
+                        } else {
+                            const int gn0 = wcol0 + j * 16 + g * 4;
+                            if (f_rot && (gn0 & 63) < 32 && gn0 < e_rot_cols) {
+                                const int gm = wrow0 + i * 16 + li;
+                                const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+                                v *= *reinterpret_cast<const f32x4*>(e_rot + (int64_t)rr * 32 + (gn0 & 63));
+                            }
                         }
                         return v;
                     }
@@ -587,6 +631,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     __bf16* const crow = eC + roff;
                     __bf16* const c2row = eC2 + roff;
                     bf16x4 oc[NJ], od[NJ], xs[NJ];
+                    if constexpr (LATE_R) { if (i < 3) rot_fetch(i + 1, rotv[(i + 1) & 1]); }
+                    if constexpr (LATE_X) {       // undo the 16-byte load layout (as the EARLY path below does)
+    #pragma unroll
+                        for (int jp = 0; jp < NJ / 2; ++jp) {
+                            const u32x4 v4 = lx[i % LXD][jp];
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(v4[0], v4[2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(v4[1], v4[3], false, false);
+                            xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
+                            xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
+                        }
+                        if (i + LXD < 4) lx_fetch(i + LXD, lx[i % LXD]);
+                    }
                     if (EARLY && (f_res || f_aux)) {
     #pragma unroll
                         for (int jp = 0; jp < NJ / 2; ++jp) {
@@ -615,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                         }
                         if (f_res || f_aux) {
                             bf16x4 xx;
-                            if (EARLY) xx = xs[j];
+                            if (EARLY || LATE_X) xx = xs[j];
                             else {
                                 const int gn = wcol0 + j * 16 + g * 4;
                                 xx = (mok && gn < eN) ? *reinterpret_cast<const bf16x4*>(pre_src + (int64_t)out_row(gm) * pre_ld + gn) : bf16x4{};

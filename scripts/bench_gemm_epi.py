@@ -1,7 +1,7 @@
 """Cold-cache GEMM timing of one shape under different epilogues (what the training step really runs)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from merlot_reserve_amd import ops
+from merlot_reserve_amd import ops, _lib
 dev = torch.device('cuda:0')
 WS = torch.zeros(32 * 1024 * 1024, device=dev)
 M, H = 15424, 768
@@ -18,7 +18,9 @@ def run(name, m, n, k, tb, variants):
         sets.append((a, b, c, c2, x))
     bias = torch.randn(n, device=dev).to(torch.bfloat16)
     tab = torch.rand(241, 32, device=dev)
-    for vname, kw in variants:
+    for vname, kw, bn in [(v, k_, b_) for v, k_ in variants for b_ in (0, 128, 192, 256)]:
+        _lib.load().mr_set_option(b'gemm_tile_n', bn)
+        vname = f'{vname} bn={bn}'
         def call(a, b, c, c2, x):
             k2 = {}
             for key, val in kw.items():
@@ -40,3 +42,5 @@ run('fwd mlp1', M, 4 * H, H, 0, [('plain', {}), ('bias', {'bias': True}), ('bias
 run('dgrad mlp2', M, 4 * H, H, 1, [('plain', {}), ('aux', {'aux': True})])
 run('fwd qkv', M, 3 * H, H, 0, [('plain', {}), ('bias', {'bias': True}), ('bias+rot', {'bias': True, 'rot_tab': True, 'rot_cols': 2 * H})])
 run('fwd proj', M, H, H, 0, [('plain', {}), ('residual', {'residual': True})])
+run('fwd mlp2', M, H, 4 * H, 0, [('plain', {}), ('residual', {'residual': True})])
+run('dgrad mlp1', M, H, 4 * H, 1, [('plain', {})])

@@ -1,9 +1,29 @@
-"""Summarise a rocprofv3 kernel_stats.csv: per-kernel total / avg, normalised per step."""
+"""Summarise a rocprofv3 kernel_stats.csv: per-kernel total / avg, normalised per step.
+usage: prof_summary.py kernel_stats.csv [bench args as given to bench.py ...]   (steps are derived from --steps / --warmup /
+--no-roofline: 1 eager + warm-up + timed + 2 x min(timed, 3) instrumented eager steps)"""
 import csv, sys
-path, steps = sys.argv[1], float(sys.argv[2])
+path, args = sys.argv[1], sys.argv[2:]
+def opt(name, default):
+    return int(args[args.index(name) + 1]) if name in args else default
+K, W = opt('--steps', 10), opt('--warmup', 3)
+steps = 1 + W + K + (0 if '--no-roofline' in args else 2 * min(K, 3))
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'cast_params' not in r['Name'])
+print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 2 x {min(K, 3)} instrumented eager') + ')')
 print(f'total kernel ms/step (excl. one-off init): {tot / 1e6 / steps:.2f}')
-for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 20]:
+fam = {}
+def family(n):
+    if 'gemm' in n or 'splitk' in n: return 'gemm'
+    if 'attn' in n: return 'attention'
+    if 'ln_' in n or 'colsum' in n or 'reduce_' in n: return 'layernorm+reductions'
+    if 'adam' in n or 'nan_to_num' in n or 'cast_params' in n: return 'optimizer'
+    if 'ccl' in n.lower() or 'Reduce' in n: return 'rccl'
+    return 'rowops+other'
+for r in rows:
+    if 'cast_params' in r['Name']:
+        continue
+    fam[family(r['Name'])] = fam.get(family(r['Name']), 0.0) + float(r['TotalDurationNs']) / 1e6 / steps
+print('by family (ms/step): ' + ', '.join(f'{k} {v:.2f}' for k, v in sorted(fam.items(), key=lambda kv: -kv[1])))
+for r in rows[:60]:
     n = r['Name'].replace('(anonymous namespace)::', '').replace('_ZN12_GLOBAL__N_1', '')[:70]
     print(f"{n:70s} calls/step={float(r['Calls']) / steps:7.1f} ms/step={float(r['TotalDurationNs']) / 1e6 / steps:7.2f} avg_us={float(r['AverageNs']) / 1e3:8.1f}")

@@ -171,7 +171,12 @@ def test_vcr_full_size_forward_backward(dev, model_name):
     logits = model.apply({'params': params}, batch)
     eng, store = model.engine, model.params_store
     eng.loss_and_grad_logits()
-    inj = (torch.randn(8, generator=g) * 0.2).to(torch.bfloat16)
+    # Injected dL/dlogits with a non-zero mean.  The head is Dense(1), so the gradient entering the joint tower is rank one
+    # (proj x inj) over 8 positions whose features are nearly identical at random initialisation: with zero-mean weights
+    # every parameter gradient would be a difference of near-equal sums -- for the large model (scripts/debug_vcr_large.py)
+    # already d proj = sum_i inj_i * pooled_h[i], a product of the FORWARD alone, then differs by 17 % between bf16 and fp32
+    # storage of pooled_h (logits within 0.8 %), uniformly over the depth: conditioning of the test, not of the kernels.
+    inj = (0.25 + 0.15 * torch.randn(8, generator=g)).to(torch.bfloat16)
     eng.dlogits[:, 0] = inj.to(dev)
     eng.backward()
     torch.cuda.synchronize()
