@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--resadapt', action='store_true', help='resolution-adaptation grid 18x32 (BASELINE config 4; joint length 1312)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-h2d', action='store_true', help='skip the extra pass that feeds the inputs from host memory every step')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the hipGraph')
     ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL communicator, collectives inside the graph -- with a single rank')
     ap.add_argument('--comm', default='native', choices=['native', 'torch'], help="native: the library's RCCL communicator (captured into the hipGraph); torch: torch.distributed nccl (eager step)")
@@ -186,6 +187,23 @@ def main():
         dt = float(t.item())
     loss = trainer.loss_info()['loss']                         # mean over ranks (a collective when world > 1)
 
+    # the same steps with the inputs crossing PCIe every step (pinned double-buffered prefetch on a copy stream,
+    # merlot_reserve_amd/loader.py = the reference's prefetch_to_device): reported beside `value`, never as it
+    h2d_ms = None
+    if use_graph and not args.no_h2d:
+        import itertools
+        from merlot_reserve_amd.loader import PrefetchLoader
+        host = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+        plans = [trainer.plan(b) for b in batches]
+        loader = PrefetchLoader(itertools.islice(itertools.cycle(host), args.steps + 2), dev, depth=2)
+        for i, b in enumerate(loader):
+            if i == 2:
+                barrier()
+                t1 = time.perf_counter()
+            trainer.train_step_graph(b, plans[i % 2])
+        barrier()
+        h2d_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     roof, breakdown = None, None
     if not args.no_roofline:
         nprof = min(args.steps, 3)
@@ -248,7 +266,7 @@ def main():
                        'comm': comm_kind, 'rccl_ranks': None if comm is None else comm.world,
                        'gradient_buckets': [str(b[0]) for b in trainer.buckets],
                        'exposed_gradient_fraction': (trainer.buckets[-1][2] - trainer.buckets[-1][1]) / trainer.params.total,
-                       'hipgraph': bool(use_graph),
+                       'hipgraph': bool(use_graph), 'ms_per_step_inputs_from_host': h2d_ms,
                        'step_tflop_algorithmic': step_flops / 1e12,
                        'step_mfma_frac': step_flops / (dt / args.steps) / MFMA_BF16_PEAK},
             'roofline': roof, 'breakdown': breakdown,

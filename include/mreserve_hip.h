@@ -78,8 +78,16 @@ typedef struct {
     const void* aux; int64_t ldaux;
     int64_t out_grp, out_grp_stride, out_grp_off;
     void* workspace; int64_t workspace_bytes; /* optional fp32 scratch: enables split-K for few-tile / long-K problems */
+    /* optional: column sums of the STORED output (the bias gradient of the layer that produced the upstream gradient, i.e.
+     * colsum of d(pre-activation) = the aux-multiplied dgrad), as per-(256-row tile, 64-row wave) partial rows
+     * colsum[(4 * (m / 256) + (m % 256) / 64), n] fp32 with row stride ldcs -- mr_gemm_colsum_rows(M) rows -- to be summed by
+     * mr_reduce_partials in a fixed order.  Only for problems mr_gemm_colsum_supported() accepts (256-row kernel, aux
+     * epilogue, bf16 output); mr_gemm returns MR_EINVAL otherwise. */
+    void* colsum; int64_t ldcs;
 } mr_gemm_args;
 int mr_gemm(const mr_gemm_args* args, void* stream);
+int64_t mr_gemm_colsum_rows(int64_t M);
+int32_t mr_gemm_colsum_supported(const mr_gemm_args* args);
 /* count independent GEMMs (same transA/transB, epilogue limited to bias).  When they qualify (<= 4 problems, large M,
  * N % 128 == 0) they run as ONE persistent launch sharing the 256 CUs -- the four weight gradients of a transformer
  * layer -- with no split-K; otherwise this is count calls of mr_gemm.  Results are identical either way. */

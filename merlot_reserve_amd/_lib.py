@@ -21,7 +21,8 @@ class GemmArgs(C.Structure):
                 ('residual', vp), ('ldr', i64),
                 ('aux', vp), ('ldaux', i64),
                 ('out_grp', i64), ('out_grp_stride', i64), ('out_grp_off', i64),
-                ('workspace', vp), ('workspace_bytes', i64)]
+                ('workspace', vp), ('workspace_bytes', i64),
+                ('colsum', vp), ('ldcs', i64)]
 
 
 class ReduceJob(C.Structure):
@@ -36,6 +37,8 @@ PROTOTYPES = {
     'mr_last_error': (C.c_char_p, []),
     'mr_gemm': (i32, [C.POINTER(GemmArgs), vp]),
     'mr_gemm_grouped': (i32, [C.POINTER(GemmArgs), i32, vp]),
+    'mr_gemm_colsum_rows': (i64, [i64]),
+    'mr_gemm_colsum_supported': (i32, [C.POINTER(GemmArgs)]),
     'mr_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, vp, vp, i64, i64, f32, vp]),
     'mr_layernorm_bwd_workspace': (i64, [i64]),
     'mr_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp]),

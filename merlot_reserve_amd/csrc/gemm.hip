@@ -329,6 +329,8 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
                      "mr_gemm: fp32 output supports bias only");
     }
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
+    MR_CHECK_ARG(!a->colsum || (use_gemm256() && mr_gemm_colsum_supported(a) && a->ldcs >= a->N && ((uintptr_t)a->colsum % 16) == 0 && a->ldcs % 4 == 0),
+                 "mr_gemm: colsum is only produced by the 256-row kernel with the aux epilogue (ask mr_gemm_colsum_supported)");
     if (use_gemm256() && mr_gemm256_eligible(a)) {
         mr_gemm256_launch(a, static_cast<hipStream_t>(stream), launch_splitk_reduce);
         MR_CHECK_LAUNCH("mr_gemm (256-row kernel)");

@@ -134,6 +134,18 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int l
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15: the 16 output rows a lane group holds for one column set):
+// quad butterflies, then the two mirrors -- four v_add with DPP modifiers, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+#define MR_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+    v += MR_DPP(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += MR_DPP(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += MR_DPP(v, 0x141);     // row_half_mirror
+    v += MR_DPP(v, 0x140);     // row_mirror
+#undef MR_DPP
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -351,6 +363,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
         const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;   // BN = 96 never gets a rot_tab (host)
         const void* const dummy = pc.A;
+        float* const e_cs = static_cast<float*>(pc.colsum);
+        const int64_t e_ldcs = pc.ldcs;
         auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
         u32x2 pbias[NJ];
         u32x2 pre2[NPRE];       // (i, j) -> 4 bf16 of residual / aux;  or, "rotary": (i, j < 2) -> two halves of 4 fp32 scales
@@ -542,6 +556,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 // block: 8-byte loads issued and awaited row block by row block cost the aux GEMM 27 %, the residual ones
                 // 10-22 %.  Likewise the "rotary" scales, one row block ahead.  (Specialised modes only: the generic mode keeps
                 // every flag dynamic and would hold all of these live at once.)
+                // column sums of the stored tile (the bias gradient: see mr_gemm_args.colsum), aux mode only: that epilogue waits
+                // on memory, the extra vector work hides under it
+                constexpr bool CS = MODE == 4;
+                const bool f_cs = CS && e_cs != nullptr;
+                f32x4 cs[CS ? NJ : 1];
+                if constexpr (CS) {
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 constexpr bool LATE_X = !EARLY && (MODE == 3 || MODE == 4);
                 constexpr bool LATE_R = !EARLY && MODE == 1 && BN == 192;     // 256-wide: 2 x 8 scale vectors beside 128 accumulators spill
                 constexpr int LXD = (BN == 256) ? 2 : 4;        // row blocks in flight (256-wide: 2, or the tile's 128 accumulators spill)
@@ -681,6 +704,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                                 o[r] = f_res ? (__bf16)((float)o[r] + (float)xx[r]) : (__bf16)((float)o[r] * (float)xx[r]);
                         }
                         oc[j] = o;
+                        if constexpr (CS) {
+                            if (f_cs && mok) {
+    #pragma unroll
+                                for (int r = 0; r < 4; ++r) cs[j][r] += (float)o[r];
+                            }
+                        }
                     }
     #pragma unroll
                     for (int jp = 0; jp < NJ / 2; ++jp) {
@@ -692,6 +721,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                         if (mok && col < eN) {
                             if (f_c2) *reinterpret_cast<bf16x4*>(c2row + col) = od[NJ - 1];
                             *reinterpret_cast<bf16x4*>(crow + col) = oc[NJ - 1];
+                        }
+                    }
+                }
+                if constexpr (CS) {
+                    if (f_cs) {       // the wave's 64 rows: 4 row blocks summed in registers, the 16 rows of a block across the DPP row
+                        float* const prow = e_cs + (int64_t)((m0 / BM) * 4 + wm) * e_ldcs;
+    #pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) cs[j][r] = row16_sum(cs[j][r]);
+                            const int col = wcol0 + j * 16 + g * 4;
+                            if (li == 0 && col < eN) *reinterpret_cast<f32x4*>(prow + col) = cs[j];
                         }
                     }
                 }
@@ -748,6 +789,12 @@ bool mr_gemm256_eligible(const mr_gemm_args* a) {
     return true;
 }
 
+extern "C" int64_t mr_gemm_colsum_rows(int64_t M) { return 4 * ((M + g256::BM - 1) / g256::BM); }
+extern "C" int32_t mr_gemm_colsum_supported(const mr_gemm_args* a) {
+    return a && mr_gemm256_eligible(a) && a->c_dtype == MR_DT_BF16 && a->aux && !a->residual && !a->c2 && a->act == MR_ACT_NONE &&
+           !a->rot_tab && a->out_grp == 0 && a->N % 4 == 0;
+}
+
 int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const mr_gemm_args*, int64_t, hipStream_t)) {
     const int64_t tm = (a->M + g256::BM - 1) / g256::BM;
     // tile width: the one that wastes the fewest CU-rounds (256 workgroups per round, one per CU)
@@ -771,6 +818,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     }
     { const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn; if (f == 96 || f == 128 || (f == 256 && can256) || (f == 192 && can192)) bn = f; }
     if (a->rot_tab && bn == 96) bn = 128;
+    if (a->colsum && bn == 256 && can192) bn = 192;     // the column-sum accumulators beside a 256-wide tile's 128 accumulators spill (measured: +22 us)
     const int64_t tn = (a->N + bn - 1) / bn;
     const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
     int64_t splits = 1;

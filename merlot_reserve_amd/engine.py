@@ -64,6 +64,12 @@ class TowerEngine:
         # single mr_reduce_partials launch
         sc.ln_ws2 = ops.layernorm_bwd_workspace(H, dev)
         sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
+        # per-(tile, wave) column-sum partials written by the d(pre-activation) GEMM's epilogue (the fc1 bias gradient)
+        sc.cs_fused = f(4 * ((Ms + 255) // 256) * 4 * H)
+        # tower-level reductions (pre / final LayerNorm, pooling and projection biases) keep their partial rows in these until
+        # the tower's ONE mr_reduce_partials launch (they used to be two latency-bound launches each)
+        sc.tower_ln_ws = [ops.layernorm_bwd_workspace(H, dev) for _ in range(2)]
+        sc.tower_cs_ws = [ops.colsum_workspace(H, dev) for _ in range(6)]
         sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
         sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
         sc.Dpatch = z(Ps, H)
@@ -76,6 +82,29 @@ class TowerEngine:
 
     def gemm_args(self, a, b, out, **kw):
         return ops.gemm_args(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
+
+    # tower-level deferred reductions: between _begin_tower_reductions() and _flush_tower_reductions() every LayerNorm /
+    # colsum issued through _t_ln_bwd / _t_colsum leaves its partial rows in a workspace of its own
+    def _begin_tower_reductions(self):
+        return {'jobs': None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else [], 'ln': 0, 'cs': 0, 'sc': self.cur}
+
+    def _t_ln_bwd(self, tr, *a, **k):
+        if tr is None or tr['jobs'] is None:
+            return ops.layernorm_bwd(*a, self.cur.ln_ws, **k)
+        ws = tr['sc'].tower_ln_ws[tr['ln']]
+        tr['ln'] += 1
+        return ops.layernorm_bwd(*a, ws, jobs=tr['jobs'], **k)
+
+    def _t_colsum(self, tr, x, out):
+        if tr is None or tr['jobs'] is None:
+            return ops.colsum(x, out, self.cur.cs_ws)
+        ws = tr['sc'].tower_cs_ws[tr['cs']]
+        tr['cs'] += 1
+        return ops.colsum(x, out, ws, jobs=tr['jobs'])
+
+    def _flush_tower_reductions(self, tr):
+        if tr is not None and tr['jobs']:
+            ops.reduce_partials(tr['jobs'])          # (clears the list)
 
     def _on_side(self, fn):
         """Issue fn()'s kernels on the side stream (forked from / joined to the current stream by the caller)."""
@@ -171,7 +200,7 @@ class TowerEngine:
         k = 2 * st.L + 1
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
-    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None):
+    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None):
         """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (one of D / two scratch
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
         gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K).
@@ -181,18 +210,23 @@ class TowerEngine:
         T_a, T_q, T_h = self.cur.T_a[:M], self.cur.T_q[:M], self.cur.T_h[:M]
         Dcur, Dmid, Dnext = D, self.cur.T_d1[:M], self.cur.T_d2[:M]
         k = 2 * st.L + 1
-        ops.layernorm_bwd(Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
-                          G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'], self.cur.ln_ws)
+        self._t_ln_bwd(tr, Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
+                       G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'])
+        # everything above the layers (heads, pooling, final LayerNorm) is reduced here: a data-parallel trainer hands the
+        # tower's LAST layers' gradient bucket -- which holds these leaves -- to the all-reduce at the first layer_done
+        self._flush_tower_reductions(tr)
         jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
-            self.gemm(Dcur, W[n['w2']], T_h, transB=True, aux=st.hpre[l])                    # d hpre
+            fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']], jobs, transB=True,
+                                            aux=st.hpre[l], ws=self.cur.gemm_ws)            # d hpre (+ its column sums = d bias)
             self.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
                               G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
             self.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
             ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh)
-            ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
+            if not fused_bb1:
+                ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
             ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
             self.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
             ops.gemm_grouped([self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
@@ -206,8 +240,8 @@ class TowerEngine:
             if layer_done is not None:
                 layer_done(l)
             Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
-        ops.layernorm_bwd(Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
-                          G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'], self.cur.ln_ws)
+        self._t_ln_bwd(tr, Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
+                       G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'])
         return Dcur
 
     # ------------------------------------------------------------------------------------------ CLS tower head + pool
@@ -227,33 +261,33 @@ class TowerEngine:
         self.gemm(po, W[f'{prefix_pool}/out/kernel'], out_seq, bias=W[f'{prefix_pool}/out/bias'])
 
     def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D,
-                                  layer_done=None):
+                                  layer_done=None, tr=None):
         """d_seq: grad wrt the pooled sequence output; d_cls: grad wrt the cls output.  Returns D = grad wrt st.xin."""
         W, G, nh, M = self.p.w, self.p.g, st.H // 64, st.M
         Gn = qin.shape[0]
         d_po, d_q, d_qin = self.cur.d_pool_po[:Gn], self.cur.d_pool_q[:Gn], self.cur.d_pool_qin[:Gn]
         d_k, d_v = self.cur.d_k[:M], self.cur.d_v[:M]
-        ops.colsum(d_seq, G[f'{prefix_pool}/out/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, d_seq, G[f'{prefix_pool}/out/bias'])
         self.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
         self.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
         ops.poolattn_bwd(q, k, v, pool_rows, probs, d_po, d_q, d_k, d_v, nh)
-        ops.colsum(d_q, G[f'{prefix_pool}/query/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, d_q, G[f'{prefix_pool}/query/bias'])
         self.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
         self.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
-        ops.colsum(d_k, G[f'{prefix_pool}/key/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, d_k, G[f'{prefix_pool}/key/bias'])
         self.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
         self.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
-        ops.colsum(d_v, G[f'{prefix_pool}/value/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, d_v, G[f'{prefix_pool}/value/bias'])
         self.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
         self.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
         ops.rows_mean_bwd(d_qin, pool_rows, D)
         # cls head
         cls_in = self._cls_view(st.xf, st.nseq, st.S)
-        ops.colsum(d_cls, G[f'{prefix_t}/cls_proj/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, d_cls, G[f'{prefix_t}/cls_proj/bias'])
         self.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
         Dc = self._cls_view(D, st.nseq, st.S)
         self.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
-        D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done)
+        D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done, tr=tr)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
 
@@ -528,11 +562,13 @@ class PretrainEngine(TowerEngine):
             # span tower (only its cls output is used: gradient enters at the CLS rows)
             Ds = self.Ds
             Ds.zero_()
+            tr = self._begin_tower_reductions()
             cls_in = self._cls_view(ts.xf, ts.nseq, ts.S)
-            ops.colsum(self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'], self.cur.cs_ws)
+            self._t_colsum(tr, self.d_s_cls, G['span_encoder/transformer/cls_proj/bias'])
             self.gemm(cls_in, self.d_s_cls, G['span_encoder/transformer/cls_proj/kernel'], transA=True)
             self.gemm(self.d_s_cls, W['span_encoder/transformer/cls_proj/kernel'], self._cls_view(Ds, ts.nseq, ts.S), transB=True)
-            Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds)
+            Ds = self.encoder_backward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'), Ds, tr=tr)
+            self._flush_tower_reductions(tr)
             ops.sum_rows_strided(Ds, ts.nseq, ts.S, 0, G['span_encoder/transformer/cls'])
             if Ds.data_ptr() != self.Ds.data_ptr():            # the joint tower reuses the rotating scratch: keep a copy
                 self.Ds.copy_(Ds)
@@ -544,11 +580,13 @@ class PretrainEngine(TowerEngine):
         Ds = self._on_side(span_bwd)
         # joint tower
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
-        ops.colsum(self.d_hj, G['head/bias'], self.cur.cs_ws)
+        trj = self._begin_tower_reductions()
+        self._t_colsum(trj, self.d_hj, G['head/bias'])
         self.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
         Dj = self.Dj
         self.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
-        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj)
+        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj, tr=trj)
+        self._flush_tower_reductions(trj)
         main.wait_stream(self.side_stream)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
         ops.segment_sum([Dj, Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
@@ -559,22 +597,26 @@ class PretrainEngine(TowerEngine):
     def backward_stage_audio(self):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
         ta = self.ta
+        tr = self._begin_tower_reductions()
         Da = self._tower_with_pool_backward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                             self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
-                                            self.a_probs, self.d_audio_seq, self.d_a_cls, self.Da)
+                                            self.a_probs, self.d_audio_seq, self.d_a_cls, self.Da, tr=tr)
         Dp = self.cur.Dpatch[:d.Na * d.a_len]
         ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
-        ops.colsum(Dp, G['audio_encoder/embedding/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, Dp, G['audio_encoder/embedding/bias'])
+        self._flush_tower_reductions(tr)
         self.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
     def backward_stage_vision(self, layer_done=None):
         d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
         tv = self.tv
+        tr = self._begin_tower_reductions()
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                             self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
-                                            self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv, layer_done=layer_done)
+                                            self.v_probs, self.d_imgs_seq, self.d_v_cls, self.Dv, layer_done=layer_done, tr=tr)
         Dp = self.cur.Dpatch[:d.Nv * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
-        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, Dp, G['vision_encoder/embedding/bias'])
+        self._flush_tower_reductions(tr)
         self.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
 
     def loss_info(self):

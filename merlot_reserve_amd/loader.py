@@ -1,0 +1,100 @@
+"""Host -> device input prefetch: the counterpart of `flax.jax_utils.prefetch_to_device(iter, size=1)` at the end of the
+reference's input pipeline (pretrain/dataloader.py:957-958), for one process per GPU.
+
+A batch is the dict of pretrain/dataloader.py:732-789 for ONE device: float arrays `images` [B, 16*hw, 768] and `audio_clips`
+[B, 48*60, 65] (bf16 on the wire, like the reference: :786-788) and the int32 token streams.  The integer streams stay on the
+host -- the planner (planner.py) turns them into index lists there, and those travel through the engine's own pinned
+staging ring (engine.set_plan).  The two float arrays (26 MB per base batch of 4 records) are what this loader moves:
+
+    host batch -> pinned staging buffer (ring of `depth`) -> async H2D copy on a dedicated copy stream -> device buffer
+    (ring of `depth`), guarded by one event per slot in each direction:
+      * a pinned slot is rewritten only after the copy that read it has completed,
+      * a device slot is overwritten only after the compute stream has finished the step that consumed it
+        (the consumer calls `release()` -- or simply asks for the next batch -- on the stream that ran the step).
+
+While step t runs, batch t+1 is already crossing PCIe (~0.5 ms at Gen5 x16 for the base batch), so the transfer is off the
+step's critical path; bench.py reports the throughput with resident inputs as `value` and this path separately.
+"""
+import numpy as np
+import torch
+
+FLOAT_KEYS = ('images', 'audio_clips')
+
+
+class PrefetchLoader:
+    def __init__(self, batches, device, depth=2, dtype=torch.bfloat16):
+        """batches: an iterable of host batches (numpy arrays or CPU tensors for FLOAT_KEYS; anything else is passed through).
+        depth >= 2: slots in the pinned and device rings (1 batch being consumed + depth - 1 in flight)."""
+        assert depth >= 2
+        self.it = iter(batches)
+        self.device = torch.device(device)
+        self.depth, self.dtype = depth, dtype
+        self.cuda = self.device.type == 'cuda'
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.pinned, self.dev = [None] * depth, [None] * depth
+        self.h2d_done = [None] * depth            # event: the H2D copy out of pinned slot i / into device slot i has completed
+        self.consumed = [None] * depth            # event: the compute stream is done with device slot i
+        self.queue = []                           # (slot, passthrough dict) of batches in flight, oldest first
+        self.turn = 0
+        self.current = None
+        for _ in range(depth - 1):
+            self._issue()
+
+    def _alloc(self, slot, batch):
+        self.pinned[slot] = {k: torch.empty(tuple(batch[k].shape), dtype=self.dtype, pin_memory=self.cuda) for k in FLOAT_KEYS}
+        self.dev[slot] = {k: torch.empty(tuple(batch[k].shape), dtype=self.dtype, device=self.device) for k in FLOAT_KEYS}
+
+    def _issue(self):
+        """Take the next host batch and start its transfer into the next slot.  Returns False at the end of the data."""
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            return False
+        slot = self.turn
+        self.turn = (self.turn + 1) % self.depth
+        if self.pinned[slot] is None or any(tuple(batch[k].shape) != tuple(self.pinned[slot][k].shape) for k in FLOAT_KEYS):
+            self._alloc(slot, batch)
+        if self.h2d_done[slot] is not None:
+            self.h2d_done[slot].synchronize()                     # the pinned slot's previous copy has left it
+        for k in FLOAT_KEYS:
+            src = batch[k]
+            src = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src
+            self.pinned[slot][k].copy_(src)                       # host-side cast to the wire dtype + memcpy into pinned memory
+        if self.cuda:
+            with torch.cuda.stream(self.copy_stream):
+                if self.consumed[slot] is not None:
+                    self.copy_stream.wait_event(self.consumed[slot])   # the step that read this device slot has finished
+                for k in FLOAT_KEYS:
+                    self.dev[slot][k].copy_(self.pinned[slot][k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.h2d_done[slot] = ev
+        else:
+            for k in FLOAT_KEYS:
+                self.dev[slot][k].copy_(self.pinned[slot][k])
+        self.queue.append((slot, {k: v for k, v in batch.items() if k not in FLOAT_KEYS}))
+        return True
+
+    def release(self):
+        """Mark the batch handed out last as consumed at this point of the CURRENT stream (called by __next__ too)."""
+        if self.current is not None and self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.consumed[self.current] = ev
+        self.current = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self.release()
+        self._issue()                                             # keep depth - 1 transfers in flight
+        if not self.queue:
+            raise StopIteration
+        slot, rest = self.queue.pop(0)
+        if self.cuda:
+            torch.cuda.current_stream().wait_event(self.h2d_done[slot])    # device-side wait: the host does not block
+        self.current = slot
+        out = dict(rest)
+        out.update(self.dev[slot])
+        return out

@@ -51,7 +51,7 @@ def _timed(family):
 
 
 def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,
-              residual=None, aux=None, row_map=None, ws=None):
+              residual=None, aux=None, row_map=None, ws=None, colsum=None):
     """Builds the mr_gemm_args of out[M,N] = op(a) @ op(b) (see gemm()).  ws: the CALLER's fp32 scratch for split-K
     partials (None disables split-K); it is per engine and per stream -- there is no module-level workspace, so two
     engines (or a captured graph and a later engine) can never share or outlive each other's scratch."""
@@ -86,6 +86,11 @@ def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, ro
     else:
         g.out_grp = g.out_grp_stride = g.out_grp_off = 0
         assert out.shape[0] >= M and out.shape[1] >= N
+    if colsum is not None:       # fp32 [mr_gemm_colsum_rows(M), >= N]: per-(tile, wave) column sums of the stored output
+        assert colsum.dtype == F32 and colsum.shape[0] >= _lib.load().mr_gemm_colsum_rows(M) and colsum.shape[1] >= N
+        g.colsum, g.ldcs = colsum.data_ptr(), _ld(colsum)
+    else:
+        g.colsum, g.ldcs = None, 0
     if ws is not None:
         assert ws.dtype == F32 and ws.device == a.device
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -131,6 +136,25 @@ def gemm_grouped(arg_list):
 
 
 @_timed('layernorm+reductions')
+def gemm_colsum_job(a, b, out, colsum_ws, bias_grad, jobs, **kw):
+    """out = op(a) @ op(b) * aux with the bias gradient colsum(out) folded into the GEMM's epilogue when the library supports it
+    for this problem (per-tile partial rows in colsum_ws, reduced later with the other deferred jobs); otherwise the GEMM
+    and a separate column-sum pass over `out`.  Returns True when fused."""
+    lib = _lib.load()
+    M = a.shape[1] if kw.get('transA') else a.shape[0]
+    N = out.shape[1]
+    rows = lib.mr_gemm_colsum_rows(M)
+    cs = colsum_ws[:rows * N].view(rows, N) if colsum_ws.numel() >= rows * N else None
+    if cs is not None and jobs is not None:
+        g = gemm_args(a, b, out, colsum=cs, **kw)
+        if lib.mr_gemm_colsum_supported(C.byref(g)):
+            gemm(a, b, out, colsum=cs, **kw)
+            jobs.append(_lib.ReduceJob(cs.data_ptr(), rows, N, N, bias_grad.data_ptr(), bias_grad.data_ptr()))
+            return True
+    gemm(a, b, out, **kw)
+    return False
+
+
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
     rows, H = x.shape
     if x.dtype == F32:

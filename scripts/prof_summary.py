@@ -6,7 +6,7 @@ path, args = sys.argv[1], sys.argv[2:]
 def opt(name, default):
     return int(args[args.index(name) + 1]) if name in args else default
 K, W = opt('--steps', 10), opt('--warmup', 3)
-steps = 1 + W + K + (0 if '--no-roofline' in args else 2 * min(K, 3))
+steps = 1 + W + K + (0 if "--no-roofline" in args else 2 * min(K, 3)) + (0 if "--no-h2d" in args or "--no-graph" in args else K + 2)
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'cast_params' not in r['Name'])
 print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 2 x {min(K, 3)} instrumented eager') + ')')

@@ -3,7 +3,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_out
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline "$@" > /tmp/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-h2d "$@" > /tmp/trace.log 2>&1
 tail -1 /tmp/trace.log
 mkdir -p $root/gpurun_out/trace
 f=$(ls /tmp/trace_out/*/*kernel_trace.csv | head -1)

@@ -544,6 +544,34 @@ def test_gemm256_epilogues(dev, tile_n):
     assert relerr(o32, ref) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(15424 // 4, 3072, 768), (1500, 768, 512), (2304, 1024, 256)])
+def test_gemm256_fused_colsum(dev, tile_n, M, N, K):
+    """The aux-epilogue GEMM (d pre-activation = (dY . W2^T) * gelu') with the bias gradient folded in: per-(tile, wave) column
+    sums of the STORED bf16 output, reduced by mr_reduce_partials -- equal to the separate column-sum pass over the output."""
+    from merlot_reserve_amd import _lib, ops
+    a, w = rnd((M, K), dev, seed=1), rnd((N, K), dev, scale=0.1, seed=2)
+    aux = rnd((M, N), dev, seed=3)
+    out = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
+    rows = _lib.load().mr_gemm_colsum_rows(M)
+    ws = torch.full((rows * N,), float('nan'), device=dev)
+    bias_grad = torch.zeros(N, dtype=BF16, device=dev)
+    jobs = []
+    fused = ops.gemm_colsum_job(a, w, out, ws, bias_grad, jobs, transB=True, aux=aux)
+    assert fused and len(jobs) == 1
+    ops.reduce_partials(jobs)
+    ref = (a.float() @ w.float().T).to(BF16).float() * aux.float()
+    assert_close(out, ref, 4e-3, 'aux GEMM')
+    want = out.float().sum(0)                                   # column sums of what was stored
+    assert_close(bias_grad, want, 6e-3, 'fused bias gradient')
+    ref2 = torch.zeros(N, dtype=BF16, device=dev)
+    ops.colsum(out, ref2, ops.colsum_workspace(N, dev))
+    assert_close(bias_grad, ref2.float(), 6e-3, 'fused vs separate column sum')
+    # problems the 256-row kernel does not take fall back to the separate pass
+    small = rnd((300, K), dev, seed=4)
+    o2 = torch.zeros(300, N, dtype=BF16, device=dev)
+    assert not ops.gemm_colsum_job(small, w, o2, ws, bias_grad, [], transB=True, aux=aux[:300])
+
+
 @pytest.mark.parametrize('group_tile', [0, 128, 256])
 def test_gemm_grouped(dev, group_tile):
     """Four wgrad-shaped problems in one persistent launch == four separate GEMMs (both tile widths of the shared launch)."""
