@@ -131,10 +131,14 @@ int mr_reduce_partials(const mr_reduce_job* jobs, int32_t count, void* stream);
 int mr_attention_fwd(const void* qkv, const int32_t* code, void* out, float* lse,
                      int64_t nseq, int64_t S, int64_t nh, void* stream);
 /* dqkv [nseq*S, 3H] bf16 = gradient wrt the PRE-"rotary" qkv when rot_tab != NULL (the diagonal
- * scaling is applied to dq, dk on the way out), else wrt qkv as given.  delta: fp32 [nseq, nh, S] workspace. */
+ * scaling is applied to dq, dk on the way out), else wrt qkv as given.  delta: fp32 [nseq, nh, S] workspace (rowsum(dO * O),
+ * computed by the dQ kernel).  colsum (optional): fp32 [mr_attention_bwd_colsum_rows(nseq, S), 3H] -- per (sequence, 64- or
+ * 128-position block) column sums of the stored dqkv, i.e. partial rows of the qkv bias gradient (M:228) to be summed in a
+ * fixed order by mr_reduce_partials; every element is written. */
 int mr_attention_bwd(const void* qkv, const int32_t* code, const void* out, const void* dout, const float* lse,
-                     float* delta, void* dqkv, const float* rot_tab, int64_t rot_rows,
+                     float* delta, void* dqkv, const float* rot_tab, int64_t rot_rows, float* colsum,
                      int64_t nseq, int64_t S, int64_t nh, void* stream);
+int64_t mr_attention_bwd_colsum_rows(int64_t nseq, int64_t S);
 
 /* ---- attention pooling core (flax MultiHeadDotProductAttention with 1 query and R keys: M:419-427, 467-472)
  * q [G, H]; k, v rows gathered by key_rows [G, R] (row indices into k/v, ld = ldkv); out [G, H].

@@ -48,7 +48,8 @@ PROTOTYPES = {
     'mr_reduce_partials': (i32, [C.POINTER(ReduceJob), i32, vp]),
     'mr_colsum': (i32, [vp, i64, i64, i64, vp, vp, vp]),
     'mr_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
-    'mr_attention_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    'mr_attention_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]),
+    'mr_attention_bwd_colsum_rows': (i64, [i64, i64]),
     'mr_poolattn_fwd': (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i64, i64, vp]),
     'mr_poolattn_bwd': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     'mr_segment_sum': (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i32, i64, i64, f32, i32, vp]),

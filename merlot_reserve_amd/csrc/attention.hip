@@ -117,6 +117,32 @@ __device__ __forceinline__ void add_bias(f32x4& s, const i32x4& ck, const f32x4&
     for (int r = 0; r < 4; ++r) s[r] = (ck[r] == cq) ? s[r] : s[r] + nk[r];
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15): quad butterflies, then the two mirrors (no LDS)
+__device__ __forceinline__ float row16_sum(float v) {
+#define MR_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true))
+    v += MR_DPP(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += MR_DPP(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += MR_DPP(v, 0x141);     // row_half_mirror
+    v += MR_DPP(v, 0x140);     // row_mirror
+#undef MR_DPP
+    return v;
+}
+
+// Column sums of what a workgroup stored (the qkv bias gradient, flax DenseGeneral bias: M:228): cs[db][r] = this lane's sum over
+// its own rows of column d = 16 db + 4 g + r (the bf16-ROUNDED values, like a column-sum pass over the stored tensor).  Rows across
+// the 16 lanes of a DPP row, then the 4 waves through `red`; thread d < 64 writes dst[d].  All threads must call it.
+__device__ __forceinline__ void block_colsum_store(f32x4 (&cs)[4], float (*red)[64], float* __restrict__ dst, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[db][r] = row16_sum(cs[db][r]);
+        if (i == 0) *reinterpret_cast<f32x4*>(&red[wave][db * 16 + g * 4]) = cs[db];
+    }
+    __syncthreads();
+    if (tid < 64) dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 // XCD-aware block order.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, so with the plain
 // (block, head, sequence) grid the query blocks of ONE (sequence, head) -- which all stream the same K / V rows -- landed
 // on different XCDs and every XCD's L2 fetched those rows for itself (rocprofv3 FETCH_SIZE: 3.7x the algorithmic bytes
@@ -298,7 +324,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __b
                                                              const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                              __bf16* __restrict__ dqkv, const float* __restrict__ rot_tab,
-                                                             int64_t rot_rows, int64_t S, int64_t nh) {
+                                                             int64_t rot_rows, float* __restrict__ colsum, int64_t S, int64_t nh) {
+    __shared__ __attribute__((aligned(16))) float red[4][64];
     __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDV];   // row reads (S^T) and tr reads (dQ^T)
     __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDR];   // row reads (dP^T)
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
@@ -437,6 +464,9 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __b
         }
         __syncthreads();
     }
+    f32x4 cs[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) cs[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         if (qi[qb] < S) {
@@ -447,11 +477,13 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __b
                 if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + qi[qb]) % rot_rows) * 32 + d);
                 bf16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (__bf16)x[r];
+                for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; cs[db][r] += (float)v[r]; }
                 *reinterpret_cast<bf16x4*>(dqkv + (seq * S + qi[qb]) * ld + h * 64 + d) = v;
             }
         }
     }
+    if (colsum != nullptr)        // wave-uniform: partial row (sequence, query block), columns of this head's q
+        block_colsum_store(cs, red, colsum + (seq * ((S + 64 * QB - 1) / (64 * QB)) + ab_.blk) * ld + h * 64, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -464,7 +496,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                                                               const __bf16* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, __bf16* __restrict__ dqkv,
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
-                                                              int64_t S, int64_t nh) {
+                                                              float* __restrict__ colsum, int64_t S, int64_t nh) {
+    __shared__ __attribute__((aligned(16))) float red[4][64];
     __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TK * LDV];    // row reads (S) and tr reads (dK^T)
     __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TK * LDV];    // dO: row reads (dP) and tr reads (dV^T)
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
@@ -611,6 +644,9 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     }
     // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores.  dK: the 1/8 folded into kf was on the OTHER operand
     // of S = q . (k/8), so d(score)/dk = q / 8 still has to be applied here.
+    f32x4 csk[4], csv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { csk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (ki[kb] < S) {
@@ -621,11 +657,20 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                 if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + ki[kb]) % rot_rows) * 32 + d);
                 bf16x4 a, c;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r]; }
+                for (int r = 0; r < 4; ++r) {
+                    a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r];
+                    csk[db][r] += (float)a[r]; csv[db][r] += (float)c[r];
+                }
                 *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + H + h * 64 + d) = a;
                 *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + 2 * H + h * 64 + d) = c;
             }
         }
+    }
+    if (colsum != nullptr) {      // wave-uniform: partial row (sequence, key block), columns of this head's k and v
+        float* prow = colsum + (seq * ((S + 64 * KB - 1) / (64 * KB)) + ab_.blk) * ld;
+        block_colsum_store(csk, red, prow + H + h * 64, tid);
+        __syncthreads();
+        block_colsum_store(csv, red, prow + 2 * H + h * 64, tid);
     }
 }
 
@@ -660,9 +705,14 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     return MR_OK;
 }
 
+extern "C" int64_t mr_attention_bwd_colsum_rows(int64_t nseq, int64_t S) {
+    const int64_t per = (S > attn_qb_threshold()) ? 128 : 64;          // queries (keys) per workgroup
+    return nseq * ((S + per - 1) / per);
+}
+
 extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void* out, const void* dout, const float* lse,
-                                float* delta, void* dqkv, const float* rot_tab, int64_t rot_rows, int64_t nseq, int64_t S,
-                                int64_t nh, void* stream) {
+                                float* delta, void* dqkv, const float* rot_tab, int64_t rot_rows, float* colsum, int64_t nseq,
+                                int64_t S, int64_t nh, void* stream) {
     MR_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "mr_attention_bwd: null pointer");
     MR_CHECK_ARG(nseq > 0 && S > 0 && nh > 0, "mr_attention_bwd: bad shape");
     MR_CHECK_ARG(nseq <= 65535 && nh <= 65535, "mr_attention_bwd: nseq / nh exceed grid limits");
@@ -676,9 +726,9 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, oo, d, lse, delta, g, \
-                           rot_tab, rot_rows, S, nh);                                                                         \
+                           rot_tab, rot_rows, colsum, S, nh);                                                                 \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
-                           rot_tab, rot_rows, S, nh);                                                                         \
+                           rot_tab, rot_rows, colsum, S, nh);                                                                 \
     } while (0)
     if (two && code) MR_LAUNCH_BWD(2, true);
     else if (two) MR_LAUNCH_BWD(2, false);

@@ -436,8 +436,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             // k-tile cseq+1 must have landed before anyone reads it: everything but this step's 6 pieces (this also
             // retires the previous item's epilogue stores, which were issued before them) and the residual / aux loads
             // requested behind this k-tile's and the previous k-tile's pieces
-            if (EARLY && issued && pre_now + pre_prev == 2) wait_vmcnt<WAITN + 2 * NJ>();
-            else if (EARLY && issued && pre_now + pre_prev == 1) wait_vmcnt<WAITN + NJ>();
+            // (a pre_rows call issues PRE_LOADS loads: one 16-byte load per pair of column blocks + one 8-byte load for an odd
+            // block.  The counts must be exact: vmcnt retires in order, and any slack here would let pieces of k-tile cseq+1 --
+            // older than all of these -- still be in flight when the barrier opens.  They were 2 x NJ / NJ, i.e. 4 / 2 too many,
+            // until round 2: never observed to fail, the pieces are a whole k-tile old by then, but not guaranteed either.)
+            constexpr int PRE_LOADS = NJ / 2 + (NJ & 1);
+            if (EARLY && issued && pre_now + pre_prev == 2) wait_vmcnt<WAITN + 2 * PRE_LOADS>();
+            else if (EARLY && issued && pre_now + pre_prev == 1) wait_vmcnt<WAITN + PRE_LOADS>();
             else RING_WAIT(issued);
             pre_prev = pre_now;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -66,6 +66,9 @@ class TowerEngine:
         sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
         # per-(tile, wave) column-sum partials written by the d(pre-activation) GEMM's epilogue (the fc1 bias gradient)
         sc.cs_fused = f(4 * ((Ms + 255) // 256) * 4 * H)
+        # per-(sequence, block) column-sum partials written by the attention backward kernels (the qkv bias gradient): at most
+        # one row per 16 positions (short sequences) of [3H]
+        sc.cs_attn = f(((Ms + 15) // 16 + 64) * 3 * H)
         # tower-level reductions (pre / final LayerNorm, pooling and projection biases) keep their partial rows in these until
         # the tower's ONE mr_reduce_partials launch (they used to be two latency-bound launches each)
         sc.tower_ln_ws = [ops.layernorm_bwd_workspace(H, dev) for _ in range(2)]
@@ -218,16 +221,20 @@ class TowerEngine:
         jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
-            fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']], jobs, transB=True,
+            fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']],
+                                            jobs if os.environ.get('MR_NO_GEMM_COLSUM') != '1' else None, transB=True,
                                             aux=st.hpre[l], ws=self.cur.gemm_ws)            # d hpre (+ its column sums = d bias)
             self.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
                               G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
             self.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
-            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh)
+            fuse_q = jobs is not None and os.environ.get('MR_NO_ATTN_COLSUM') != '1'          # (A/B switch)
+            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh,
+                              colsum_ws=self.cur.cs_attn, bias_grad=G[n['bqkv']], jobs=jobs if fuse_q else None)   # (+ column sums of T_q = d bias)
             if not fused_bb1:
                 ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
-            ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
+            if not fuse_q:
+                ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
             self.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
             ops.gemm_grouped([self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
                               self.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),

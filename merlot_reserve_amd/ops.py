@@ -227,12 +227,22 @@ def attention_fwd(qkv, code, out, lse, nseq, S, nh):
 
 
 @_timed('attention')
-def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh):
+def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh, colsum_ws=None, bias_grad=None, jobs=None):
+    """With colsum_ws / bias_grad / jobs: the qkv bias gradient (column sums of dqkv) comes out of the backward kernels as
+    per-block partial rows in colsum_ws, reduced later with the layer's other deferred jobs (no pass over dqkv)."""
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     rr = 0 if rot_tab is None else rot_tab.numel() // 32
-    check(_lib.load().mr_attention_bwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                       delta.data_ptr(), dqkv.data_ptr(), _ptr(rot_tab), rr, nseq, S, nh, _stream()),
+    lib = _lib.load()
+    cs = None
+    if jobs is not None and colsum_ws is not None:
+        rows, n3 = lib.mr_attention_bwd_colsum_rows(nseq, S), dqkv.shape[1]
+        assert colsum_ws.dtype == F32 and colsum_ws.numel() >= rows * n3
+        cs = colsum_ws[:rows * n3].view(rows, n3)
+    check(lib.mr_attention_bwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                               delta.data_ptr(), dqkv.data_ptr(), _ptr(rot_tab), rr, _ptr(cs), nseq, S, nh, _stream()),
           'mr_attention_bwd')
+    if cs is not None:
+        jobs.append(_lib.ReduceJob(cs.data_ptr(), cs.shape[0], cs.shape[1], cs.shape[1], bias_grad.data_ptr(), bias_grad.data_ptr()))
     return dqkv
 
 

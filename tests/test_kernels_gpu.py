@@ -250,10 +250,18 @@ def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
     g = qr.grad
     for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
         assert_close(dqkv[:, sl], g[:, sl], 1.5e-2, f'attn {name}')
-    # rotary-scale on the way out
+    # rotary-scale on the way out, with the qkv bias gradient (column sums of the stored dqkv) folded into the kernels
+    from merlot_reserve_amd import _lib
     tab = torch.rand(S, 32, device=dev) * 2 - 1
     dq2 = torch.zeros_like(qkv)
-    ops.attention_bwd(qkv, code, out, dout, lse, delta, dq2, tab, nseq, S, nh)
+    rows = _lib.load().mr_attention_bwd_colsum_rows(nseq, S)
+    ws = torch.full((rows * 3 * H,), float('nan'), device=dev)
+    bias_grad = torch.zeros(3 * H, dtype=BF16, device=dev)
+    jobs = []
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dq2, tab, nseq, S, nh, colsum_ws=ws, bias_grad=bias_grad, jobs=jobs)
+    ops.reduce_partials(jobs)
+    assert torch.isfinite(ws).all()                                   # every partial written
+    assert_close(bias_grad, dq2.float().sum(0), 6e-3, 'attn fused qkv bias gradient')
     scale = torch.ones(nseq * S, 3 * H, device=dev)
     rows = torch.arange(nseq * S, device=dev) % S
     for h in range(2 * nh):
