@@ -152,6 +152,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // One unit of work: an output tile (and, under split-K, one K range of it).
 struct Item {
     int pi, m0, n0, kt0, nkt, split;
+    int slot;          // stream-K: >= 0 = a PARTIAL k-range of the tile: raw fp32 accumulators go to slab `slot` of the workspace
     bool valid;
 };
 
@@ -166,14 +167,24 @@ struct G256Args {
     // slice of B stays L2-resident while its A strips stream through.  (With the plain row-major order every XCD swept
     // all of B once per round of 256 tiles: rocprofv3 FETCH_SIZE showed 6x the operand bytes leaving L2 per launch.)
     int xmode, px, py, tm, tn;
+    // Stream-K (grouped weight gradients: 216 tiles of 241 k-tiles on 256 CUs, or 192 on 256 for the large model, used 84 % /
+    // 75 % of the chip for one round): the tiles' k-tiles form ONE sequence of `nwork * sk_nkt` units cut into gridDim.x equal
+    // ranges, one per workgroup.  A workgroup's range covers the tail of one tile, whole tiles, and the head of another; a
+    // k-range that is not a whole tile leaves its raw fp32 accumulators in slab 2 * wg + (first item ? 0 : 1) of sk_ws
+    // ([256][BN] each), and streamk_fixup_kernel sums a split tile's slabs in workgroup order (fixed order: reproducible).
+    // (xmode == 2 selects it; the k-tiles per tile are kt_per_split, the slabs live in p[0].workspace: no extra fields -- at
+    // 1024 bytes instead of 1000 the by-value kernel argument was copied to scratch and every variant spilled)
     int tiles_n[MAXG], tile_start[MAXG + 1];
     mr_gemm_args p[MAXG];
 };
 
 constexpr int XPANEL = 8;
-__device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
+// stream-K constants of one workgroup (computed once, at kernel entry: the divisions stay out of the k-loop)
+struct SkRange { int u0, u1, tfirst; };
+__device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int bperm, const SkRange& sk) {
     Item it;
-    if (ga.xmode) {
+    it.slot = -1;
+    if (ga.xmode == 1) {
         const int r = w >> 8, bp = w & 255, x = bp >> 5, sl = bp & 31;     // w = bperm + r * 256, bperm = xcd * 32 + slot
         const int xi = x / ga.py, xj = x - xi * ga.py;
         const int m_lo = xi * ga.tm / ga.px, hm = (xi + 1) * ga.tm / ga.px - m_lo;
@@ -192,17 +203,39 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn) {
         it.nkt = (int)((ga.p[0].K + BK - 1) / BK);
         return it;
     }
-    it.valid = w < ga.nwork;
-    const int tile = (ga.splits == 1) ? w : w / ga.splits;
-    it.split = w - tile * ga.splits;
+    // plain / split-K / stream-K share ONE decode of (tile -> problem, m0, n0): a second copy of these dynamically indexed reads
+    // of the by-value argument made the compiler spill the whole 1000-byte struct to scratch
+    int tile, k0 = 0, k1 = 0;
+    const bool sk_mode = ga.xmode == 2;
+    if (sk_mode) {
+        const int q = (w - bperm) >> 8;                          // the workgroup's q-th item (stream-K grids have 256 workgroups)
+        const int nkt = ga.kt_per_split;
+        tile = sk.tfirst + q;
+        const int tb = tile * nkt;
+        it.valid = tb < sk.u1;
+        k0 = (q == 0) ? sk.u0 - tb : 0;
+        k1 = (sk.u1 - tb < nkt) ? sk.u1 - tb : nkt;
+        it.split = 0;
+        if (k0 != 0 || k1 != nkt) it.slot = 2 * bperm + (q == 0 ? 0 : 1);
+        if (!it.valid) tile = 0;
+    } else {
+        it.valid = w < ga.nwork;
+        tile = (ga.splits == 1) ? w : w / ga.splits;
+        it.split = w - tile * ga.splits;
+    }
     it.pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
     const int lt = tile - ga.tile_start[it.pi], tn = ga.tiles_n[it.pi];
     it.m0 = (lt / tn) * BM;
     it.n0 = (lt % tn) * bn;
-    const int nk_all = (int)((ga.p[it.pi].K + BK - 1) / BK);
-    it.kt0 = it.split * ga.kt_per_split;
-    const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
-    it.nkt = kt1 - it.kt0;
+    if (sk_mode) {
+        it.kt0 = k0;
+        it.nkt = k1 - k0;
+    } else {
+        const int nk_all = (int)((ga.p[it.pi].K + BK - 1) / BK);
+        it.kt0 = it.split * ga.kt_per_split;
+        const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
+        it.nkt = kt1 - it.kt0;
+    }
     return it;
 }
 
@@ -229,7 +262,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     const int splits = ga.splits;
-#define GET_ITEM(w) make_item(ga, (w), BN)
+    SkRange skr = {0, 0, 0};
+    if (ga.xmode == 2) {       // units = (tile, k-tile) pairs; this workgroup's range [u0, u1) (G = 256; units < 2^31 checked on the host)
+        const int64_t U = (int64_t)ga.nwork * ga.kt_per_split;
+        skr.u0 = (int)((int64_t)bperm * U / G);
+        skr.u1 = (int)((int64_t)(bperm + 1) * U / G);
+        skr.tfirst = skr.u0 / ga.kt_per_split;
+    }
+#define GET_ITEM(w) make_item(ga, (w), BN, bperm, skr)
 
     // ---- issue cursors (one per operand): run ahead of the compute cursor, across item boundaries ----
     int iwa = bperm, ika = 0, ista = 0, iwb = bperm, ikb = 0, istb = 0;
@@ -360,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int e_rot_rows = (int)pc.rot_rows, e_rot_cols = (int)pc.rot_cols;
         const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
         const bool do_act = (pc.act == MR_ACT_GELU1702);
-        const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
+        const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16) && ci.slot < 0;
         const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;   // BN = 96 never gets a rot_tab (host)
         const void* const dummy = pc.A;
         float* const e_cs = static_cast<float*>(pc.colsum);
@@ -501,7 +541,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         if (!epi_bf16) {
             // split-K partials and fp32 outputs (contrastive logits): rare, small; direct loads / scalar stores
             const mr_gemm_args& p = ga.p[ci.pi];
-            if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
+            if (ci.slot >= 0) {  // stream-K partial: raw fp32 accumulators into the workgroup's slab, tile-local [256][BN]
+                float* Wp = static_cast<float*>(ga.p[0].workspace) + (int64_t)ci.slot * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wm * 64 + i * 16 + li;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(Wp + r * BN + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
+                }
+            } else if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
                 float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 // every flag dynamic and would hold all of these live at once.)
                 // column sums of the stored tile (the bias gradient: see mr_gemm_args.colsum), aux mode only: that epilogue waits
                 // on memory, the extra vector work hides under it
-                constexpr bool CS = MODE == 4;
+                constexpr bool CS = MODE == 4 && BN != 256;     // (the host takes 192-wide tiles when column sums are asked for: beside 128 accumulators they spill)
                 const bool f_cs = CS && e_cs != nullptr;
                 f32x4 cs[CS ? NJ : 1];
                 if constexpr (CS) {
@@ -767,6 +815,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
     }
 }
 
+// Stream-K second pass: one workgroup per output tile; a tile that one workgroup computed whole was stored by it and is skipped.
+template <int BN>
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const G256Args ga, int G) {
+    const int tile = blockIdx.x;
+    const int64_t nkt = ga.kt_per_split, U = (int64_t)ga.nwork * nkt;
+    const int64_t tb = (int64_t)tile * nkt, te = tb + nkt;
+    auto u0 = [&](int64_t c) { return c * U / G; };
+    int c = (int)(tb * G / U);
+    while (c > 0 && u0(c) > tb) --c;
+    while (u0(c + 1) <= tb) ++c;                               // c = the workgroup whose range holds the tile's first k-tile
+    if (u0(c) <= tb && u0(c + 1) >= te) return;                 // whole tile in one range: already stored
+    const int pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
+    const mr_gemm_args& p = ga.p[pi];
+    const int lt = tile - ga.tile_start[pi], tn = ga.tiles_n[pi];
+    const int m0 = (lt / tn) * BM, n0 = (lt % tn) * BN;
+    __bf16* C = static_cast<__bf16*>(p.C);
+    for (int e = threadIdx.x; e < BM * BN / 4; e += 256) {
+        const int r = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int cc = c; cc < G && u0(cc) < te; ++cc) {         // contributors in workgroup order
+            const int q = tile - (int)(u0(cc) / nkt);
+            const float* slab = static_cast<const float*>(ga.p[0].workspace) + (int64_t)(2 * cc + (q == 0 ? 0 : 1)) * (BM * BN);
+            sum += *reinterpret_cast<const f32x4*>(slab + r * BN + c4);
+        }
+        const int64_t m = m0 + r, n = n0 + c4;
+        if (m < p.M && n < p.N) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (__bf16)sum[k];
+            *reinterpret_cast<bf16x4*>(C + m * p.ldc + n) = o;
+        }
+    }
+}
+
 template <int BN>
 static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
     dim3 block(512);
@@ -782,6 +864,7 @@ static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
 constexpr int64_t NUM_CU = 256;    // MI355X
 extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
 extern int g_mr_opt_group_tile_n;  // mr_set_option("gemm_group_tile_n")
+extern int g_mr_opt_group_streamk; // mr_set_option("gemm_group_streamk"): -1 = environment / default (off)
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -905,7 +988,29 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         can256 = can256 && list[k].N % 256 == 0;
     }
     int bn = (can256 && ((t256 + NUM_CU - 1) / NUM_CU) * c256_cost < ((t128 + NUM_CU - 1) / NUM_CU) * 100) ? 256 : 128;
-    if (g_mr_opt_group_tile_n == 128 || (g_mr_opt_group_tile_n == 256 && can256)) bn = g_mr_opt_group_tile_n;
+    // Stream-K (see G256Args), OPT-IN (MR_G256_STREAMK=1 / mr_set_option("gemm_group_streamk", 1)): when the tiles leave > 8 % of
+    // the CU-rounds idle, the problems share one K and the caller's workspace holds two [256][BN] fp32 slabs per workgroup.
+    // Measured on the base model's weight gradients (round 2): 315 us against 165 us for the plain one-tile-per-CU schedule.
+    // With K = 15 424 every workgroup of the plain schedule walks K in lockstep with the other tiles of its row / column, so
+    // an operand strip is fetched once per XCD; stream-K puts neighbouring workgroups at DIFFERENT k offsets of the same tile,
+    // nothing is shared, and the launch fetches 1.7 GB instead of 0.53 GB -- HBM-bound.  Kept for shapes with short K.
+    static int sk_env = -1;
+    if (sk_env < 0) { const char* e = getenv("MR_G256_STREAMK"); sk_env = e ? atoi(e) : 0; }
+    if (g_mr_opt_group_streamk >= 0) sk_env = g_mr_opt_group_streamk;
+    bool same_k = true;
+    for (int k = 1; k < count; ++k) same_k = same_k && list[k].K == list[0].K;
+    bool streamk = false;
+    if (sk_env && same_k && list[0].workspace != nullptr) {
+        const int sbn = can256 ? 256 : 128;
+        const int64_t st = can256 ? t256 : t128, nk = (list[0].K + g256::BK - 1) / g256::BK;
+        const double eff = (double)st / (double)(((st + NUM_CU - 1) / NUM_CU) * NUM_CU);
+        const int64_t need = 2 * NUM_CU * (int64_t)g256::BM * sbn * (int64_t)sizeof(float);
+        if ((eff < 0.92 || sbn != bn) && st * nk >= 8 * NUM_CU && list[0].workspace_bytes >= need) { streamk = true; bn = sbn; }
+    }
+    if (g_mr_opt_group_tile_n == 128 || (g_mr_opt_group_tile_n == 256 && can256)) {
+        if (bn != g_mr_opt_group_tile_n) streamk = false;       // a forced width (tests, A/B): the plain schedule
+        bn = g_mr_opt_group_tile_n;
+    }
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     int64_t tiles = 0;
@@ -922,6 +1027,18 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         if (nk > nk_max) nk_max = nk;
     }
     ga.count = count; ga.nwork = (int)tiles; ga.splits = 1; ga.kt_per_split = (int)nk_max;
+    if (streamk) {
+        ga.xmode = 2;
+        dim3 grid((unsigned)NUM_CU);
+        if (bn == 256) {
+            g256::launch<256>(ga, grid, s);
+            hipLaunchKernelGGL(g256::streamk_fixup_kernel<256>, dim3((unsigned)tiles), dim3(256), 0, s, ga, (int)NUM_CU);
+        } else {
+            g256::launch<128>(ga, grid, s);
+            hipLaunchKernelGGL(g256::streamk_fixup_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, s, ga, (int)NUM_CU);
+        }
+        return true;
+    }
     dim3 grid((unsigned)(tiles < NUM_CU ? tiles : NUM_CU));
     if (bn == 256) g256::launch<256>(ga, grid, s);
     else g256::launch<128>(ga, grid, s);
