@@ -89,7 +89,8 @@ class TowerEngine:
     # tower-level deferred reductions: between _begin_tower_reductions() and _flush_tower_reductions() every LayerNorm /
     # colsum issued through _t_ln_bwd / _t_colsum leaves its partial rows in a workspace of its own
     def _begin_tower_reductions(self):
-        return {'jobs': None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else [], 'ln': 0, 'cs': 0, 'sc': self.cur}
+        off = os.environ.get('MR_NO_BATCH_REDUCE') == '1' or os.environ.get('MR_NO_TOWER_DEFER') == '1'      # (A/B switches)
+        return {'jobs': None if off else [], 'ln': 0, 'cs': 0, 'sc': self.cur}
 
     def _t_ln_bwd(self, tr, *a, **k):
         if tr is None or tr['jobs'] is None:

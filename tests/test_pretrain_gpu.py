@@ -225,10 +225,13 @@ def test_fp32_forward_parity_1e3(dev, hidden_size, B):
 
 
 def test_training_reduces_the_contrastive_loss(dev):
-    """100 graph-replayed steps on two alternating tiny batches: the contrastive loss falls well below its chance level
+    """300 graph-replayed steps on two alternating tiny batches: the contrastive loss falls well below its chance level
     (7.34 = sum over objectives of ln(#candidates)): forward, backward and the folded optimizer work together over many
     steps.  (text_to_audio and stuff_to_span are memorised; imgs_to_audio stays at chance on iid-noise frames, whose ViT
-    embeddings are nearly identical.)"""
+    embeddings are nearly identical.)  The descent goes plateau by plateau (6.0 -> 5.6 -> 5.2 -> 4.6 ...) and WHEN a
+    plateau is left is sensitive to single-ulp differences of bf16 gradients (scripts/step_ab.py: three reduction
+    schedules with gradients equal to 1 ulp in < 10 elements reach 6.03 / 5.97 / 5.65 after 100 steps and 4.51 / 4.21 /
+    4.59 after 300), so the bound is on the 300-step value, which every schedule passes with margin."""
     from merlot_reserve_amd.config import tiny_config
     from merlot_reserve_amd.synthetic import make_batch
     from merlot_reserve_amd.trainer import Trainer
@@ -242,13 +245,13 @@ def test_training_reduces_the_contrastive_loss(dev):
     first = tr.loss_info()['loss']
     tr.capture(batches[0])
     hist = []
-    for i in range(100):
+    for i in range(300):
         tr.train_step_graph(batches[i % 2], plans[i % 2])
-        if i % 10 == 9:
+        if i % 20 == 19:
             hist.append(tr.loss_info()['loss'])
     assert all(np.isfinite(hist)), hist
-    assert hist[-1] < 0.8 * first, (first, hist)
-    assert tr.state.step == 101
+    assert hist[4] < 0.9 * first and hist[-1] < 0.75 * first, (first, hist)
+    assert tr.state.step == 301
 
 
 def _full_size_config(case):
