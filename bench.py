@@ -174,7 +174,22 @@ def main():
 
     run(1, graph=False)                                        # eager step: allocates every buffer
     if use_graph:
-        trainer.capture(batches[0])
+        ok = 1
+        try:
+            trainer.capture(batches[0])
+        except Exception as e:                                   # (never seen with one rank; a multi-rank capture cannot be rehearsed on a 1-GPU box)
+            if comm is None:
+                raise
+            print(f'[rank {rank}] hipGraph capture of the step failed ({e}); stepping eagerly', file=sys.stderr)
+            ok = 0
+        if dist is not None:                                     # every rank must take the same path
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if not ok:
+            use_graph, trainer.graph = False, None
+            trainer.engine.plan_frozen = False
+            torch.cuda.synchronize()
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -227,6 +242,15 @@ def main():
         breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in ops.FAMILY_PROFILE.items()}
         launches = {k: len(v) // nprof for k, v in ops.FAMILY_PROFILE.items()}
         breakdown['gemm'], launches['gemm'] = round(ms_x / nprof, 3), len(ops.GEMM_PROFILE) // nprof
+        if os.environ.get('MR_BENCH_GEMM_SHAPES'):      # diagnostic: per-shape totals of the exclusive pass -> text file
+            agg = {}
+            for e0, e1, fl_, tag in ops.GEMM_PROFILE:
+                a = agg.setdefault(tag, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl_
+            with open(os.environ['MR_BENCH_GEMM_SHAPES'], 'w') as f:
+                f.write('# (M, N, K, transA, transB, bias, rot, c2, act, residual, aux) | (grouped, n, K): launches/step ms/step avg_us TFLOP/s\n')
+                for tag, (n_, ms_, fl_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f'{str(tag):70s} {n_ // nprof:4d} {ms_ / nprof:7.3f} {ms_ / n_ * 1e3:8.1f} {fl_ / ms_ / 1e9:7.1f}\n')
         ops.GEMM_PROFILE, ops.FAMILY_PROFILE = None, None
         del os.environ['MR_NO_SIDE_STREAM']
         breakdown = {'ms_per_step': breakdown, 'launches_per_step': launches, 'sum_ms': round(sum(breakdown.values()), 3),

@@ -33,6 +33,11 @@
 #else
 #define MR_DMA(...) __builtin_amdgcn_raw_ptr_buffer_load_lds(__VA_ARGS__)
 #endif
+#ifdef MR_DIAG_NOSTORE     /* timing-only build (no output): the bf16 epilogue computes everything and stores nothing */
+#define MR_DIAG_ST(c) ((c) && ga.nwork < 0)
+#else
+#define MR_DIAG_ST(c) (c)
+#endif
 #ifdef MR_DIAG_STAMPS
 #define MR_STAMP(slot)                                                                              \
     do {                                                                                            \
@@ -47,7 +52,13 @@
 namespace g256 {
 
 constexpr int BM = 256, BK = 64;
-constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
+// NW = waves per workgroup.  8 (the kernels above: one 512-thread workgroup per CU, BK = 64) or 4: 256 x 128 tiles, BK = 32,
+// 72 KiB of LDS, TWO workgroups per CU (still two waves per SIMD, 256 registers each).  The two workgroups of a CU are
+// independent: one's barrier waits, fragment-read latencies and -- above all -- its epilogue (loads, GELU, stores: 25-30 % of a
+// K = 768 tile) run under the other's MFMAs instead of leaving the matrix pipe idle.  Per wave and k-step the counts are those
+// of the 8-wave 128-wide kernel (4 A pieces + 2 B pieces, 32 MFMAs); the price is 1.5x the LDS-DMA bytes per FLOP of a
+// 256 x 256 tile.
+constexpr int bk_of(int NW) { return NW == 8 ? 64 : 32; }
 // B is staged 128 wide (BN = 128 | 96: 48-KiB stages, 3-stage ring, two k-tiles ahead) or 256 wide (BN = 256: 64-KiB
 // stages, 2-stage ring, one k-tile ahead).  The k-loop is bound by the LDS-DMA fill rate of a CU (~60-70 GB/s measured
 // with the MFMAs compiled out), so the 256 x 256 tile -- 2/3 of the bytes per FLOP -- is the fast one wherever the
@@ -55,9 +66,12 @@ constexpr int STAGE_A = BM * BK * 2;        // 32 KiB
 // BN = 192 uses the 256-wide geometry with the B columns beyond 192 left to the buffer descriptor's zero fill (no L2
 // traffic): 244 tiles instead of 183 for M = 15424, N = 768 -- one full round of the 256 CUs -- at 3/4 of the MFMAs
 // and 7/8 of the bytes of a 256-wide tile.
-template <int BN> struct Geo {
+template <int BN, int NW = 8> struct Geo {
+    static_assert(NW == 8 || (NW == 4 && BN == 128), "4-wave workgroups: 256 x 128 tiles only");
+    static constexpr int BKT = bk_of(NW);
     static constexpr int BW = (BN > 128) ? 256 : 128;
-    static constexpr int STAGE_B = BW * BK * 2;
+    static constexpr int STAGE_A = BM * BKT * 2;           // 32 KiB (16 KiB with 4 waves)
+    static constexpr int STAGE_B = BW * BKT * 2;
     // Two rings.  A (32 KiB per k-tile) always runs TWO k-tiles ahead of the MFMAs in 3 stages.  B runs two ahead in 3
     // stages when it is 128 wide (144 KiB in all) and ONE ahead in 2 stages when it is 256 wide (96 + 64 = 160 KiB, all of
     // the LDS): the B pieces of k-tile t+1 are issued first in step t and must have landed by its end, the A pieces of
@@ -69,12 +83,13 @@ template <int BN> struct Geo {
     static constexpr int NSTAGE_B = B_AHEAD + 1;
     static constexpr int OFF_B = NSTAGE_A * STAGE_A;
     static constexpr int LDS_BYTES = OFF_B + NSTAGE_B * STAGE_B;
-    static constexpr int NBP = BW / 64;                    // 1-KiB B pieces per wave and k-tile
+    static constexpr int NBP = STAGE_B / 1024 / NW;        // 1-KiB B pieces per wave and k-tile (A: always 4)
+    static_assert(STAGE_A / 1024 / NW == 4, "4 A pieces per wave");
     // pieces of one step that may still be in flight behind its barrier: the step's A pieces, plus its B pieces when B
     // also runs two ahead
     static constexpr int WAITN = 4 + (B_AHEAD == 2 ? NBP : 0);
 };
-static_assert(Geo<256>::LDS_BYTES == 160 * 1024 && Geo<128>::LDS_BYTES == 144 * 1024, "LDS budget");
+static_assert(Geo<256>::LDS_BYTES == 160 * 1024 && Geo<128>::LDS_BYTES == 144 * 1024 && Geo<128, 4>::LDS_BYTES == 72 * 1024, "LDS budget");
 constexpr unsigned OOB = 0x80000000u;      // >= any operand extent (< 2^31 B, checked on the host); + soffset cannot wrap
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -85,9 +100,20 @@ __device__ __forceinline__ int swz_ks(int k) { return 2 * ((k & 3) + 4 * ((k >> 
 // byte offset (into the operand's buffer, for k-tile 0) of the 16-byte chunk that lane `lane` of piece `p` fetches.
 // The k-tile advance is a wave-uniform scalar offset (128 B per k-tile for K-contiguous, 64 rows for K-strided), and
 // k-rows past K fall beyond the operand's extent, so validity does not depend on the k-tile.
-template <bool TR, int W>
+// K-contiguous tile with BK = 32 ([rows][32 k], 64-B rows, 16 rows per piece): chunk ^= (-(row >> 2)) & 3.  ds_read_b128 serves
+// a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (16 lanes = 256 B per LDS cycle); with fragment lane
+// (i, g) reading row i, chunk g, this XOR gives every such group 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz_k32(int row) { return (-(row >> 2)) & 3; }
+
+template <bool TR, int W, int BKT = 64>
 __device__ __forceinline__ unsigned piece_src(int p, int lane, int64_t ld, int64_t own0, int64_t own_n) {
-    if (!TR) {
+    if (!TR && BKT == 32) {
+        const int row = p * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz_k32(row);
+        const int64_t grow = own0 + row;
+        if (grow >= own_n) return OOB;
+        return (unsigned)((grow * ld + chunk * 8) * 2);
+    } else if (!TR) {
         const int row = p * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz_kc(row);
         const int64_t grow = own0 + row;
@@ -111,10 +137,13 @@ __device__ __forceinline__ unsigned piece_src(int p, int lane, int64_t ld, int64
 #define PRE_LOAD_B64(dst, ptr) (dst) = *reinterpret_cast<const u32x2*>(ptr)
 __device__ __forceinline__ void reg_fence(u32x2& v) { asm volatile("" : "+v"(v)); }
 
-template <bool TR, int W>
+template <bool TR, int W, int BKT = 64>
 __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int lane) {
     const int g = lane >> 4, i = lane & 15;
-    if (!TR) {
+    if (!TR && BKT == 32) {
+        const int row = own0 + i;
+        return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((g ^ swz_k32(row)) << 4));
+    } else if (!TR) {
         const int row = own0 + i;
         return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((kk * 4 + g) ^ swz_kc(row)) << 4));
     } else {
@@ -181,15 +210,17 @@ struct G256Args {
 constexpr int XPANEL = 8;
 // stream-K constants of one workgroup (computed once, at kernel entry: the divisions stay out of the k-loop)
 struct SkRange { int u0, u1, tfirst; };
+template <int BKT, int GSH>     // GSH = log2(workgroups of a full grid): 8, or 9 for the two-per-CU kernel
 __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int bperm, const SkRange& sk) {
     Item it;
     it.slot = -1;
     if (ga.xmode == 1) {
-        const int r = w >> 8, bp = w & 255, x = bp >> 5, sl = bp & 31;     // w = bperm + r * 256, bperm = xcd * 32 + slot
+        constexpr int PX = 1 << (GSH - 3);                                 // workgroups per XCD
+        const int r = w >> GSH, bp = w & ((1 << GSH) - 1), x = bp / PX, sl = bp % PX;     // w = bperm + r * 256, bperm = xcd * 32 + slot
         const int xi = x / ga.py, xj = x - xi * ga.py;
         const int m_lo = xi * ga.tm / ga.px, hm = (xi + 1) * ga.tm / ga.px - m_lo;
         const int n_lo = xj * ga.tn / ga.py, hn = (xj + 1) * ga.tn / ga.py - n_lo;
-        const int q = r * 32 + sl;
+        const int q = r * PX + sl;
         it.valid = q < hm * hn;
         const int gw = hn < XPANEL ? hn : XPANEL;
         const int panel = q / (hm * gw), rem = q - panel * hm * gw;
@@ -200,7 +231,7 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
         it.m0 = (m_lo + m) * BM;
         it.n0 = (n_lo + n) * bn;
         it.kt0 = 0;
-        it.nkt = (int)((ga.p[0].K + BK - 1) / BK);
+        it.nkt = (int)((ga.p[0].K + BKT - 1) / BKT);
         return it;
     }
     // plain / split-K / stream-K share ONE decode of (tile -> problem, m0, n0): a second copy of these dynamically indexed reads
@@ -231,7 +262,7 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
         it.kt0 = k0;
         it.nkt = k1 - k0;
     } else {
-        const int nk_all = (int)((ga.p[it.pi].K + BK - 1) / BK);
+        const int nk_all = (int)((ga.p[it.pi].K + BKT - 1) / BKT);
         it.kt0 = it.split * ga.kt_per_split;
         const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
         it.nkt = kt1 - it.kt0;
@@ -239,21 +270,24 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
     return it;
 }
 
-template <int BN, bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
-    constexpr int NJ = BN / 32;                  // 16-col MFMA tiles per wave (wave tile = 64 x BN/2)
-    constexpr int BW = Geo<BN>::BW, NBP = Geo<BN>::NBP, STAGE_B = Geo<BN>::STAGE_B, OFF_B = Geo<BN>::OFF_B;
-    constexpr int NSTAGE_A = Geo<BN>::NSTAGE_A, NSTAGE_B = Geo<BN>::NSTAGE_B, B_AHEAD = Geo<BN>::B_AHEAD;
-    constexpr int WAITN = Geo<BN>::WAITN;
+template <int BN, bool TA, bool TB, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) {
+    using GEO = Geo<BN, NW>;
+    constexpr int BKT = GEO::BKT, STAGE_A = GEO::STAGE_A;
+    constexpr int WCOLS = (NW == 8) ? BN / 2 : BN;       // wave tile = 64 x WCOLS: waves 4 x 2 (8 waves) or 4 x 1
+    constexpr int NJ = WCOLS / 16;                       // 16-col MFMA tiles per wave
+    constexpr int BW = GEO::BW, NBP = GEO::NBP, STAGE_B = GEO::STAGE_B, OFF_B = GEO::OFF_B;
+    constexpr int NSTAGE_A = GEO::NSTAGE_A, NSTAGE_B = GEO::NSTAGE_B, B_AHEAD = GEO::B_AHEAD;
+    constexpr int WAITN = GEO::WAITN;
     // Epilogue operands: fetched EARLY (top of the last k-tile, see PRE_LOAD_B64) by the 128 / 96-wide variants; the 256 /
     // 192-wide ones have no registers to park them in and load them in the epilogue itself, row block by row block.
-    constexpr bool EARLY = BN <= 128;
+    constexpr bool EARLY = NJ <= 4;
     constexpr int NPRE = EARLY ? 4 * NJ : 1;
-    __shared__ __attribute__((aligned(16))) char smem[Geo<BN>::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[GEO::LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: LDS-DMA bases stay scalar
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (NW == 8) ? wave >> 1 : wave, wn = (NW == 8) ? wave & 1 : 0;
     const int g = lane >> 4, li = lane & 15;
 
     // PERSISTENT workgroups: block b handles work items b', b' + G, ... where b' is the XCD-aware permutation of b
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         skr.u1 = (int)((int64_t)(bperm + 1) * U / G);
         skr.tfirst = skr.u0 / ga.kt_per_split;
     }
-#define GET_ITEM(w) make_item(ga, (w), BN, bperm, skr)
+#define GET_ITEM(w) make_item<BKT, (NW == 8 ? 8 : 9)>(ga, (w), BN, bperm, skr)
 
     // ---- issue cursors (one per operand): run ahead of the compute cursor, across item boundaries ----
     int iwa = bperm, ika = 0, ista = 0, iwb = bperm, ikb = 0, istb = 0;
@@ -282,11 +316,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int64_t lda_ = q_.lda, M_ = q_.M, K_ = q_.K;                                                              \
         const int64_t a_rows = TA ? K_ : M_, a_cols = TA ? M_ : K_;                                                     \
         ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.A), 0, (int)(((a_rows - 1) * lda_ + a_cols) * 2), 0x00020000); \
-        a_step = TA ? (unsigned)(BK * lda_ * 2) : (unsigned)(BK * 2);                                                   \
-        ao0 = piece_src<TA, 256>(wave * 4 + 0, lane, lda_, ia.m0, M_);                                                  \
-        ao1 = piece_src<TA, 256>(wave * 4 + 1, lane, lda_, ia.m0, M_);                                                  \
-        ao2 = piece_src<TA, 256>(wave * 4 + 2, lane, lda_, ia.m0, M_);                                                  \
-        ao3 = piece_src<TA, 256>(wave * 4 + 3, lane, lda_, ia.m0, M_);                                                  \
+        a_step = TA ? (unsigned)(BKT * lda_ * 2) : (unsigned)(BKT * 2);                                                  \
+        ao0 = piece_src<TA, 256, BKT>(wave * 4 + 0, lane, lda_, ia.m0, M_);                                                  \
+        ao1 = piece_src<TA, 256, BKT>(wave * 4 + 1, lane, lda_, ia.m0, M_);                                                  \
+        ao2 = piece_src<TA, 256, BKT>(wave * 4 + 2, lane, lda_, ia.m0, M_);                                                  \
+        ao3 = piece_src<TA, 256, BKT>(wave * 4 + 3, lane, lda_, ia.m0, M_);                                                  \
     } while (0)
 #define SET_OFFSETS_B()                                                                                                 \
     do {                                                                                                                \
@@ -294,13 +328,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
         const int64_t ldb_ = q_.ldb, N_ = q_.N, K_ = q_.K;                                                              \
         const int64_t b_rows = TB ? N_ : K_, b_cols = TB ? K_ : N_;                                                     \
         rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q_.B), 0, (int)(((b_rows - 1) * ldb_ + b_cols) * 2), 0x00020000); \
-        b_step = TB ? (unsigned)(BK * 2) : (unsigned)(BK * ldb_ * 2);                                                   \
+        b_step = TB ? (unsigned)(BKT * 2) : (unsigned)(BKT * ldb_ * 2);                                                  \
         const int64_t nb_ = (BN < BW && ib.n0 + BN < N_) ? ib.n0 + BN : N_;    /* columns the tile really covers */       \
-        bo0 = piece_src<!TB, BW>(wave * NBP + 0, lane, ldb_, ib.n0, nb_);                                               \
-        bo1 = piece_src<!TB, BW>(wave * NBP + 1, lane, ldb_, ib.n0, nb_);                                               \
+        bo0 = piece_src<!TB, BW, BKT>(wave * NBP + 0, lane, ldb_, ib.n0, nb_);                                               \
+        bo1 = piece_src<!TB, BW, BKT>(wave * NBP + 1, lane, ldb_, ib.n0, nb_);                                               \
         if (NBP == 4) {                                                                                                 \
-            bo2 = piece_src<!TB, BW>(wave * NBP + 2, lane, ldb_, ib.n0, nb_);                                           \
-            bo3 = piece_src<!TB, BW>(wave * NBP + 3, lane, ldb_, ib.n0, nb_);                                           \
+            bo2 = piece_src<!TB, BW, BKT>(wave * NBP + 2, lane, ldb_, ib.n0, nb_);                                           \
+            bo3 = piece_src<!TB, BW, BKT>(wave * NBP + 3, lane, ldb_, ib.n0, nb_);                                           \
         }                                                                                                               \
     } while (0)
     // The wave's 4 A pieces / NBP B pieces of the next k-tile of each cursor's sequence (if any).  They are issued between
@@ -421,14 +455,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             // epilogue undoes it with the same two v_permlane16_swap.  8-byte loads touched every line four times.
 #pragma unroll
             for (int jp = 0; jp < NJ / 2; ++jp) {
-                const int gn = ci.n0 + wn * (BN / 2) + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                const int gn = ci.n0 + wn * WCOLS + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
                 const void* src_ = (gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(src_);
                 pre2[(i * NJ + 2 * jp) % NPRE] = u32x2{v[0], v[1]};
                 pre2[(i * NJ + 2 * jp + 1) % NPRE] = u32x2{v[2], v[3]};
             }
             if (NJ & 1) {
-                const int gn = ci.n0 + wn * (BN / 2) + (NJ - 1) * 16 + g * 4;
+                const int gn = ci.n0 + wn * WCOLS + (NJ - 1) * 16 + g * 4;
                 const void* src_ = (gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy;
                 PRE_LOAD_B64(pre2[(i * NJ + NJ - 1) % NPRE], src_);
             }
@@ -444,19 +478,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             // NJ <= 4), so the fragments in flight stay at A(kk) + 2 B halves even for the 128-column waves of BN = 256.
             constexpr int NH = (NJ > 4) ? 2 : 1, JH = NJ / NH;
             bf16x8 af[4];
+            constexpr int UNITS = (BKT / 32) * NH;
 #pragma unroll
-            for (int u = 0; u < 2 * NH; ++u) {
+            for (int u = 0; u < UNITS; ++u) {
                 const int kk = u / NH, h = u % NH;
                 bf16x8 bfr[JH];
                 if (h == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = MR_DIAG_FRAG((frag<TA, 256>(As, wm * 64 + i * 16, kk, lane)));
+                    for (int i = 0; i < 4; ++i) af[i] = MR_DIAG_FRAG((frag<TA, 256, BKT>(As, wm * 64 + i * 16, kk, lane)));
                 }
 #pragma unroll
-                for (int j = 0; j < JH; ++j) bfr[j] = MR_DIAG_FRAG((frag<!TB, BW>(Bs, wn * (BN / 2) + (h * JH + j) * 16, kk, lane)));
+                for (int j = 0; j < JH; ++j) bfr[j] = MR_DIAG_FRAG((frag<!TB, BW, BKT>(Bs, wn * WCOLS + (h * JH + j) * 16, kk, lane)));
                 // the DMA issue rides in the shadow of the fragment reads' latency / the previous unit's MFMAs
                 if (u == 0) ISSUE_B();
-                if (u == NH) ISSUE_A(issued);
+                if (u == UNITS / 2) ISSUE_A(issued);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -504,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             if (EARLY && epi_bf16) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int gn = ci.n0 + wn * (BN / 2) + j * 16 + g * 4;
+                    const int gn = ci.n0 + wn * WCOLS + j * 16 + g * 4;
                     const void* src_ = (e_bias != nullptr && gn < eN) ? (const void*)(e_bias + gn) : dummy;
                     PRE_LOAD_B64(pbias[j], src_);
                 }
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
             for (int k = 0; k < NPRE; ++k) reg_fence(pre2[k]);
         }
         const int m0 = ci.m0, n0 = ci.n0;
-        const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * (BN / 2);
+        const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * WCOLS;
         if (!epi_bf16) {
             // split-K partials and fp32 outputs (contrastive logits): rare, small; direct loads / scalar stores
             const mr_gemm_args& p = ga.p[ci.pi];
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 for (int i = 0; i < 4; ++i) {
                     const int r = wm * 64 + i * 16 + li;
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(Wp + r * BN + wn * (BN / 2) + j * 16 + g * 4) = acc[i][j];
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(Wp + r * BN + wn * WCOLS + j * 16 + g * 4) = acc[i][j];
                 }
             } else if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
                 float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
@@ -611,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 // every flag dynamic and would hold all of these live at once.)
                 // column sums of the stored tile (the bias gradient: see mr_gemm_args.colsum), aux mode only: that epilogue waits
                 // on memory, the extra vector work hides under it
-                constexpr bool CS = MODE == 4 && BN != 256;     // (the host takes 192-wide tiles when column sums are asked for: beside 128 accumulators they spill)
+                constexpr bool CS = MODE == 4 && NJ < 8;     // (the host takes 192-wide tiles when column sums are asked for: beside 128 accumulators they spill)
                 const bool f_cs = CS && e_cs != nullptr;
                 f32x4 cs[CS ? NJ : 1];
                 if constexpr (CS) {
@@ -620,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                 }
                 constexpr bool LATE_X = !EARLY && (MODE == 3 || MODE == 4);
                 constexpr bool LATE_R = !EARLY && MODE == 1 && BN == 192;     // 256-wide: 2 x 8 scale vectors beside 128 accumulators spill
-                constexpr int LXD = (BN == 256) ? 2 : 4;        // row blocks in flight (256-wide: 2, or the tile's 128 accumulators spill)
+                constexpr int LXD = (NJ == 8) ? 2 : 4;       // row blocks in flight (256-wide: 2, or the tile's 128 accumulators spill)
                 u32x4 lx[LATE_X ? LXD : 1][LATE_X ? NJ / 2 : 1];
                 auto lx_fetch = [&](int i, u32x4 (&dst)[LATE_X ? NJ / 2 : 1]) {
                     if constexpr (LATE_X) {
@@ -697,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
                     const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
-                    if (mok && col < eN) *reinterpret_cast<u32x4*>(rowp + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    if (MR_DIAG_ST(mok && col < eN)) *reinterpret_cast<u32x4*>(rowp + col) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 };
     #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -849,14 +884,14 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(const G256Args ga, i
     }
 }
 
-template <int BN>
+template <int BN, int NW = 8>
 static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
-    dim3 block(512);
+    dim3 block(NW * 64);
     const bool ta = ga.p[0].transA, tb = ga.p[0].transB;
-    if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, false>), grid, block, 0, s, ga);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, true>), grid, block, 0, s, ga);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, true, false>), grid, block, 0, s, ga);
-    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true>), grid, block, 0, s, ga);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, false, NW>), grid, block, 0, s, ga);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, true, NW>), grid, block, 0, s, ga);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, true, false, NW>), grid, block, 0, s, ga);
+    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true, NW>), grid, block, 0, s, ga);
 }
 
 }  // namespace g256
@@ -904,11 +939,17 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
         const int64_t t192 = tm * ((a->N + 191) / 192), c192 = ((t192 + 255) / 256) * c192_cost;
         if (can192 && c192 < best) { bn = 192; best = c192; }
     }
-    { const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn; if (f == 96 || f == 128 || (f == 256 && can256) || (f == 192 && can192)) bn = f; }
+    int nw = 8;                 // waves per workgroup: 4 = the two-workgroups-per-CU kernel (256 x 128 tiles, BK = 32)
+    {
+        const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn;
+        if (f == 96 || f == 128 || (f == 256 && can256) || (f == 192 && can192)) bn = f;
+        if (f == 4128 && !a->colsum) { bn = 128; nw = 4; }
+    }
     if (a->rot_tab && bn == 96) bn = 128;
     if (a->colsum && bn == 256 && can192) bn = 192;     // the column-sum accumulators beside a 256-wide tile's 128 accumulators spill (measured: +22 us)
     const int64_t tn = (a->N + bn - 1) / bn;
-    const int64_t nk = (a->K + g256::BK - 1) / g256::BK;
+    const int64_t bk = g256::bk_of(nw), full_grid = (nw == 4) ? 2 * NUM_CU : NUM_CU;
+    const int64_t nk = (a->K + bk - 1) / bk;
     int64_t splits = 1;
     const bool plain = !a->rot_tab && !a->c2 && a->act == MR_ACT_NONE && !a->residual && !a->aux && a->out_grp == 0;
     if (a->workspace && plain && a->N % 4 == 0 && tm * tn < 192 && nk >= 16) {
@@ -922,7 +963,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     int64_t kps = (nk + splits - 1) / splits;
     splits = (nk + kps - 1) / kps;
     const int64_t nwork = tm * tn * splits;
-    int64_t gsz = nwork < NUM_CU ? nwork : NUM_CU;               // persistent: one workgroup per CU
+    int64_t gsz = nwork < full_grid ? nwork : full_grid;         // persistent: one workgroup per CU (two with 4 waves)
     if (grid_mode == 1) gsz = nwork;                             // (experiment) one item per workgroup
     else if (grid_mode > 1) gsz = nwork < grid_mode ? nwork : grid_mode;
     dim3 grid((unsigned)gsz);
@@ -931,7 +972,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     ga.count = 1; ga.nwork = (int)nwork; ga.splits = (int)splits; ga.kt_per_split = (int)kps;
     static int xmode_env = -1;
     if (xmode_env < 0) { const char* e = getenv("MR_G256_XMODE"); xmode_env = e ? atoi(e) : 1; }
-    if (xmode_env && splits == 1 && gsz == NUM_CU && nwork >= 2 * NUM_CU) {
+    if (xmode_env && splits == 1 && gsz == full_grid && nwork >= 2 * full_grid) {
         // choose the XCD partition: fewest rounds first (the slowest XCD sets the time), then least traffic out of L2
         const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
         double best = 1e300;
@@ -942,7 +983,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
             for (int xi = 0; xi < px; ++xi)
                 for (int xj = 0; xj < py; ++xj) {
                     const int64_t hm = (xi + 1) * tm / px - xi * tm / px, hn = (xj + 1) * tn / py - xj * tn / py;
-                    const int64_t r = (hm * hn + 31) / 32;
+                    const int64_t r = (hm * hn + full_grid / 8 - 1) / (full_grid / 8);
                     if (r > rounds) rounds = r;
                 }
             const bool b_fits = b_bytes / py < 2.5e6;         // a cell's B slice stays in the XCD's 4-MiB L2
@@ -958,7 +999,8 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     ga.tile_start[0] = 0;
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
     ga.p[0] = *a;
-    if (bn == 256) g256::launch<256>(ga, grid, s);
+    if (nw == 4) g256::launch<128, 4>(ga, grid, s);
+    else if (bn == 256) g256::launch<256>(ga, grid, s);
     else if (bn == 192) g256::launch<192>(ga, grid, s);
     else if (bn == 128) g256::launch<128>(ga, grid, s);
     else g256::launch<96>(ga, grid, s);

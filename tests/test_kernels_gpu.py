@@ -492,7 +492,7 @@ GEMM256_CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 96, 128, 192, 256])
+@pytest.fixture(params=[0, 96, 128, 192, 256, 4128])      # 4128 = 128-wide tiles, 4-wave workgroups, two per CU
 def tile_n(request):
     """Forces the output-tile width of the 256-row GEMM (0 = the library's own choice) for the duration of a test."""
     from merlot_reserve_amd import _lib
