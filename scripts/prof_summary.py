@@ -9,7 +9,16 @@ K, W = opt('--steps', 10), opt('--warmup', 3)
 steps = 1 + W + K + (0 if "--no-roofline" in args else 2 * min(K, 3)) + (0 if "--no-h2d" in args or "--no-graph" in args else K + 2)
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'cast_params' not in r['Name'])
-print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 2 x {min(K, 3)} instrumented eager') + ')')
+h2d = 0 if "--no-h2d" in args or "--no-graph" in args else K + 2
+print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 2 x {min(K, 3)} instrumented eager')
+      + (f' + {h2d} replays fed from host memory' if h2d else '') + ')')
+if '--bench-log' in args:      # the bench line of the SAME run: under rocprofv3 every dispatch is serialised and stamped, so the step is
+    import json                # slower than un-profiled and ~equal to the kernel sum; the un-profiled step overlaps the towers' tails
+    for line in open(args[args.index('--bench-log') + 1]):
+        if line.startswith('{"metric"'):
+            d = json.loads(line)
+            print(f"# bench.py ms_per_step in this profiled run: {d['ms_per_step']:.2f}.  The kernel sum below need not equal it: launches of the two towers that "
+                  f"overlap on two streams each count the time they share the GPU (sum > step), and rocprofv3's tracing adds ~10 us per dispatch (profiled step > un-profiled step, DESIGN.md section 3)")
 print(f'total kernel ms/step (excl. one-off init): {tot / 1e6 / steps:.2f}')
 fam = {}
 def family(n):

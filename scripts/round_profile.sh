@@ -10,5 +10,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python
 tail -1 $out/bench.log | cut -c1-400
 f=$(ls /tmp/prof_$tag/*/*kernel_stats.csv | head -1)
 cp $f $out/kernel_stats.csv
-python3 $root/scripts/prof_summary.py $out/kernel_stats.csv "$@" > $out/summary.txt
+python3 $root/scripts/prof_summary.py $out/kernel_stats.csv "$@" --bench-log $out/bench.log > $out/summary.txt
 head -40 $out/summary.txt
