@@ -14,8 +14,11 @@
 // Softmax statistics are then per lane (no shuffles except a 4-lane max/sum) and nothing goes through LDS twice.
 //
 // Pipeline: a wave owns 16*QB queries (keys in the dK/dV kernel); the K/V (Q/dO) tiles of the inner loop are double
-// buffered in LDS: the next tile's global loads are issued into registers before the current tile is multiplied and
-// written to the other buffer afterwards -- one barrier per tile, global latency under the MFMAs.
+// buffered in LDS and filled by LDS-DMA (buffer_load ... lds, 4 wave instructions per tile pair): the next tile is requested
+// straight into the other buffer at the top of the iteration and waited for (vmcnt(0)) at its end -- one barrier per tile, no
+// staging registers, no LDS stores, rows past the sequence zero-filled by the buffer descriptor.  (Round 2: the register-staged
+// version's global-load issue and LDS stores were ~1 200 of a tile's ~4 300 wave cycles in the forward kernel, and its 16 staging
+// registers kept that kernel at two waves per SIMD; with three: joint 79.5 -> 68.1 us, ViT 37.3 -> 31.5 us.)
 //
 // Per-score vector work of the BACKWARD kernels (~10 vector instructions per score against 1/16 of an MFMA):
 //   * the 1/8 of "query / sqrt(depth)" is folded into the Q (dQ) or K (dK/dV) fragments once per workgroup --
@@ -31,22 +34,33 @@
 #include <stdlib.h>
 #include "mr_common.h"
 
-// timing-only diagnostic builds (scripts/build_diag.sh; wrong results): -DMR_ATTN_DIAG_NOLOAD keeps re-using the first K / V
-// tile (no global loads, no LDS refills in the loop); -DMR_ATTN_OCC=n sets the waves per SIMD the register allocator targets
+// diagnostic builds (scripts/build_diag.sh): -DMR_ATTN_OCC=n / -DMR_ATTN_OCC_DQ=n set the waves per SIMD the register allocator targets
+// (the forward kernel fits three by itself since its K / V tiles are LDS-DMA staged: 162-168 registers)
+#ifndef MR_ATTN_OCC_DQ      /* dQ kernel: 183-190 registers; forced to three waves per SIMD it spills 15-37 (masked -4 %, unmasked +15 %) */
+#define MR_ATTN_OCC_DQ 2
+#endif
 #ifndef MR_ATTN_OCC
 #define MR_ATTN_OCC 2
 #endif
-#ifdef MR_ATTN_DIAG_NOLOAD
-#define MR_ATTN_MORE(cond) false
+// -DMR_ATTN_STAMPS (diagnostic build): s_memtime stamps of the forward kernel's phases for the first tiles of the first workgroups,
+// into a buffer of their own that mr_diag_attn_stamps() copies out; no stamp executes in the product build
+#ifdef MR_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[512 * 16 * 8];
+#define MR_ASTAMP(slot)                                                                                        \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (lane == 0 && wave == 0 && blockIdx.x < 512 && t < 16) g_attn_stamps[(blockIdx.x * 16 + t) * 8 + (slot)] = t_; \
+    } while (0)
 #else
-#define MR_ATTN_MORE(cond) (cond)
+#define MR_ASTAMP(slot) do {} while (0)
 #endif
 
 namespace {
 
 constexpr int TK = 64;        // inner tile (keys in fwd / dQ, queries in dK/dV)
-constexpr int LDR = 72;       // row-read-only tile stride (elements): 144 B
-constexpr int LDV = 80;       // tiles that are tr-read: 160 B rows (8 rows x 32 B tile the 64 banks)
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float NEG_BIAS = -8589934592.0f;         // -2^33: stands in for the reference's -1e10 bias (see above)
 constexpr float PAD_LSE = 0.25f * NEG_BIAS;        // an LSE below this marks a row with no allowed key
@@ -56,21 +70,6 @@ constexpr int CODE_PADQ = -3;                      // query with no allowed key 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, int col0, int lane) {
-    // rows row0 + 4g + {0..3} and row0 + 16 + 4g + {0..3}; 16 columns from col0; lane receives column (lane & 15)
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const __bf16* a0 = tile + (row0 + 4 * g + q) * ld + col0 + 4 * p;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(MR_LDS_PTR(s16x4, a0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(MR_LDS_PTR(s16x4, a0 + 16 * ld));
-    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, both);
-}
-
-__device__ __forceinline__ bf16x8 row_frag(const __bf16* tile, int ld, int row0, int dd, int lane) {
-    const int g = lane >> 4, i = lane & 15;
-    return *reinterpret_cast<const bf16x8*>(tile + (row0 + i) * ld + dd * 32 + g * 8);
-}
-
 __device__ __forceinline__ bf16x8 pack_acc_pair(const f32x4& a, const f32x4& b) {
     bf16x8 r;
 #pragma unroll
@@ -78,23 +77,38 @@ __device__ __forceinline__ bf16x8 pack_acc_pair(const f32x4& a, const f32x4& b) 
     return r;
 }
 
-// register-staged copy of a [64 rows][64 cols] bf16 tile: 2 x 16 B per thread (256 threads)
-struct TileRegs { u32x4 v[2]; };
-__device__ __forceinline__ void tile_load(const __bf16* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int tid, TileRegs& r) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, rr = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + rr < nrows) v = *reinterpret_cast<const u32x4*>(src + (row0 + rr) * ld + 8 * ch);
-        r.v[it] = v;
-    }
+// ---- LDS-DMA staged tiles (all three kernels).  A [64 rows][64 dims] bf16 tile is an UNPADDED 8-KiB image (LDS-DMA writes 1 KiB per
+// wave instruction, lane-linear: piece p = rows 8p .. 8p+7, lane l = row 8p + (l >> 3), 16-byte slot l & 7), so the bank-conflict
+// padding a register-staged tile would use becomes an XOR on the SOURCE chunk: slot = chunk ^ 2 * ((row >> 1) & 3).  The XOR is even, so the
+// two chunks a ds_read_b64_tr_b16 row segment spans stay adjacent; with it both read forms are conflict-free (checked over the
+// hardware's lane groups: ds_read_b128 rows i = lane & 15 / chunk 4 dd + g, and the transposed 8-byte reads of tr_frag_d_issue).
+// No staging registers, no ds_write, no per-load bounds branch: rows past the sequence lie beyond the buffer descriptor's extent and
+// arrive as zeros.
+constexpr int TILE_B = TK * 64 * 2;      // 8 KiB
+__device__ __forceinline__ int dswz(int row) { return 2 * ((row >> 1) & 3); }
+// byte offset (from the tile's first row, tile 0) of the 16-byte chunk lane `lane` of piece `p` fetches
+__device__ __forceinline__ unsigned dma_src(int p, int lane, int64_t ld) {
+    const int row = p * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ dswz(row);
+    return (unsigned)((row * ld + chunk * 8) * 2);
 }
-__device__ __forceinline__ void tile_store(__bf16* tile, int tld, int tid, const TileRegs& r) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, rr = c >> 3, ch = c & 7;
-        *reinterpret_cast<u32x4*>(tile + rr * tld + 8 * ch) = r.v[it];
-    }
+__device__ __forceinline__ bf16x8 row_frag_d(const char* tile, int row0, int dd, int lane) {
+    const int g = lane >> 4, row = row0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((dd * 4 + g) ^ dswz(row)) << 4));
+}
+// transposed fragment (rows row0 + 4g + {0..3} and row0 + 16 + 4g + {0..3}; 16 columns from col0; lane receives column lane & 15)
+// from a DMA image.  Inline asm: with LDS-DMA in flight hipcc would put s_waitcnt vmcnt(0) in front of
+// the ds_read_tr builtin (it cannot tell it from the DMA's LDS writes) and drain the prefetch; the caller waits with lgkmcnt(0).
+__device__ __forceinline__ void tr_frag_d_issue(const char* tile, int row0, int col0, int lane, s16x4& lo, s16x4& hi) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = row0 + 4 * g + q, col = col0 + 4 * p;
+    const unsigned a0 = (unsigned)(uintptr_t)MR_LDS_PTR(const char, tile + row * 128 + ((((col >> 3)) ^ dswz(row)) << 4) + (col & 7) * 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(a0));       // row + 16: same swizzle
+}
+__device__ __forceinline__ bf16x8 tr_join(const s16x4& lo, const s16x4& hi) {
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
 }
 
 // per-key metadata of tile position k: its code and the bias a query with a DIFFERENT code adds to the score
@@ -178,10 +192,11 @@ template <int QB, bool MASKED>
 __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                           __bf16* __restrict__ out, float* __restrict__ lse,
                                                           int64_t S, int64_t nh) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDR];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDV];
+    __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];          // LDS-DMA images (see dma_src)
+    __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
     const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
@@ -211,41 +226,59 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         for (int db = 0; db < 4; ++db) ot[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // K / V of this (sequence, head): rows beyond S are beyond the descriptors' extent (zero fill); the tile advance is a scalar offset
     const __bf16* Kg = base + H + h * 64;
     const __bf16* Vg = base + 2 * H + h * 64;
+    const int ext = (int)(((S - 1) * ld + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
+    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned tile_step = (unsigned)(TK * ld * 2);
     auto key_code = [&](int64_t k) -> int { return (k < S) ? (MASKED ? code[seq * S + k] : 0) : CODE_NONE; };
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b
+        const unsigned so = (unsigned)t * tile_step;
+        char* kd = Ks[b] + wave * 2048;
+        char* vd = Vs[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
+    };
 
-    TileRegs kr, vr;
     int cr = 0;
-    tile_load(Kg, ld, 0, S, tid, kr);
-    tile_load(Vg, ld, 0, S, tid, vr);
-    if (tid < TK) cr = key_code(tid);
-    tile_store(Ks[0], LDR, tid, kr);
-    tile_store(Vs[0], LDV, tid, vr);
-    if (tid < TK) Cs[0][tid] = cr;
+    stage(0, 0);
+    if (tid < TK) Cs[0][tid] = key_code(tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
     for (int t = 0; t < nt; ++t) {
-#ifdef MR_ATTN_DIAG_NOLOAD
-        const int b = 0;
-#else
         const int b = t & 1;
-#endif
-        if (MR_ATTN_MORE(t + 1 < nt)) {      // next tile: global -> registers, in flight during this tile's MFMAs
-            tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
-            tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
+        MR_ASTAMP(0);
+        if (t + 1 < nt) {      // next tile: straight into the other buffer (last read one iteration ago, behind that iteration's barrier)
+            stage(t + 1, b ^ 1);
             if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
         }
+        MR_ASTAMP(1);
         f32x4 st[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const bf16x8 k0 = row_frag(Ks[b], LDR, kb * 16, 0, lane), k1 = row_frag(Ks[b], LDR, kb * 16, 1, lane);
+            const bf16x8 k0 = row_frag_d(Ks[b], kb * 16, 0, lane), k1 = row_frag_d(Ks[b], kb * 16, 1, lane);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], a, 0, 0, 0);
             }
+        }
+        MR_ASTAMP(2);
+        // the V fragments do not depend on the softmax: the first half (keys 0-31) is requested now and lands while it runs; the
+        // second half after it (its registers are the softmax's), landing under the first half's MFMAs
+        // (the masked variant holds the codes as well and would lose its third wave per SIMD to these 16 registers: it asks late)
+        constexpr bool V_EARLY = !MASKED;
+        s16x4 vlo[2][4], vhi[2][4];
+        if constexpr (V_EARLY) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) tr_frag_d_issue(Vs[b], 0, 16 * db, lane, vlo[0][db], vhi[0][db]);
         }
         i32x4 ck[4];
 #pragma unroll
@@ -282,21 +315,37 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             pf[qb][0] = pack_acc_pair(st[qb][0], st[qb][1]);
             pf[qb][1] = pack_acc_pair(st[qb][2], st[qb][3]);
         }
+        MR_ASTAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!V_EARLY) {
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int db = 0; db < 4; ++db) tr_frag_d_issue(Vs[b], 0, 16 * db, lane, vlo[0][db], vhi[0][db]);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) tr_frag_d_issue(Vs[b], 32, 16 * db, lane, vlo[1][db], vhi[1][db]);
+        // (the compiler does not count the asm reads: explicit waits) everything older than the 8 reads just issued has returned
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            if (t2 == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const bf16x8 vf = tr_frag(Vs[b], LDV, 32 * t2, 16 * db, lane);
+                const bf16x8 vf = tr_join(vlo[t2][db], vhi[t2][db]);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][t2], ot[qb][db], 0, 0, 0);
             }
-        if (MR_ATTN_MORE(t + 1 < nt)) {      // the other buffer was last read one iteration ago, behind that iteration's barrier
-            tile_store(Ks[b ^ 1], LDR, tid, kr);
-            tile_store(Vs[b ^ 1], LDV, tid, vr);
-            if (tid < TK) Cs[b ^ 1][tid] = cr;
         }
+        MR_ASTAMP(4);
+        if (t + 1 < nt && tid < TK) Cs[b ^ 1][tid] = cr;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
+        MR_ASTAMP(5);
         __syncthreads();
+        MR_ASTAMP(6);
     }
     // lane holds O^T[d = 16 db + 4 g + r][query i]: 4 consecutive d of one row -> one 8-byte store per (qb, db)
 #pragma unroll
@@ -320,17 +369,18 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
 
 // ------------------------------------------------------------------------------------------------ dQ (+ delta = rowsum(dO * O))
 template <int QB, bool MASKED>
-__global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                              const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                              __bf16* __restrict__ dqkv, const float* __restrict__ rot_tab,
                                                              int64_t rot_rows, float* __restrict__ colsum, int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) float red[4][64];
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][TK * LDV];   // row reads (S^T) and tr reads (dQ^T)
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][TK * LDR];   // row reads (dP^T)
+    __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];       // LDS-DMA images: row reads (S^T) and tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];       // row reads (dP^T)
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     __shared__ __attribute__((aligned(16))) float Ns[2][TK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
     const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
@@ -388,36 +438,42 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __b
 
     const __bf16* Kg = base + H + h * 64;
     const __bf16* Vg = base + 2 * H + h * 64;
-    TileRegs kr, vr;
+    const int ext = (int)(((S - 1) * ld + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
+    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned tile_step = (unsigned)(TK * ld * 2);
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b (as in the forward kernel)
+        const unsigned so = (unsigned)t * tile_step;
+        char* kd = Ks[b] + wave * 2048;
+        char* vd = Vs[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
+    };
     int cr = 0;
     float nr = 0.f;
-    tile_load(Kg, ld, 0, S, tid, kr);
-    tile_load(Vg, ld, 0, S, tid, vr);
-    if (tid < TK) key_meta(tid, S, code_seq, MASKED, cr, nr);
-    tile_store(Ks[0], LDV, tid, kr);
-    tile_store(Vs[0], LDR, tid, vr);
-    if (tid < TK) { Cs[0][tid] = cr; Ns[0][tid] = nr; }
+    stage(0, 0);
+    if (tid < TK) { key_meta(tid, S, code_seq, MASKED, cr, nr); Cs[0][tid] = cr; Ns[0][tid] = nr; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
     const bool ragged = (S & (TK - 1)) != 0;
     for (int t = 0; t < nt; ++t) {
-#ifdef MR_ATTN_DIAG_NOLOAD
-        const int b = 0;
-#else
         const int b = t & 1;
-#endif
-        if (MR_ATTN_MORE(t + 1 < nt)) {
-            tile_load(Kg, ld, (int64_t)(t + 1) * TK, S, tid, kr);
-            tile_load(Vg, ld, (int64_t)(t + 1) * TK, S, tid, vr);
+        if (t + 1 < nt) {
+            stage(t + 1, b ^ 1);
             if (tid < TK) key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
         }
         const bool need_bias = MASKED || (ragged && t == nt - 1);
-        f32x4 ds[QB][4];
+        f32x4 ds[QB][2];
+        bf16x8 dsf[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const bf16x8 k0 = row_frag(Ks[b], LDV, kb * 16, 0, lane), k1 = row_frag(Ks[b], LDV, kb * 16, 1, lane);
-            const bf16x8 v0 = row_frag(Vs[b], LDR, kb * 16, 0, lane), v1 = row_frag(Vs[b], LDR, kb * 16, 1, lane);
+            const bf16x8 k0 = row_frag_d(Ks[b], kb * 16, 0, lane), k1 = row_frag_d(Ks[b], kb * 16, 1, lane);
+            const bf16x8 v0 = row_frag_d(Vs[b], kb * 16, 0, lane), v1 = row_frag_d(Vs[b], kb * 16, 1, lane);
             i32x4 ck = {0, 0, 0, 0};
             f32x4 nk = {0.f, 0.f, 0.f, 0.f};
             if (need_bias) {
@@ -439,29 +495,35 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dq_kernel(const __b
                     for (int r = 0; r < 4; ++r) pv[r] = padq[qb] ? ((ck[r] == CODE_NONE) ? 0.f : inv_S) : pv[r];
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[qb][kb][r] = pv[r] * (dp[r] - del[qb]);
+                for (int r = 0; r < 4; ++r) ds[qb][kb & 1][r] = pv[r] * (dp[r] - del[qb]);
+                if (kb & 1) dsf[qb][kb >> 1] = pack_acc_pair(ds[qb][0], ds[qb][1]);     // packed pair by pair: 16 fewer live registers
             }
         }
-        bf16x8 dsf[QB][2];
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            dsf[qb][0] = pack_acc_pair(ds[qb][0], ds[qb][1]);
-            dsf[qb][1] = pack_acc_pair(ds[qb][2], ds[qb][3]);
-        }
+        // K^T fragments (asm reads, explicit waits: see tr_frag_d_issue): both halves requested, the second lands under the first's MFMAs
+        s16x4 klo[2][4], khi[2][4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
+            for (int db = 0; db < 4; ++db) tr_frag_d_issue(Ks[b], 32 * t2, 16 * db, lane, klo[t2][db], khi[t2][db]);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            if (t2 == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const bf16x8 kt = tr_frag(Ks[b], LDV, 32 * t2, 16 * db, lane);
+                const bf16x8 kt = tr_join(klo[t2][db], khi[t2][db]);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][t2], dq[qb][db], 0, 0, 0);
             }
-        if (MR_ATTN_MORE(t + 1 < nt)) {
-            tile_store(Ks[b ^ 1], LDV, tid, kr);
-            tile_store(Vs[b ^ 1], LDR, tid, vr);
-            if (tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
         }
+        if (t + 1 < nt && tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     }
     f32x4 cs[4];
@@ -498,12 +560,13 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
                                                               float* __restrict__ colsum, int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) float red[4][64];
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[2][TK * LDV];    // row reads (S) and tr reads (dK^T)
-    __shared__ __attribute__((aligned(16))) __bf16 Ds[2][TK * LDV];    // dO: row reads (dP) and tr reads (dV^T)
+    __shared__ __attribute__((aligned(16))) char Qs[2][TILE_B];        // LDS-DMA images: row reads (S) and tr reads (dK^T)
+    __shared__ __attribute__((aligned(16))) char Ds[2][TILE_B];        // dO: row reads (dP) and tr reads (dV^T)
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     __shared__ int32_t Fs[2];                                          // tile has a row without allowed key
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
     const int64_t seq = ab_.seq, h = ab_.h, kbase = ab_.blk * (64 * KB);
     const int64_t H = nh * 64, ld = 3 * H;
@@ -543,7 +606,19 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     const __bf16* Dg = dout + seq * S * H + h * 64;
     const float* Lg = lse + (seq * nh + h) * S;
     const float* Eg = delta + (seq * nh + h) * S;
-    TileRegs qr, dr;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Dg), 0, (int)(((S - 1) * H + 64) * 2), 0x00020000);
+    const unsigned sq0 = dma_src(wave * 2, lane, ld), sq1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned sd0 = dma_src(wave * 2, lane, H), sd1 = dma_src(wave * 2 + 1, lane, H);
+    const unsigned q_step = (unsigned)(TK * ld * 2), d_step = (unsigned)(TK * H * 2);
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of query tile t (Q rows, dO rows) -> buffer b
+        char* qd = Qs[b] + wave * 2048;
+        char* dd_ = Ds[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd), 16, sq0, (unsigned)t * q_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd + 1024), 16, sq1, (unsigned)t * q_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_), 16, sd0, (unsigned)t * d_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_ + 1024), 16, sd1, (unsigned)t * d_step, 0, 0);
+    };
     float lr = 0.f, er = 0.f, ur = 0.f;
     int cr = 0, fr = 0;
     auto side_load = [&](int64_t q0) {        // wave 0 (tid < TK) stages the 64 queries' scalars
@@ -559,24 +634,17 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
             fr = MASKED ? (int)__any(pad) : 0;
         }
     };
-    tile_load(Qg, ld, 0, S, tid, qr);
-    tile_load(Dg, H, 0, S, tid, dr);
+    stage(0, 0);
     side_load(0);
-    tile_store(Qs[0], LDV, tid, qr);
-    tile_store(Ds[0], LDV, tid, dr);
     if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; Us[0][tid] = ur; if (tid == 0) Fs[0] = fr; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
     for (int t = 0; t < nt; ++t) {
-#ifdef MR_ATTN_DIAG_NOLOAD
-        const int b = 0;
-#else
         const int b = t & 1;
-#endif
-        if (MR_ATTN_MORE(t + 1 < nt)) {
-            tile_load(Qg, ld, (int64_t)(t + 1) * TK, S, tid, qr);
-            tile_load(Dg, H, (int64_t)(t + 1) * TK, S, tid, dr);
+        if (t + 1 < nt) {
+            stage(t + 1, b ^ 1);
             side_load((int64_t)(t + 1) * TK);
         }
         const bool tile_pad = MASKED && Fs[b] != 0;
@@ -586,8 +654,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 const int qb = 2 * t2 + q2;
-                const bf16x8 q0f = row_frag(Qs[b], LDV, qb * 16, 0, lane), q1f = row_frag(Qs[b], LDV, qb * 16, 1, lane);
-                const bf16x8 d0f = row_frag(Ds[b], LDV, qb * 16, 0, lane), d1f = row_frag(Ds[b], LDV, qb * 16, 1, lane);
+                const bf16x8 q0f = row_frag_d(Qs[b], qb * 16, 0, lane), q1f = row_frag_d(Qs[b], qb * 16, 1, lane);
+                const bf16x8 d0f = row_frag_d(Ds[b], qb * 16, 0, lane), d1f = row_frag_d(Ds[b], qb * 16, 1, lane);
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
                 i32x4 c4 = {0, 0, 0, 0};
@@ -624,10 +692,25 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                 pf[kb] = pack_acc_pair(pp[kb][0], pp[kb][1]);
                 dsf[kb] = pack_acc_pair(ds[kb][0], ds[kb][1]);
             }
+            // dO^T / Q^T fragments of this half-tile (asm reads, explicit waits: see tr_frag_d_issue): dims 0-31 and 32-63 as two
+            // groups of 8 reads, the second landing under the first's MFMAs
+            s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const bf16x8 dot = tr_frag(Ds[b], LDV, 32 * t2, 16 * db, lane);
-                const bf16x8 qt = tr_frag(Qs[b], LDV, 32 * t2, 16 * db, lane);
+                tr_frag_d_issue(Ds[b], 32 * t2, 16 * db, lane, dlo[db], dhi[db]);
+                tr_frag_d_issue(Qs[b], 32 * t2, 16 * db, lane, qlo[db], qhi[db]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                if (db == 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bf16x8 dot = tr_join(dlo[db], dhi[db]);
+                const bf16x8 qt = tr_join(qlo[db], qhi[db]);
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], dv[kb][db], 0, 0, 0);
@@ -635,11 +718,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                 }
             }
         }
-        if (MR_ATTN_MORE(t + 1 < nt)) {
-            tile_store(Qs[b ^ 1], LDV, tid, qr);
-            tile_store(Ds[b ^ 1], LDV, tid, dr);
-            if (tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) Fs[b ^ 1] = fr; }
-        }
+        if (t + 1 < nt && tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) Fs[b ^ 1] = fr; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     }
     // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores.  dK: the 1/8 folded into kf was on the OTHER operand
@@ -738,3 +818,12 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     MR_CHECK_LAUNCH("mr_attention_bwd");
     return MR_OK;
 }
+
+#ifdef MR_ATTN_STAMPS
+extern "C" int mr_diag_attn_stamps(unsigned long long* host_out) {      // diagnostic build only
+    (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 512 * 16 * 8);
+    unsigned long long z = 0;
+    (void)z;
+    return 0;
+}
+#endif
