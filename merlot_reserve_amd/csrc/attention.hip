@@ -32,12 +32,16 @@
 // constant -2^33 in the backward kernels (bias * log2 e is exact; a PAD row is recognised by its LSE < PAD_LSE and given
 // P = 1/S); the forward keeps the literal -1e10 (in the exp2 domain), for which every score of a PAD row is the same number.
 #include <stdlib.h>
+#include <type_traits>
 #include "mr_common.h"
 
 // diagnostic builds (scripts/build_diag.sh): -DMR_ATTN_OCC=n / -DMR_ATTN_OCC_DQ=n set the waves per SIMD the register allocator targets
 // (the forward kernel fits three by itself since its K / V tiles are LDS-DMA staged: 162-168 registers)
-#ifndef MR_ATTN_OCC_DQ      /* dQ kernel: 183-190 registers; forced to three waves per SIMD it spills 15-37 (masked -4 %, unmasked +15 %) */
+#ifndef MR_ATTN_OCC_DQ      /* masked dQ kernel: 183 registers; forced to three waves per SIMD it spills 15 (-4 %): left at two */
 #define MR_ATTN_OCC_DQ 2
+#endif
+#ifndef MR_ATTN_OCC_DQ_UNMASKED   /* unmasked dQ kernel: fits three waves per SIMD since the ragged last tile is peeled */
+#define MR_ATTN_OCC_DQ_UNMASKED 3
 #endif
 #ifndef MR_ATTN_OCC
 #define MR_ATTN_OCC 2
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
 
 // ------------------------------------------------------------------------------------------------ dQ (+ delta = rowsum(dO * O))
 template <int QB, bool MASKED>
-__global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMASKED)) void attn_bwd_dq_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                              const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                              __bf16* __restrict__ dqkv, const float* __restrict__ rot_tab,
@@ -389,21 +393,21 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const 
     const float inv_S = 1.0f / (float)S;
 
     bf16x8 qf[QB][2], dof[QB][2];
-    int64_t qi[QB];
+    int qi[QB];      // (32-bit: S < 2^31; address arithmetic widens at the use)
     int cq[QB];
     float nlse2[QB], del[QB];
     bool padq[QB];
     bool any_pad = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        qi[qb] = q0 + (wave * QB + qb) * 16 + i;
+        qi[qb] = (int)q0 + (wave * QB + qb) * 16 + i;
         const bool ok = qi[qb] < S;
         float dsum = 0.f;
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
             u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u}, x = {0u, 0u, 0u, 0u};
             if (ok) {
-                v = *reinterpret_cast<const u32x4*>(base + qi[qb] * ld + h * 64 + dd * 32 + g * 8);
+                v = *reinterpret_cast<const u32x4*>(base + (int64_t)qi[qb] * ld + h * 64 + dd * 32 + g * 8);
                 w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
                 x = *reinterpret_cast<const u32x4*>(o + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
             }
@@ -461,13 +465,16 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const 
 
     const int nt = (int)((S + TK - 1) / TK);
     const bool ragged = (S & (TK - 1)) != 0;
-    for (int t = 0; t < nt; ++t) {
+    // one key tile; NB (compile time) = the scores of this tile need the per-key bias: always when masked, otherwise only in a ragged
+    // LAST tile (keys beyond the sequence) -- which is peeled below so that the hot loop of the unmasked towers carries neither the
+    // test nor the addresses of the staged codes (as one loop with a run-time flag the kernel needed 190 registers)
+    auto tile_body = [&](int t, auto nb_c) {
+        constexpr bool need_bias = decltype(nb_c)::value;
         const int b = t & 1;
         if (t + 1 < nt) {
             stage(t + 1, b ^ 1);
             if (tid < TK) key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
         }
-        const bool need_bias = MASKED || (ragged && t == nt - 1);
         f32x4 ds[QB][2];
         bf16x8 dsf[QB][2];
 #pragma unroll
@@ -499,24 +506,19 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const 
                 if (kb & 1) dsf[qb][kb >> 1] = pack_acc_pair(ds[qb][0], ds[qb][1]);     // packed pair by pair: 16 fewer live registers
             }
         }
-        // K^T fragments (asm reads, explicit waits: see tr_frag_d_issue): both halves requested, the second lands under the first's MFMAs
-        s16x4 klo[2][4], khi[2][4];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int db = 0; db < 4; ++db) tr_frag_d_issue(Ks[b], 32 * t2, 16 * db, lane, klo[t2][db], khi[t2][db]);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        // K^T fragments (asm reads, explicit waits: see tr_frag_d_issue), one 32-key half at a time: the second half is requested once
+        // the first half's MFMAs are issued and lands under them (its 16 registers are the first half's: 3 waves per SIMD)
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-            if (t2 == 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            s16x4 klo[4], khi[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) tr_frag_d_issue(Ks[b], 32 * t2, 16 * db, lane, klo[db], khi[db]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const bf16x8 kt = tr_join(klo[t2][db], khi[t2][db]);
+                const bf16x8 kt = tr_join(klo[db], khi[db]);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][t2], dq[qb][db], 0, 0, 0);
@@ -525,6 +527,13 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC_DQ) void attn_bwd_dq_kernel(const 
         if (t + 1 < nt && tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
+    };
+    if constexpr (MASKED) {
+        for (int t = 0; t < nt; ++t) tile_body(t, std::integral_constant<bool, true>{});
+    } else {
+        for (int t = 0; t < nt - 1; ++t) tile_body(t, std::integral_constant<bool, false>{});
+        if (ragged) tile_body(nt - 1, std::integral_constant<bool, true>{});
+        else tile_body(nt - 1, std::integral_constant<bool, false>{});
     }
     f32x4 cs[4];
 #pragma unroll
