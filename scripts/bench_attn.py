@@ -27,9 +27,10 @@ for name, nseq, S, nh, masked in shapes:
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        n_it = int(os.environ.get('ATTN_ITERS', '10'))
+        for _ in range(n_it):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 100
+        us = e0.elapsed_time(e1) * 1e3 / n_it
         print(f'{name:6s} {label} {us:8.1f} us  {fl * mult / us / 1e6:7.1f} TF/s (algorithmic)')
