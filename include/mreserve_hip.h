@@ -43,6 +43,8 @@ const char* mr_last_error(void);
  *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 192 | 256 : forces the output-tile width of the 256-row GEMM
  *   "gemm_group_tile_n"  0 = choose (default) | 128 | 256 : tile width of mr_gemm_grouped's shared launch
  *   "gemm_group_streamk"  -1 = default (off) | 0 | 1 : stream-K schedule of mr_gemm_grouped (needs args[0].workspace)
+ *   "gemm_group_headtail" -1 = default (off) | 0 | 1 : head / tail K split of mr_gemm_grouped when the tiles leave >= 1/5 of the CUs
+ *                         idle and divide evenly over them (needs args[0].workspace for two fp32 slabs per tile)
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
  * Returns MR_EINVAL for an unknown name. */
 int mr_set_option(const char* name, int value);

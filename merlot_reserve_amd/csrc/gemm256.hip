@@ -203,13 +203,21 @@ struct G256Args {
     // ([256][BN] each), and streamk_fixup_kernel sums a split tile's slabs in workgroup order (fixed order: reproducible).
     // (xmode == 2 selects it; the k-tiles per tile are kt_per_split, the slabs live in p[0].workspace: no extra fields -- at
     // 1024 bytes instead of 1000 the by-value kernel argument was copied to scratch and every variant spilled)
+    // Head / tail split (xmode == 3; the large model's grouped weight gradients: T = 192 tiles of 241 k-tiles on 256 CUs, i.e. one
+    // round at 75 % of the chip): the first T workgroups compute k-tiles [0, W) of "their" tile, the other G - T workgroups the
+    // tails [W, nkt) of P = T / (G - T) tiles each (W = px, P = py; 181 and 3 x 60 k-tiles instead of 241).  Unlike stream-K
+    // every workgroup of a kind walks the SAME k range at the same time, so operand strips stay shared in L2.  Each tile leaves
+    // two raw fp32 slabs (2 tile, 2 tile + 1) in p[0].workspace, summed by headtail_fixup_kernel.
     int tiles_n[MAXG], tile_start[MAXG + 1];
     mr_gemm_args p[MAXG];
 };
 
 constexpr int XPANEL = 8;
 // stream-K constants of one workgroup (computed once, at kernel entry: the divisions stay out of the k-loop)
-struct SkRange { int u0, u1, tfirst; };
+struct SkRange {
+    int u0, u1, tfirst;
+    int ht_n, ht_tile0, ht_k0, ht_k1, ht_part;      // head / tail split (xmode == 3): this workgroup's ht_n items, all over k-tiles [ht_k0, ht_k1)
+};
 template <int BKT, int GSH>     // GSH = log2(workgroups of a full grid): 8, or 9 for the two-per-CU kernel
 __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int bperm, const SkRange& sk) {
     Item it;
@@ -237,8 +245,17 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
     // plain / split-K / stream-K share ONE decode of (tile -> problem, m0, n0): a second copy of these dynamically indexed reads
     // of the by-value argument made the compiler spill the whole 1000-byte struct to scratch
     int tile, k0 = 0, k1 = 0;
-    const bool sk_mode = ga.xmode == 2;
-    if (sk_mode) {
+    const bool sk_mode = ga.xmode == 2, ht_mode = sk.ht_n > 0;
+    if (ht_mode) {                                              // (constants from the kernel's entry: nothing of `ga` is read here)
+        const int q = (w - bperm) >> 8;                          // 256 workgroups
+        it.valid = q < sk.ht_n;
+        tile = sk.ht_tile0 + q;
+        k0 = sk.ht_k0;
+        k1 = sk.ht_k1;
+        it.split = 0;
+        it.slot = 2 * tile + sk.ht_part;
+        if (!it.valid) tile = 0;
+    } else if (sk_mode) {
         const int q = (w - bperm) >> 8;                          // the workgroup's q-th item (stream-K grids have 256 workgroups)
         const int nkt = ga.kt_per_split;
         tile = sk.tfirst + q;
@@ -258,7 +275,7 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
     const int lt = tile - ga.tile_start[it.pi], tn = ga.tiles_n[it.pi];
     it.m0 = (lt / tn) * BM;
     it.n0 = (lt % tn) * bn;
-    if (sk_mode) {
+    if (sk_mode || ht_mode) {
         it.kt0 = k0;
         it.nkt = k1 - k0;
     } else {
@@ -296,7 +313,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     const int splits = ga.splits;
-    SkRange skr = {0, 0, 0};
+    SkRange skr = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ga.xmode == 3) {       // head / tail split: T = nwork head workgroups, the rest take P = py tails each; W = px
+        const bool head = bperm < ga.nwork;
+        skr.ht_n = head ? 1 : ga.py;
+        skr.ht_tile0 = head ? bperm : (bperm - ga.nwork) * ga.py;
+        skr.ht_k0 = head ? 0 : ga.px;
+        skr.ht_k1 = head ? ga.px : ga.kt_per_split;
+        skr.ht_part = head ? 0 : 1;
+    }
     if (ga.xmode == 2) {       // units = (tile, k-tile) pairs; this workgroup's range [u0, u1) (G = 256; units < 2^31 checked on the host)
         const int64_t U = (int64_t)ga.nwork * ga.kt_per_split;
         skr.u0 = (int)((int64_t)bperm * U / G);
@@ -884,6 +909,31 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(const G256Args ga, i
     }
 }
 
+// Head / tail second pass: C tile = head slab + tail slab (fixed order), 4 workgroups per tile (64 rows each).
+template <int BN>
+__global__ __launch_bounds__(256) void headtail_fixup_kernel(const G256Args ga) {
+    const int tile = blockIdx.x >> 2, part = blockIdx.x & 3;
+    const int pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
+    const mr_gemm_args& p = ga.p[pi];
+    const int lt = tile - ga.tile_start[pi], tn = ga.tiles_n[pi];
+    const int m0 = (lt / tn) * BM, n0 = (lt % tn) * BN;
+    __bf16* C = static_cast<__bf16*>(p.C);
+    const float* s0 = static_cast<const float*>(ga.p[0].workspace) + (int64_t)(2 * tile) * (BM * BN);
+    const float* s1 = s0 + BM * BN;
+    const int64_t M = p.M, N = p.N, ldc = p.ldc;
+    for (int e = threadIdx.x; e < 64 * BN / 4; e += 256) {
+        const int r = part * 64 + e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+        const f32x4 sum = *reinterpret_cast<const f32x4*>(s0 + r * BN + c4) + *reinterpret_cast<const f32x4*>(s1 + r * BN + c4);
+        const int64_t m = m0 + r, n = n0 + c4;
+        if (m < M && n < N) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (__bf16)sum[k];
+            *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
+        }
+    }
+}
+
 template <int BN, int NW = 8>
 static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
     dim3 block(NW * 64);
@@ -900,6 +950,7 @@ constexpr int64_t NUM_CU = 256;    // MI355X
 extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
 extern int g_mr_opt_group_tile_n;  // mr_set_option("gemm_group_tile_n")
 extern int g_mr_opt_group_streamk; // mr_set_option("gemm_group_streamk"): -1 = environment / default (off)
+extern int g_mr_opt_group_headtail; // mr_set_option("gemm_group_headtail"): -1 = environment / default (off)
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -1053,6 +1104,27 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         if (bn != g_mr_opt_group_tile_n) streamk = false;       // a forced width (tests, A/B): the plain schedule
         bn = g_mr_opt_group_tile_n;
     }
+    // Head / tail split (see G256Args): a single partial round that leaves >= 1/5 of the CUs idle, tiles an exact multiple of the idle CUs
+    // OPT-IN (MR_G256_HEADTAIL=1 / mr_set_option("gemm_group_headtail", 1)).  Measured on the large model (round 2): the launch goes
+    // from 362 to 343 us with all 256 CUs busy instead of 192 -- not the 25 % the idle CUs promise, because these K = 15 424 GEMMs are
+    // bound by operand delivery (L2 fill / HBM), not by CU count -- the fix-up pass makes the short audio-tower launch 9 % slower,
+    // and the replayed step does not move (88.5 ms either way).
+    static int ht_env0 = -1;
+    if (ht_env0 < 0) { const char* e = getenv("MR_G256_HEADTAIL"); ht_env0 = e ? atoi(e) : 0; }
+    const int ht_env = g_mr_opt_group_headtail >= 0 ? g_mr_opt_group_headtail : ht_env0;
+    bool headtail = false;
+    int ht_w = 0, ht_p = 0;
+    {
+        const int64_t st = (bn == 256) ? t256 : t128, nk = (list[0].K + g256::BK - 1) / g256::BK, idle = NUM_CU - st;
+        bool out_ok = true;
+        for (int k = 0; k < count; ++k) out_ok = out_ok && list[k].c_dtype == MR_DT_BF16 && !list[k].bias && list[k].N % 4 == 0 && list[k].ldc % 4 == 0;
+        if (ht_env && !streamk && same_k && out_ok && g_mr_opt_group_tile_n == 0 && st < NUM_CU && idle * 5 >= NUM_CU && st % idle == 0 && st / idle <= 8 &&
+            list[0].workspace != nullptr && list[0].workspace_bytes >= 2 * st * (int64_t)g256::BM * bn * (int64_t)sizeof(float)) {
+            ht_p = (int)(st / idle);
+            ht_w = (int)((nk * ht_p + ht_p) / (ht_p + 1));           // heads W, tails P (nk - W): within one k-tile of each other
+            headtail = nk >= 16 * (ht_p + 1) && ht_w < nk;
+        }
+    }
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     int64_t tiles = 0;
@@ -1078,6 +1150,18 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         } else {
             g256::launch<128>(ga, grid, s);
             hipLaunchKernelGGL(g256::streamk_fixup_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, s, ga, (int)NUM_CU);
+        }
+        return true;
+    }
+    if (headtail) {
+        ga.xmode = 3; ga.px = ht_w; ga.py = ht_p;
+        dim3 grid((unsigned)NUM_CU);
+        if (bn == 256) {
+            g256::launch<256>(ga, grid, s);
+            hipLaunchKernelGGL(g256::headtail_fixup_kernel<256>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, ga);
+        } else {
+            g256::launch<128>(ga, grid, s);
+            hipLaunchKernelGGL(g256::headtail_fixup_kernel<128>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, ga);
         }
         return true;
     }
