@@ -269,6 +269,44 @@ def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
     assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
 
 
+@pytest.mark.parametrize('nseq,S,nh,masked', [(2, 241, 2, False), (1, 100, 2, True), (3, 31, 2, False)])
+def test_attention_reads_nothing_past_the_sequence(dev, nseq, S, nh, masked):
+    """The K / V (Q / dO) tiles are fetched by LDS-DMA in whole 64-row tiles; rows past a sequence's end must come back as zeros (the
+    buffer descriptor's extent), never as whatever lies behind: here the operands are leading views of NaN-filled allocations, so a
+    read past the LAST sequence meets NaN; and the first sequence computed alone (followed by NaN instead of the second sequence's
+    rows) must give bit-identical rows, so nothing of a neighbouring sequence leaks in either."""
+    from merlot_reserve_amd import ops
+    H = nh * 64
+    rows = nseq * S
+    big = torch.full((rows + 256, 3 * H), float('nan'), dtype=BF16, device=dev)
+    bigd = torch.full((rows + 256, H), float('nan'), dtype=BF16, device=dev)
+    bigo = torch.full((rows + 256, H), float('nan'), dtype=BF16, device=dev)
+    qkv, dout, out = big[:rows], bigd[:rows], bigo[:rows]
+    qkv.copy_(rnd((rows, 3 * H), dev, seed=1))
+    dout.copy_(rnd((rows, H), dev, seed=2))
+    code = None
+    if masked:
+        c = torch.zeros(nseq, S, dtype=torch.int32)
+        c[:, 5:9] = -1
+        code = c.reshape(-1).to(dev)
+    lse = torch.zeros(nseq, nh, S, device=dev)
+    delta = torch.zeros(nseq, nh, S, device=dev)
+    dqkv = torch.zeros(rows, 3 * H, dtype=BF16, device=dev)
+    ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all() and torch.isfinite(lse).all()
+    qr = qkv.float().clone().requires_grad_(True)
+    ref_o, _ = ref_attention(qr, code, nseq, S, nh)
+    assert_close(out, ref_o, 4e-3, 'attn out')
+    if nseq > 1:       # the first sequence alone (what follows it is now NaN too) gives the same rows
+        out1 = torch.full((S + 256, H), float('nan'), dtype=BF16, device=dev)
+        big1 = torch.full((S + 256, 3 * H), float('nan'), dtype=BF16, device=dev)
+        big1[:S].copy_(qkv[:S])
+        lse1 = torch.zeros(1, nh, S, device=dev)
+        ops.attention_fwd(big1[:S], None if code is None else code[:S].contiguous(), out1[:S], lse1, 1, S, nh)
+        assert torch.equal(out1[:S], out[:S]) and torch.equal(lse1[0], lse[0])
+
+
 @pytest.mark.parametrize('nseq,S,nh', [(2, 22, 2), (1, 130, 2)])
 def test_attention_bwd_through_pad_query_rows(dev, nseq, S, nh):
     """A PAD query row has no allowed key: every score is exactly -1e10, the reference's softmax is uniform over all S
