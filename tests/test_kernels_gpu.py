@@ -409,6 +409,10 @@ def test_small_helpers(dev):
     out = torch.zeros(128, dtype=BF16, device=dev)
     ops.sum_rows_strided(x, 3, 17, 0, out)
     assert_close(out, x.float()[[0, 17, 34]].sum(0), 4e-3, 'sum_rows_strided')
+    x = rnd((70 * 5, 200), dev, seed=6)                     # more groups than the kernel's 16 row groups, ragged column count
+    out = torch.zeros(200, dtype=BF16, device=dev)
+    ops.sum_rows_strided(x, 70, 5, 2, out)
+    assert_close(out, x.float()[2::5].sum(0), 4e-3, 'sum_rows_strided (70 groups)')
     a, b = rnd((64, 128), dev, seed=4), rnd((64, 128), dev, seed=5)
     y = torch.zeros_like(a)
     ops.add_(a, b, y)
