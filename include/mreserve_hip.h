@@ -41,6 +41,7 @@ int mr_version(void);
 const char* mr_last_error(void);
 /* Tuning / diagnostic knobs (process-wide, not thread-safe against concurrent launches).  Known names:
  *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 192 | 256 : forces the output-tile width of the 256-row GEMM
+ *                   | 4128 : 128-wide tiles computed by 4-wave workgroups, two per CU (experiment)
  *   "gemm_group_tile_n"  0 = choose (default) | 128 | 256 : tile width of mr_gemm_grouped's shared launch
  *   "gemm_group_streamk"  -1 = default (off) | 0 | 1 : stream-K schedule of mr_gemm_grouped (needs args[0].workspace)
  *   "gemm_group_headtail" -1 = default (off) | 0 | 1 : head / tail K split of mr_gemm_grouped when the tiles leave >= 1/5 of the CUs
