@@ -9,45 +9,68 @@ namespace {
 constexpr int MAXC = 4;           // 16-byte chunks per lane (template MC <= MAXC): H <= 64 * 8 * 4 = 2048
 constexpr int PART_ROWS = 1024;   // ln_bwd grid: 4 blocks per CU    // rows of the fp32 partial-sum workspace
 
+// Two rows per wave: both rows' chunks are requested before either row's reductions run (with one row per wave the kernel sat at
+// 4.1 TB/s: a wave had 1.5 loads in flight for H = 768), gamma / beta are fetched once for both.
 template <int MC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ x, int64_t ldx, const __bf16* __restrict__ gamma,
                                                      const __bf16* __restrict__ beta, __bf16* __restrict__ y, int64_t ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
                                                      int H, float eps) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
     const int nch = H >> 3;
-    float v[MC][8];
-    float s = 0.f, s2 = 0.f;
+    u32x4 raw[2][MC];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            raw[r][k] = u32x4{0u, 0u, 0u, 0u};
+            if (c < nch && (r == 0 || two)) raw[r][k] = *reinterpret_cast<const u32x4*>(x + (row0 + r) * ldx + 8 * c);
+        }
+    u32x4 graw[MC], braw[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) {
         const int c = lane + 64 * k;
+        graw[k] = u32x4{0u, 0u, 0u, 0u}; braw[k] = graw[k];
         if (c < nch) {
-            unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + 8 * c), v[k]);
+            graw[k] = *reinterpret_cast<const u32x4*>(gamma + 8 * c);
+            braw[k] = *reinterpret_cast<const u32x4*>(beta + 8 * c);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && !two) break;
+        float v[MC][8];
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            unpack8(raw[r][k], v[k]);                     // chunks beyond H are zeros: they add nothing
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s += v[k][e]; s2 += v[k][e] * v[k][e]; }
         }
-    }
-    s = wave_sum(s);
-    s2 = wave_sum(s2);
-    const float mean = s / (float)H;
-    const float var = s2 / (float)H - mean * mean;
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
-    }
+        s = wave_sum(s);
+        s2 = wave_sum(s2);
+        const float mean = s / (float)H;
+        const float var = s2 / (float)H - mean * mean;
+        const float rstd = rsqrtf(var + eps);
+        if (lane == 0) {
+            if (mean_out) mean_out[row0 + r] = mean;
+            if (rstd_out) rstd_out[row0 + r] = rstd;
+        }
 #pragma unroll
-    for (int k = 0; k < MC; ++k) {
-        const int c = lane + 64 * k;
-        if (c < nch) {
-            float gm[8], bt[8], o[8];
-            unpack8(*reinterpret_cast<const u32x4*>(gamma + 8 * c), gm);
-            unpack8(*reinterpret_cast<const u32x4*>(beta + 8 * c), bt);
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                float gm[8], bt[8], o[8];
+                unpack8(graw[k], gm);
+                unpack8(braw[k], bt);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * (rstd * gm[e]) + bt[e];
-            *reinterpret_cast<u32x4*>(y + row * ldy + 8 * c) = pack8(o);
+                for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * (rstd * gm[e]) + bt[e];
+                *reinterpret_cast<u32x4*>(y + (row0 + r) * ldy + 8 * c) = pack8(o);
+            }
         }
     }
 }
@@ -269,7 +292,7 @@ extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
     MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_fwd: H=%ld unsupported", (long)H);
     MR_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0, "mr_layernorm_fwd: leading dims must be multiples of 8");
     auto kern = (H <= 1024) ? ln_fwd_kernel<2> : ln_fwd_kernel<MAXC>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const __bf16*>(x), ldx, static_cast<const __bf16*>(gamma), static_cast<const __bf16*>(beta),
                        static_cast<__bf16*>(y), ldy, mean, rstd, rows, (int)H, eps);
     MR_CHECK_LAUNCH("mr_layernorm_fwd");
