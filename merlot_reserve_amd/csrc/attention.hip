@@ -58,8 +58,18 @@ __device__ unsigned long long g_attn_stamps[512 * 16 * 8];
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (lane == 0 && wave == 0 && blockIdx.x < 512 && t < 16) g_attn_stamps[(blockIdx.x * 16 + t) * 8 + (slot)] = t_; \
     } while (0)
+// workgroup begin / end (tile row 15 of the workgroup's stamps, slots 0 / 1; the loop-top stamp of tile 0 marks the prologue's end)
+#define MR_ASTAMP_WG(slot)                                                                                     \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (lane == 0 && wave == 0 && blockIdx.x < 512) g_attn_stamps[(blockIdx.x * 16 + 15) * 8 + (slot)] = t_; \
+    } while (0)
 #else
 #define MR_ASTAMP(slot) do {} while (0)
+#define MR_ASTAMP_WG(slot) do {} while (0)
 #endif
 
 namespace {
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
     const int64_t seq = ab_.seq, h = ab_.h, q0 = ab_.blk * (64 * QB);
     const int64_t H = nh * 64, ld = 3 * H;
     const __bf16* base = qkv + seq * S * ld;
+    MR_ASTAMP_WG(0);
 
     bf16x8 qf[QB][2];
     int64_t qi[QB];
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             }
         }
     }
+    MR_ASTAMP_WG(1);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ (+ delta = rowsum(dO * O))

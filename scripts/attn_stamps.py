@@ -25,6 +25,7 @@ for name, nseq, S, nh, masked in [('joint', 24, 640, 12, True), ('vit', 64, 241,
     lib.mr_diag_attn_stamps(buf)
     st = torch.tensor(list(buf), dtype=torch.int64).view(512, 16, 8)
     nt = (S + 63) // 64
+    wg = st[:, 15, :2]
     st = st[:, :nt]
     names = ['load issue', 'S^T mfma issue', 'softmax', 'PV mfma issue', 'lds store', 'barrier']
     print(f'{name}: S={S} tiles={nt} kernel {e0.elapsed_time(e1) * 1e3:.1f} us')
@@ -32,4 +33,5 @@ for name, nseq, S, nh, masked in [('joint', 24, 640, 12, True), ('vit', 64, 241,
         d = (st[:, :, k + 1] - st[:, :, k]).float()
         print(f'   {nm:16s} mean {d.mean():7.0f}  (first tile {d[:, 0].mean():7.0f}, middle {d[:, 1:max(nt - 1, 2)].mean():7.0f}, last {d[:, nt - 1].mean():7.0f})')
     tile = (st[:, :, 6] - st[:, :, 0]).float()
+    print(f'   workgroup: begin -> first tile {(st[:, 0, 0] - wg[:, 0]).float().mean():.0f}, last tile -> end {(wg[:, 1] - st[:, nt - 1, 6]).float().mean():.0f}, whole {(wg[:, 1] - wg[:, 0]).float().mean():.0f} cycles')
     print(f'   per tile total   mean {tile.mean():7.0f};  wave span first->last tile {(st[:, nt - 1, 6] - st[:, 0, 0]).float().mean():.0f} cycles')
