@@ -249,7 +249,12 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
     const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
     const unsigned tile_step = (unsigned)(TK * ld * 2);
-    auto key_code = [&](int64_t k) -> int { return (k < S) ? (MASKED ? code[seq * S + k] : 0) : CODE_NONE; };
+    // per-key staging word: masked = the key's code (CODE_NONE beyond the sequence); unmasked = the additive bias of the key in the
+    // exp2 domain as float bits (0, or -inf beyond the sequence), so that a score is ONE fma(raw, SCALE2, bias) -- no compare / select
+    auto key_code = [&](int64_t k) -> int {
+        if (MASKED) return (k < S) ? code[seq * S + k] : CODE_NONE;
+        return (k < S) ? 0 : (int)0xff800000u;
+    };
     auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b
         const unsigned so = (unsigned)t * tile_step;
         char* kd = Ks[b] + wave * 2048;
@@ -306,7 +311,9 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float s = biased2<MASKED>(st[qb][kb][r], cq[qb], ck[kb][r]);
+                    // (the bias through a whole-vector bit cast: __builtin_bit_cast on ONE element of the int vector read element 0 for every r)
+                    const float s = MASKED ? biased2<true>(st[qb][kb][r], cq[qb], ck[kb][r])
+                                           : __builtin_fmaf(st[qb][kb][r], SCALE2, __builtin_bit_cast(f32x4, ck[kb])[r]);
                     st[qb][kb][r] = s;
                     tmax = fmaxf(tmax, s);
                 }
