@@ -194,12 +194,6 @@ __device__ __forceinline__ AttnBlock attn_block(int nblk, int nh) {
 // where its extra registers cost a wave per SIMD: kept as it was.)
 constexpr float SCALE2 = 0.125f * LOG2E;           // 1/sqrt(64) in the exp2 domain
 constexpr float NEG_BIG2 = -1e10f * LOG2E;         // the reference's -1e10 bias, exp2 domain
-template <bool MASKED>
-__device__ __forceinline__ float biased2(float raw, int cq, int ck) {
-    float s = raw * SCALE2;
-    if (MASKED && !(cq == ck && cq >= 0)) s += NEG_BIG2;
-    return (ck == CODE_NONE) ? -INFINITY : s;
-}
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int QB, bool MASKED>
@@ -208,7 +202,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
                                                           int64_t S, int64_t nh) {
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];          // LDS-DMA images (see dma_src)
     __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];
-    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
+    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];          // masked: key codes
+    __shared__ __attribute__((aligned(16))) float Ns[2][TK];            // additive key bias, exp2 domain (see key_meta2)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
@@ -230,6 +225,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             qf[qb][dd] = __builtin_bit_cast(bf16x8, v);
         }
         cq[qb] = (MASKED && qi[qb] < S) ? code[seq * S + qi[qb]] : 0;
+        if (MASKED && cq[qb] < 0) cq[qb] = CODE_PADQ;            // a PAD query matches no key code (a PAD key's is -1)
     }
 
     float m[QB], l[QB];
@@ -249,11 +245,15 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
     const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
     const unsigned tile_step = (unsigned)(TK * ld * 2);
-    // per-key staging word: masked = the key's code (CODE_NONE beyond the sequence); unmasked = the additive bias of the key in the
-    // exp2 domain as float bits (0, or -inf beyond the sequence), so that a score is ONE fma(raw, SCALE2, bias) -- no compare / select
-    auto key_code = [&](int64_t k) -> int {
-        if (MASKED) return (k < S) ? code[seq * S + k] : CODE_NONE;
-        return (k < S) ? 0 : (int)0xff800000u;
+    // Per-key staging: the additive bias a score gets unless the key is allowed for the query, in the exp2 domain -- the reference's
+    // literal -1e10 for a key inside the sequence (an unmasked tower allows every such key: 0), -inf beyond it -- and, masked only, the
+    // key's code.  A score is then fma(raw, SCALE2, allowed ? 0 : bias): compare + select + FMA (unmasked: the FMA alone).  A PAD
+    // query's code equals no key's, so all its scores round to the same -1e10 log2 e inside the sequence (-inf outside): uniform over
+    // the S keys, as in the reference.
+    auto key_meta2 = [&](int64_t k, int& c, float& nb) {
+        const bool in = k < S;
+        c = (MASKED && in) ? code[seq * S + k] : CODE_NONE;
+        nb = in ? (MASKED ? NEG_BIG2 : 0.f) : -INFINITY;
     };
     auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b
         const unsigned so = (unsigned)t * tile_step;
@@ -266,8 +266,9 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
     };
 
     int cr = 0;
+    float nr = 0.f;
     stage(0, 0);
-    if (tid < TK) Cs[0][tid] = key_code(tid);
+    if (tid < TK) { key_meta2(tid, cr, nr); if (MASKED) Cs[0][tid] = cr; Ns[0][tid] = nr; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         MR_ASTAMP(0);
         if (t + 1 < nt) {      // next tile: straight into the other buffer (last read one iteration ago, behind that iteration's barrier)
             stage(t + 1, b ^ 1);
-            if (tid < TK) cr = key_code((int64_t)(t + 1) * TK + tid);
+            if (tid < TK) key_meta2((int64_t)(t + 1) * TK + tid, cr, nr);
         }
         MR_ASTAMP(1);
         f32x4 st[QB][4];
@@ -300,23 +301,28 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
 #pragma unroll
             for (int db = 0; db < 4; ++db) tr_frag_d_issue(Vs[b], 0, 16 * db, lane, vlo[0][db], vhi[0][db]);
         }
-        i32x4 ck[4];
+        float tmx[QB];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) ck[kb] = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+        for (int qb = 0; qb < QB; ++qb) tmx[qb] = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {         // the staged vectors of one 16-key block at a time: 8 registers live, not 32
+            const f32x4 nbv = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
+            i32x4 ckv = {0, 0, 0, 0};
+            if (MASKED) ckv = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float bias = MASKED ? ((ckv[r] == cq[qb]) ? 0.f : nbv[r]) : nbv[r];
+                    const float s = __builtin_fmaf(st[qb][kb][r], SCALE2, bias);
+                    st[qb][kb][r] = s;
+                    tmx[qb] = fmaxf(tmx[qb], s);
+                }
+        }
         bf16x8 pf[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // (the bias through a whole-vector bit cast: __builtin_bit_cast on ONE element of the int vector read element 0 for every r)
-                    const float s = MASKED ? biased2<true>(st[qb][kb][r], cq[qb], ck[kb][r])
-                                           : __builtin_fmaf(st[qb][kb][r], SCALE2, __builtin_bit_cast(f32x4, ck[kb])[r]);
-                    st[qb][kb][r] = s;
-                    tmax = fmaxf(tmax, s);
-                }
+            float tmax = tmx[qb];
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mn = fmaxf(m[qb], tmax);
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             }
         }
         MR_ASTAMP(4);
-        if (t + 1 < nt && tid < TK) Cs[b ^ 1][tid] = cr;
+        if (t + 1 < nt && tid < TK) { if (MASKED) Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         MR_ASTAMP(5);
         __syncthreads();
