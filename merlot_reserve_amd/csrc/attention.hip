@@ -37,8 +37,8 @@
 
 // diagnostic builds (scripts/build_diag.sh): -DMR_ATTN_OCC=n / -DMR_ATTN_OCC_DQ=n set the waves per SIMD the register allocator targets
 // (the forward kernel fits three by itself since its K / V tiles are LDS-DMA staged: 162-168 registers)
-#ifndef MR_ATTN_OCC_DQ      /* masked dQ kernel: 183 registers; forced to three waves per SIMD it spills 15 (-4 %): left at two */
-#define MR_ATTN_OCC_DQ 2
+#ifndef MR_ATTN_OCC_DQ      /* masked dQ kernel: 184 registers by itself; held to three waves per SIMD it spills a few and is still faster (joint backward 181 -> 175 us) */
+#define MR_ATTN_OCC_DQ 3
 #endif
 #ifndef MR_ATTN_OCC_DQ_UNMASKED   /* unmasked dQ kernel: fits three waves per SIMD since the ragged last tile is peeled */
 #define MR_ATTN_OCC_DQ_UNMASKED 3
