@@ -219,34 +219,35 @@ static void launch_reduce(const float* partials, int nparts, int ncols, int spli
 }
 
 // Several independent reductions in ONE launch (the LayerNorm and bias gradients of a transformer layer): single level,
-// block = 64 columns of one job x 16 row groups, fixed summation order.
+// block = 32 columns of one job x 32 row groups (a row segment = one 128-byte line), fixed summation order.  (64 columns x 16 groups
+// left half of the CUs without a block and every thread with 4 dependent rounds of loads for the 244 partial rows of an fc1 bias: 11.7 us.)
 constexpr int MAX_JOBS = 8;
 struct ReduceBatch {
     int count;
     int blk_start[MAX_JOBS + 1];
     mr_reduce_job job[MAX_JOBS];
 };
+constexpr int RB_COLS = 32, RB_GRPS = 32;
 __global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    __shared__ float red[RB_GRPS][RB_COLS];
+    const int lane = threadIdx.x & (RB_COLS - 1), grp = threadIdx.x / RB_COLS;
     int j = 0;
 #pragma unroll
     for (int k = 1; k < MAX_JOBS; ++k) j += (k < rb.count && (int)blockIdx.x >= rb.blk_start[k]);
     const mr_reduce_job& q = rb.job[j];
-    const int c = ((int)blockIdx.x - rb.blk_start[j]) * 64 + lane, ncols = q.ncols, nparts = q.nparts;
+    const int c = ((int)blockIdx.x - rb.blk_start[j]) * RB_COLS + lane, ncols = q.ncols, nparts = q.nparts;
     float s = 0.f;
     if (c < ncols) {
-        // four independent chains: the loads of a group's partial rows are all in flight at once (this kernel reduces a few
-        // MB and was bound by one load latency per row), summed in a fixed order
+        // four independent chains: the loads of a group's partial rows are all in flight at once, summed in a fixed order
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int p = grp;
-        for (; p + 48 < nparts; p += 64) {
+        for (; p + 3 * RB_GRPS < nparts; p += 4 * RB_GRPS) {
             s0 += q.partials[(int64_t)p * ncols + c];
-            s1 += q.partials[(int64_t)(p + 16) * ncols + c];
-            s2 += q.partials[(int64_t)(p + 32) * ncols + c];
-            s3 += q.partials[(int64_t)(p + 48) * ncols + c];
+            s1 += q.partials[(int64_t)(p + RB_GRPS) * ncols + c];
+            s2 += q.partials[(int64_t)(p + 2 * RB_GRPS) * ncols + c];
+            s3 += q.partials[(int64_t)(p + 3 * RB_GRPS) * ncols + c];
         }
-        for (; p < nparts; p += 16) s0 += q.partials[(int64_t)p * ncols + c];
+        for (; p < nparts; p += RB_GRPS) s0 += q.partials[(int64_t)p * ncols + c];
         s = (s0 + s1) + (s2 + s3);
     }
     red[grp][lane] = s;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(1024) void reduce_batch_kernel(const ReduceBatch rb
     if (grp == 0 && c < ncols) {
         s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[k][lane];
+        for (int k = 0; k < RB_GRPS; ++k) s += red[k][lane];
         if (c < q.split) static_cast<__bf16*>(q.out0)[c] = (__bf16)s;
         else static_cast<__bf16*>(q.out1)[c - q.split] = (__bf16)s;
     }
@@ -356,7 +357,7 @@ extern "C" int mr_reduce_partials(const mr_reduce_job* jobs, int32_t count, void
                      "mr_reduce_partials: bad job %d", k);
         rb.blk_start[k] = blocks;
         rb.job[k] = q;
-        blocks += (q.ncols + 63) / 64;
+        blocks += (q.ncols + RB_COLS - 1) / RB_COLS;
     }
     rb.blk_start[count] = blocks;
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), rb);
