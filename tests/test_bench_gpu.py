@@ -1,0 +1,32 @@
+"""bench.py end to end on the GPU (a child process, few steps): the ONE JSON line the driver parses carries every field of the
+contract -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
+config.workload, the roofline object (bound, achieved, peak, unit, frac, traffic) and the per-family breakdown."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract(dev):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-h2d']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['metric'].startswith('video-segments/sec') and d['unit'] == 'video-segments/sec'
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'bf16' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['hipgraph'] is True
+    assert abs(d['value'] - 8 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']          # 4 records = 8 video-segment groups per step
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
+    assert 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert r['traffic'] is None or r['traffic'] > 0
+    b = d['breakdown']
+    assert set(b['ms_per_step']) >= {'gemm', 'attention', 'layernorm+reductions', 'optimizer'} and b['sum_ms'] > 0
