@@ -30,3 +30,18 @@ def test_bench_line_contract(dev):
     assert r['traffic'] is None or r['traffic'] > 0
     b = d['breakdown']
     assert set(b['ms_per_step']) >= {'gemm', 'attention', 'layernorm+reductions', 'optimizer'} and b['sum_ms'] > 0
+
+
+def test_bench_multi_rank_code_path_with_one_rank(dev):
+    """--force-comm: the N > 1 program (gloo control plane, the library's RCCL communicator, all-gather / reduce-scatter / five bucket
+    all-reduces captured inside the step's graph) with a single rank -- what can be rehearsed on a 1-GPU box."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-h2d',
+           '--no-roofline', '--force-comm']
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    c = d['config']
+    assert c['comm'] == 'rccl-native' and c['rccl_ranks'] == 1 and c['hipgraph'] is True
+    assert len(c['gradient_buckets']) == 5 and 0.0 < c['exposed_gradient_fraction'] < 0.2
+    assert d['value'] > 0 and d['n_gpus'] == 1
