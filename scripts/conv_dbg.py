@@ -19,5 +19,5 @@ hist = []
 for i in range(int(os.environ.get("STEPS", "100"))):
     if graph: tr.train_step_graph(batches[i % 2], plans[i % 2])
     else: tr.train_step(batches[i % 2], plan=plans[i % 2])
-    if i % 20 == 19: hist.append(round(tr.loss_info()['loss'], 3))
+    if i % 100 == 99: hist.append(round(tr.loss_info()['loss'], 3))
 print(os.environ.get('TAG'), first, hist)

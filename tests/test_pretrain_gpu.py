@@ -225,13 +225,14 @@ def test_fp32_forward_parity_1e3(dev, hidden_size, B):
 
 
 def test_training_reduces_the_contrastive_loss(dev):
-    """300 graph-replayed steps on two alternating tiny batches: the contrastive loss falls well below its chance level
+    """1000 graph-replayed steps on two alternating tiny batches: the contrastive loss falls well below its chance level
     (7.34 = sum over objectives of ln(#candidates)): forward, backward and the folded optimizer work together over many
     steps.  (text_to_audio and stuff_to_span are memorised; imgs_to_audio stays at chance on iid-noise frames, whose ViT
-    embeddings are nearly identical.)  The descent goes plateau by plateau (6.0 -> 5.6 -> 5.2 -> 4.6 ...) and WHEN a
-    plateau is left is sensitive to single-ulp differences of bf16 gradients (scripts/step_ab.py: three reduction
-    schedules with gradients equal to 1 ulp in < 10 elements reach 6.03 / 5.97 / 5.65 after 100 steps and 4.51 / 4.21 /
-    4.59 after 300), so the bound is on the 300-step value, which every schedule passes with margin."""
+    embeddings are nearly identical.)  The descent goes plateau by plateau (6.0 -> 5.6 -> 5.2 -> 4.6 -> 4.0 ...) and WHEN a
+    plateau is left is sensitive to single-ulp differences of bf16 gradients (scripts/step_ab.py, scripts/conv_dbg.py: five
+    reduction schedules whose gradients differ by one ulp in < 10 elements are anywhere between 5.66 and 4.2 after 300 steps, and
+    between 4.15 and 3.78 after 1000), so the bounds are loose at 100 steps and on the 1000-step value, which every schedule seen
+    so far passes with margin."""
     from merlot_reserve_amd.config import tiny_config
     from merlot_reserve_amd.synthetic import make_batch
     from merlot_reserve_amd.trainer import Trainer
@@ -245,13 +246,13 @@ def test_training_reduces_the_contrastive_loss(dev):
     first = tr.loss_info()['loss']
     tr.capture(batches[0])
     hist = []
-    for i in range(300):
+    for i in range(1000):
         tr.train_step_graph(batches[i % 2], plans[i % 2])
-        if i % 20 == 19:
+        if i % 100 == 99:
             hist.append(tr.loss_info()['loss'])
     assert all(np.isfinite(hist)), hist
-    assert hist[4] < 0.9 * first and hist[-1] < 0.75 * first, (first, hist)
-    assert tr.state.step == 301
+    assert hist[0] < 0.9 * first and hist[-1] < 0.65 * first, (first, hist)
+    assert tr.state.step == 1001
 
 
 def _full_size_config(case):
