@@ -37,7 +37,11 @@ def test_bench_multi_rank_code_path_with_one_rank(dev):
     all-reduces captured inside the step's graph) with a single rank -- what can be rehearsed on a 1-GPU box."""
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-h2d',
            '--no-roofline', '--force-comm']
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
