@@ -47,6 +47,8 @@ const char* mr_last_error(void);
  *   "gemm_group_headtail" -1 = default (off) | 0 | 1 : head / tail K split of mr_gemm_grouped when the tiles leave >= 1/5 of the CUs
  *                         idle and divide evenly over them (needs args[0].workspace for two fp32 slabs per tile)
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
+ *   "gemm3"         1 = default: NT problems with enough tiles run on the ping-pong kernel (gemm3.hip) | 0 = off | 256 / 192 = on
+ *                   for EVERY NT problem it can take, with that tile width (tests, A/B)
  * Returns MR_EINVAL for an unknown name. */
 int mr_set_option(const char* name, int value);
 
@@ -250,6 +252,13 @@ int mr_softmax_xent(const float* logits, int64_t row_stride, int64_t class_strid
 int mr_nan_to_num_bf16(void* g, int64_t n, void* stream);
 /* work_bf16 = bf16(master) (P:323-324) */
 int mr_cast_f32_to_bf16_params(const float* master, void* work_bf16, int64_t n, void* stream);
+/* Transposed working copies of Dense kernels: for every leaf of the table -- int32 quadruples {element offset in the flat buffers,
+ * rows (= in features K), cols (= out features N), index of the leaf's first 64 x 64 tile}, rows and cols multiples of 64, leaves
+ * in ascending tile order, in DEVICE memory -- workT[off + n * rows + k] = work[off + k * cols + n] for the tiles
+ * [tile_lo, tile_hi) (a range of leaves: one gradient bucket).  Forward GEMMs (P:323-324 casts the params once per step; the
+ * reference's XLA picks its own operand layouts) then read B = W^T [N, K] with transB = 1, like the dgrads read W [K, N]. */
+int mr_transpose_leaves(const void* work_bf16, void* workT_bf16, const int32_t* leaves_dev, int32_t nleaf, int32_t tile_lo,
+                        int32_t tile_hi, void* stream);
 
 /* ---- fp32 forward path (use_bfloat16 = false: M:594; every zero-shot / feature caller runs fp32, M:999-1000) ----
  * Same operations as above with fp32 storage and fp32 arithmetic (v_mfma_f32_16x16x4_f32 / fp32 VALU), forward only.

@@ -71,6 +71,7 @@ PROTOTYPES = {
     'mr_softmax_xent': (i32, [vp, i64, i64, vp, i64, i64, f32, vp, vp, vp, vp]),
     'mr_nan_to_num_bf16': (i32, [vp, i64, vp]),
     'mr_cast_f32_to_bf16_params': (i32, [vp, vp, i64, vp]),
+    'mr_transpose_leaves': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'mr_f32_gemm': (i32, [C.POINTER(GemmArgs), vp]),
     'mr_f32_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, i64, i64, f32, vp]),
     'mr_f32_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),

@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, 'libmreserve_hip.so')
 # attention.hip: the SLP vectoriser turns adjacent scalar fp32 adds / multiplies of the softmax into v_pk_add_f32 / v_pk_mul_f32, which
 # issue slower than the scalar pairs they replace on gfx950 (MI355X_MICROARCH.md): 961 -> 192 packed ops, backward kernels 2-4 % faster
 EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize']}
-SOURCES = ['gemm.hip', 'gemm256.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
 
 
 def _needs_build():

@@ -86,6 +86,33 @@ __global__ void cast_params_kernel(const float* __restrict__ master, __bf16* __r
     }
 }
 
+// Transposed bf16 working copies of the Dense kernels ([K, N] as flax stores them -> [N, K]) so that FORWARD GEMMs read a
+// K-contiguous B operand like the dgrads do (gemm3.hip takes "NT" operands only; K-contiguous fragments are plain
+// ds_read_b128).  One 64 x 64 tile per workgroup through LDS; the leaf of a tile is found by bisection over the leaves'
+// first-tile table.  HBM-bound: 4 B / parameter, ~1 % of a training step.
+struct TrLeaf { int off, rows, cols, tile0; };     // element offset of the leaf in the flat buffers; [rows, cols] source; its first tile
+__global__ __launch_bounds__(256) void transpose_leaves_kernel(const __bf16* __restrict__ work, __bf16* __restrict__ workT,
+                                                               const TrLeaf* __restrict__ leaves, int nleaf, int tile_lo) {
+    __shared__ __bf16 tl[64][72];
+    const int tile = tile_lo + blockIdx.x;
+    int lo = 0, hi = nleaf - 1;
+    while (lo < hi) {                     // last leaf whose first tile is <= tile
+        const int mid = (lo + hi + 1) >> 1;
+        if (leaves[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+    }
+    const TrLeaf lf = leaves[lo];
+    const int tc = lf.cols >> 6, t = tile - lf.tile0, r0 = (t / tc) << 6, c0 = (t % tc) << 6;
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    const __bf16* src = work + lf.off + (int64_t)(r0 + r) * lf.cols + c0 + q * 16;
+    const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(src), v1 = *reinterpret_cast<const bf16x8*>(src + 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { tl[q * 16 + e][r] = v0[e]; tl[q * 16 + 8 + e][r] = v1[e]; }
+    __syncthreads();
+    __bf16* dst = workT + lf.off + (int64_t)(c0 + r) * lf.rows + r0 + q * 16;
+    *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(&tl[r][q * 16]);
+    *reinterpret_cast<bf16x8*>(dst + 8) = *reinterpret_cast<const bf16x8*>(&tl[r][q * 16 + 8]);
+}
+
 }  // namespace
 
 extern "C" int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
@@ -162,5 +189,17 @@ extern "C" int mr_cast_f32_to_bf16_params(const float* master, void* work_bf16, 
     hipLaunchKernelGGL(cast_params_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), master,
                        static_cast<__bf16*>(work_bf16), n / 8);
     MR_CHECK_LAUNCH("mr_cast_f32_to_bf16_params");
+    return MR_OK;
+}
+
+extern "C" int mr_transpose_leaves(const void* work_bf16, void* workT_bf16, const int32_t* leaves_dev, int32_t nleaf, int32_t tile_lo,
+                                   int32_t tile_hi, void* stream) {
+    MR_CHECK_ARG(work_bf16 && workT_bf16 && leaves_dev && nleaf > 0, "mr_transpose_leaves: null pointer / empty table");
+    MR_CHECK_ARG(tile_lo >= 0 && tile_hi >= tile_lo, "mr_transpose_leaves: bad tile range [%d, %d)", tile_lo, tile_hi);
+    if (tile_hi == tile_lo) return MR_OK;
+    hipLaunchKernelGGL(transpose_leaves_kernel, dim3((unsigned)(tile_hi - tile_lo)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __bf16*>(work_bf16), static_cast<__bf16*>(workT_bf16),
+                       reinterpret_cast<const TrLeaf*>(leaves_dev), nleaf, tile_lo);
+    MR_CHECK_LAUNCH("mr_transpose_leaves");
     return MR_OK;
 }

@@ -300,6 +300,9 @@ bool mr_gemm256_eligible(const mr_gemm_args* a);
 int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const mr_gemm_args*, int64_t, hipStream_t));
 
 bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s);
+// gemm3.hip
+bool mr_gemm3_eligible(const mr_gemm_args* a);
+int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s);
 
 extern int g_mr_opt_v1_only;        // mr_set_option("gemm_v1_only")
 static int use_gemm256() {
@@ -331,6 +334,11 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
     MR_CHECK_ARG(!a->colsum || (use_gemm256() && mr_gemm_colsum_supported(a) && a->ldcs >= a->N && ((uintptr_t)a->colsum % 16) == 0 && a->ldcs % 4 == 0),
                  "mr_gemm: colsum is only produced by the 256-row kernel with the aux epilogue (ask mr_gemm_colsum_supported)");
+    if (use_gemm256() && mr_gemm3_eligible(a)) {
+        mr_gemm3_launch(a, static_cast<hipStream_t>(stream));
+        MR_CHECK_LAUNCH("mr_gemm (ping-pong kernel)");
+        return MR_OK;
+    }
     if (use_gemm256() && mr_gemm256_eligible(a)) {
         mr_gemm256_launch(a, static_cast<hipStream_t>(stream), launch_splitk_reduce);
         MR_CHECK_LAUNCH("mr_gemm (256-row kernel)");

@@ -1,0 +1,607 @@
+// Third-generation bf16 MFMA GEMM for gfx950, "NT" operands only:  C[M,N] = A[M,K] . B[N,K]^T, both K-contiguous
+// (activations x dgrad weights as flax stores them; forward weights through their transposed bf16 working copy).
+//
+// 256 x {256,192} x 64 tiles, 8 waves as 2 (M) x 4 (N): a wave owns 128 x {64,48} of the tile = 8 x {4,3} accumulators of
+// v_mfma_f32_16x16x32_bf16, computed per k-tile in FOUR quadrants of 64 x {32,32|16} (16 | 8 MFMAs each).
+//
+// Two wave groups, PING-PONG.  Waves 0-3 and 4-7 are the two waves of each SIMD.  Every quadrant is a phase
+//     [ LDS fragment reads of the phase | LDS-DMA issue ]  s_barrier  [ MFMAs ]  s_barrier
+// and group 1 runs one barrier behind group 0, so that between any two barriers one wave of a SIMD issues MFMAs while its
+// partner issues LDS reads and DMA: the matrix pipe never waits for fragment reads of its own wave, which is what bounds
+// the one-barrier-per-k-tile kernel of gemm256.hip (k-loop decomposition).
+//
+// Per k-tile and wave TWO phases: phase 0 reads B (8 | 6 ds_read_b128) + A0 (8) and multiplies A0 x B (32 | 24 MFMAs),
+// phase 1 reads A1 (8) and multiplies A1 x B; A0 / A1 = the wave's two 64-row halves.  (-DMR_G3_PH4: four phases of 16 | 8
+// MFMAs, quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0): twice the barriers per MFMA.)
+// Operand rings, filled by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, zero fill beyond the extents):
+//     A: 3 stages x 32 KiB, two k-tiles ahead (issued in phase 0);
+//     B: 2 stages x {32,24} KiB: k-tile t+2 overwrites k-tile t's stage in phase 1, after the B reads of k-tile t
+//        (phase 0) have been retired by a counted lgkmcnt AHEAD of that phase's barrier.  Every LDS read that a later
+//        DMA overwrites is retired ahead of a barrier the issuing wave passes before it issues: safe by construction.
+//   = 160 KiB (BN = 256) | 144 KiB (BN = 192).  One counted s_waitcnt vmcnt per k-tile (never 0 inside a tile's loop), in
+// phase 3 ahead of the barrier that precedes the first read of k-tile t+1.  The issue cursors run across output tiles
+// (persistent workgroups), so a tile's first two k-tiles land under the previous tile's epilogue.
+// The swizzle (chunk ^= (row >> 1) & 7) lives on the DMA's per-lane SOURCE address and is undone by the fragment reads.
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "gemm256_sched.h"
+
+namespace g3 {
+
+using namespace g256;
+
+template <int BN> struct Geo3 {
+    static_assert(BN == 256 || BN == 192, "tile widths of the ping-pong kernel");
+    static constexpr int WCOLS = BN / 4, NJ = WCOLS / 16, JB0 = 2, JB1 = NJ - 2;
+    static constexpr int STAGE_A = 256 * 128, NSTAGE_A = 3;
+    static constexpr int STAGE_B = BN * 128, NSTAGE_B = 2;
+    static constexpr int OFF_B = NSTAGE_A * STAGE_A;
+    static constexpr int LDS_BYTES = OFF_B + NSTAGE_B * STAGE_B;
+    static constexpr int NBP_HI = (BN == 256) ? 2 : 1;      // B pieces per wave for rows 128.. of the B tile
+    static constexpr int WAITN = 4 + 2 + NBP_HI;            // DMA pieces a wave issues per k-tile
+};
+static_assert(Geo3<256>::LDS_BYTES == 160 * 1024 && Geo3<192>::LDS_BYTES == 144 * 1024, "LDS budget");
+
+#ifdef MR_G3_NOSYNC_EPI
+constexpr bool EPI_SYNC = false;
+#else
+constexpr bool EPI_SYNC = true;
+#endif
+#ifdef MR_G3_PH4
+constexpr bool PH4 = true;
+#else
+constexpr bool PH4 = false;
+#endif
+
+// MODE (the epilogue, fixed per launch: one problem per launch):
+//   0: bias | 1: bias + "rotary" scales | 2: bias + GELU, gelu' copy to c2 | 3: + residual | 4: x aux (+ column sums)
+template <int BN, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
+    using GEO = Geo3<BN>;
+    constexpr int WCOLS = GEO::WCOLS, NJ = GEO::NJ, JB1 = GEO::JB1;
+    constexpr int STAGE_A = GEO::STAGE_A, STAGE_B = GEO::STAGE_B, OFF_B = GEO::OFF_B;
+    constexpr int NSTAGE_A = GEO::NSTAGE_A, NSTAGE_B = GEO::NSTAGE_B, NBP_HI = GEO::NBP_HI, WAITN = GEO::WAITN;
+    // store instructions a wave issues per tile, ALL unconditional (masked lanes store to an out-of-range buffer offset, which the
+    // hardware drops): vmcnt retires in order, so the first k-tile behind an epilogue may leave exactly these -- and its own DMA
+    // pieces -- in flight while waiting for the k-tile issued AHEAD of the epilogue; the stores then drain under two k-tiles of
+    // MFMAs instead of stalling the wave at its first counted wait.  (The column-sum stores of MODE 4 are not counted: fewer
+    // outstanding operations than allowed only makes the wait conservative.)
+    constexpr int NST = 8 * (NJ / 2 + (NJ & 1)) * (MODE == 2 ? 2 : 1);
+    static_assert(WAITN + NST <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) char smem[GEO::LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;             // wr = the wave GROUP (and the tile's row half), wc = column quarter
+    const int g = lane >> 4, li = lane & 15;
+
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
+    const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+    const SkRange skr = {0, 0, 0, 0, 0, 0, 0, 0};
+    // The workgroup's items (output tiles), decoded ONCE: lane q holds item q (m0 < 0 = none), fetched with v_readlane.  Decoding
+    // an item at every cursor switch -- integer divisions and kernel-argument loads inside a phase that all eight waves wait
+    // for -- cost ~4 000 cycles per tile (in-kernel stamps).  <= 64 items per workgroup (host check).
+    int m0v, n0v;
+    {
+        const Item it = make_item<64, 8>(ga, bperm + lane * G, BN, bperm, skr);
+        m0v = it.valid ? it.m0 : -1;
+        n0v = it.n0;
+    }
+    auto item_m0 = [&](int q) -> int { return q < 64 ? __builtin_amdgcn_readlane(m0v, q) : -1; };
+    auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
+    if (item_m0(0) < 0) return;
+    const mr_gemm_args& p0 = ga.p[0];
+    const int nkt = (int)(p0.K >> 6);
+    const unsigned lda2 = (unsigned)p0.lda * 2u, ldb2 = (unsigned)p0.ldb * 2u;
+    // operand descriptors: rows >= M (A) / >= N (B) lie beyond num_records and read as zeros -- the per-lane offsets carry the
+    // item's first row, so no predicate per piece: offset(item) = offset(row 0 item) + m0 * lda2
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p0.A), 0, (int)(((p0.M - 1) * p0.lda + p0.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p0.B), 0, (int)(((p0.N - 1) * p0.ldb + p0.K) * 2), 0x00020000);
+    auto rel = [&](int piece, unsigned ld2) -> unsigned {      // byte offset of this lane's chunk of 1-KiB piece `piece` in an item at row 0
+        const int row = piece * 8 + (lane >> 3);
+        return (unsigned)row * ld2 + (unsigned)(((lane & 7) ^ swz_kc(row)) * 16);
+    };
+    const unsigned ar0 = rel(wave * 2, lda2), ar1 = rel(wave * 2 + 1, lda2), ar2 = rel(16 + wave * 2, lda2), ar3 = rel(16 + wave * 2 + 1, lda2);
+    const unsigned br0 = rel(wave * 2, ldb2), br1 = rel(wave * 2 + 1, ldb2);
+    const unsigned br2 = rel(NBP_HI == 2 ? 16 + wave * 2 : 16 + wave, ldb2), br3 = rel(16 + wave * 2 + 1, ldb2);
+
+    // ---- issue cursors (one per operand), two k-tiles ahead of the compute cursor, across item boundaries ----
+    int qa = 0, ika = 0, ista = 0, qb = 0, ikb = 0, istb = 0;
+    bool va = true, vb = true, issued = false;
+    unsigned abase = (unsigned)item_m0(0) * lda2, bbase = (unsigned)item_n0(0) * ldb2;
+    // the issue slots of a k-tile: A rows 0-127, A rows 128-255 (+ advance), B rows 0-127, B rows 128.. (+ advance)
+#define G3_ISSUE_A_LO()                                                                                                 \
+    do {                                                                                                                \
+        issued = va;                                                                                                    \
+        if (va) {                                                                                                       \
+            char* st_ = smem + ista * STAGE_A + wave * 2048;                                                            \
+            const unsigned sa = (unsigned)ika * 128u;                                                                   \
+            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, abase + ar0, sa, 0, 0);                                               \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, abase + ar1, sa, 0, 0);                                        \
+        }                                                                                                               \
+    } while (0)
+#define G3_ISSUE_A_HI()                                                                                                 \
+    do {                                                                                                                \
+        if (va) {                                                                                                       \
+            char* st_ = smem + ista * STAGE_A + 16384 + wave * 2048;                                                    \
+            const unsigned sa = (unsigned)ika * 128u;                                                                   \
+            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, abase + ar2, sa, 0, 0);                                               \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, abase + ar3, sa, 0, 0);                                        \
+            ista = (ista == NSTAGE_A - 1) ? 0 : ista + 1;                                                               \
+            if (++ika == nkt) {                                                                                         \
+                ika = 0;                                                                                                \
+                const int m_ = item_m0(++qa);                                                                           \
+                va = m_ >= 0;                                                                                           \
+                abase = (unsigned)m_ * lda2;                                                                            \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#define G3_ISSUE_B_LO()                                                                                                 \
+    do {                                                                                                                \
+        if (vb) {                                                                                                       \
+            char* sb_ = smem + OFF_B + istb * STAGE_B + wave * 2048;                                                    \
+            const unsigned sb = (unsigned)ikb * 128u;                                                                   \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_), 16, bbase + br0, sb, 0, 0);                                               \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bbase + br1, sb, 0, 0);                                        \
+        }                                                                                                               \
+    } while (0)
+#define G3_ISSUE_B_HI()                                                                                                 \
+    do {                                                                                                                \
+        if (vb) {                                                                                                       \
+            char* sb_ = smem + OFF_B + istb * STAGE_B + 16384 + wave * (NBP_HI * 1024);                                 \
+            const unsigned sb = (unsigned)ikb * 128u;                                                                   \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_), 16, bbase + br2, sb, 0, 0);                                               \
+            if (NBP_HI == 2) MR_DMA(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bbase + br3, sb, 0, 0);                       \
+            istb = (istb == NSTAGE_B - 1) ? 0 : istb + 1;                                                               \
+            if (++ikb == nkt) {                                                                                         \
+                ikb = 0;                                                                                                \
+                vb = item_m0(++qb) >= 0;                                                                                \
+                bbase = (unsigned)item_n0(qb) * ldb2;                                                                   \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#define G3_RING_WAIT()                                                                                                  \
+    do {                                                                                                                \
+        if (issued) wait_vmcnt<WAITN>();                                                                                \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    } while (0)
+#define G3_BARRIER()                                                                                                    \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#define G3_LGKM(n)                                                                                                      \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+
+    // prologue: k-tiles 0 and 1 of the sequence; k-tile 0 has landed when all but the second one's pieces have
+    G3_ISSUE_A_LO(); G3_ISSUE_A_HI(); G3_ISSUE_B_LO(); G3_ISSUE_B_HI();
+    G3_ISSUE_A_LO(); G3_ISSUE_A_HI(); G3_ISSUE_B_LO(); G3_ISSUE_B_HI();
+    G3_RING_WAIT();
+    G3_BARRIER();
+    if (wr == 1) G3_BARRIER();          // group 1 runs one barrier behind group 0 from here on
+
+    int qc = 0, csa = 0, csb = 0;
+    int cm0 = item_m0(0), cn0 = item_n0(0);
+    bool have_stores = false;          // an epilogue's stores may be in flight (never before the workgroup's first tile)
+    // The bias is the accumulators' INITIAL value (no add per element in the epilogue).  A tile's bias is fetched and widened in
+    // the PREVIOUS tile's epilogue, ahead of its stores (a load consumed behind them would wait for them: vmcnt retires in order).
+    constexpr bool BIAS = MODE <= 2;             // residual / aux problems carry no bias (host check)
+    f32x4 binit[NJ];
+    auto fetch_bias = [&](int n0_) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) binit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS) {
+            const __bf16* const bp = static_cast<const __bf16*>(p0.bias);
+            if (bp != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int gn = n0_ + wc * WCOLS + j * 16 + g * 4;
+                    if (gn < (int)p0.N) {
+                        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bp + gn);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) binit[j][r] = (float)b4[r];
+                    }
+                }
+            }
+        }
+    };
+    fetch_bias(cn0);
+#ifdef MR_G3_STAMPS
+    unsigned long long* stamps = static_cast<unsigned long long*>(ga.p[0].workspace);
+    int nstamp = 0;
+#define G3_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (lane == 0 && (wave & 3) == 0 && nstamp < 8) stamps[((blockIdx.x * 2 + wr) * 8 + nstamp) * 4 + (slot)] = t_;  \
+    } while (0)
+    // per-k-tile stamps of the first 8 workgroups' wave 0 (second KiB-aligned region of the workspace)
+#define G3_KSTAMP(t)                                                                                \
+    do {                                                                                            \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (lane == 0 && wave == 0 && blockIdx.x < 8 && nstamp < 4 && (t) < 16) stamps[65536 + (blockIdx.x * 4 + nstamp) * 16 + (t)] = t_;  \
+    } while (0)
+#else
+#define G3_STAMP(slot) do {} while (0)
+#define G3_KSTAMP(t) do {} while (0)
+#endif
+    while (cm0 >= 0) {
+        // accumulators TRANSPOSED (mfma(B-frag, A-frag)): the lane holds C[m = .. + li][n = .. + 4 g + r]
+        f32x4 acc[8][NJ];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = binit[j];
+
+        G3_STAMP(0);
+        auto ktile = [&](auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;       // the tile's first k-tile: the previous tile's stores are in flight
+            const char* As = smem + csa * STAGE_A;
+            const char* Bs = smem + OFF_B + csb * STAGE_B;
+            bf16x8 a[4][2], b[NJ][2];
+            auto read_b = [&](int j0, int j1) {
+#pragma unroll
+                for (int j = j0; j < j1; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) b[j][kk] = frag<false, 256, 64>(Bs, wc * WCOLS + j * 16, kk, lane);
+            };
+            auto read_a = [&](int half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) a[i][kk] = frag<false, 256, 64>(As, wr * 128 + half * 64 + i * 16, kk, lane);
+            };
+            auto mfmas = [&](int half, int j0, int j1) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = j0; j < j1; ++j)
+                            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[half * 4 + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto tile_wait = [&]() {        // k-tile t+1 has landed behind the next barrier
+                if (FIRST && issued && have_stores) wait_vmcnt<WAITN + NST>();
+                else G3_RING_WAIT();
+            };
+            if constexpr (!PH4) {
+                // ---------------- phase 0: A0 x B.  The B reads are retired AHEAD of the barrier (phase 1 restages B) ----------------
+                read_b(0, NJ);
+                __builtin_amdgcn_sched_barrier(0);      // B before A: the counted wait below relies on the issue order
+                read_a(0);
+                __builtin_amdgcn_sched_barrier(0);
+                G3_ISSUE_A_LO();
+                G3_ISSUE_A_HI();
+                G3_LGKM(8);
+                G3_BARRIER();
+                G3_LGKM(0);
+                mfmas(0, 0, NJ);
+                G3_BARRIER();
+                // ---------------- phase 1: A1 x B.  The A reads are retired ahead of the barrier (the next phase 0 restages A) ----------------
+                read_a(1);
+                __builtin_amdgcn_sched_barrier(0);
+                G3_ISSUE_B_LO();
+                G3_ISSUE_B_HI();
+                G3_LGKM(0);
+                tile_wait();
+                G3_BARRIER();
+                mfmas(1, 0, NJ);
+                G3_BARRIER();
+            } else {
+                // ---------------- four phases: (A0,B0) (A0,B1) (A1,B1) (A1,B0) ----------------
+                read_b(0, 2);
+                read_a(0);
+                __builtin_amdgcn_sched_barrier(0);
+                G3_ISSUE_A_LO();
+                G3_BARRIER();
+                G3_LGKM(0);
+                mfmas(0, 0, 2);
+                G3_BARRIER();
+                read_b(2, NJ);
+                __builtin_amdgcn_sched_barrier(0);
+                G3_ISSUE_A_HI();
+                G3_LGKM(0);             // ahead of the barrier: B is restaged from the next phase on
+                G3_BARRIER();
+                mfmas(0, 2, NJ);
+                G3_BARRIER();
+                read_a(1);
+                __builtin_amdgcn_sched_barrier(0);
+                G3_ISSUE_B_LO();
+                G3_BARRIER();
+                G3_LGKM(0);
+                mfmas(1, 2, NJ);
+                G3_BARRIER();
+                G3_ISSUE_B_HI();
+                tile_wait();
+                G3_BARRIER();
+                mfmas(1, 0, 2);
+                G3_BARRIER();
+            }
+            csa = (csa == NSTAGE_A - 1) ? 0 : csa + 1;
+            csb = (csb == NSTAGE_B - 1) ? 0 : csb + 1;
+        };
+        G3_KSTAMP(0);
+        ktile(std::integral_constant<bool, true>{});
+        for (int t = 1; t < nkt; ++t) { G3_KSTAMP(t); ktile(std::integral_constant<bool, false>{}); }
+        G3_STAMP(1);
+
+        // ---------------- epilogue (bf16 output; registers + ordinary loads, no LDS) ----------------
+        // With EPI_SYNC the two groups' epilogues run side by side (group 0 waits for group 1's last MFMAs, group 1 waits behind
+        // its epilogue for group 0's, which restores the one-barrier offset); without, they run one after the other.
+        if (EPI_SYNC && wr == 0) G3_BARRIER();
+        {
+            const mr_gemm_args& pc = ga.p[0];
+            const int eM = (int)pc.M, eN = (int)pc.N;
+            const int e_ldc = (int)pc.ldc;
+            const __bf16* const pre_src = static_cast<const __bf16*>(MODE == 3 ? pc.residual : pc.aux);
+            const int64_t pre_ld = MODE == 3 ? pc.ldr : pc.ldaux;
+            const float* const e_rot = pc.rot_tab;
+            const int e_rot_rows = (int)pc.rot_rows, e_rot_cols = (int)pc.rot_cols;
+            const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
+            const void* const dummy = pc.A;
+            float* const e_cs = static_cast<float*>(pc.colsum);
+            const int64_t e_ldcs = pc.ldcs;
+            auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
+            const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
+            // output descriptors: every store is issued by every lane; rows >= M / columns >= N get an out-of-range offset
+            const unsigned c_bytes = (unsigned)(((int64_t)out_row(eM - 1) * e_ldc + eN) * 2);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pc.C, 0, (int)c_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(MODE == 2 ? pc.c2 : pc.C, 0, (int)c_bytes, 0x00020000);
+
+            if (item_m0(qc + 1) >= 0) fetch_bias(item_n0(qc + 1));
+            constexpr bool HAS_X = MODE == 3 || MODE == 4;
+            constexpr int LXD = 4;                                   // row blocks of the residual / aux tile in flight
+            constexpr int NXV = NJ / 2 + (NJ & 1);
+            u32x4 lx[HAS_X ? LXD : 1][HAS_X ? NXV : 1];
+            auto lx_fetch = [&](int i, u32x4 (&dst)[HAS_X ? NXV : 1]) {
+                if constexpr (HAS_X) {
+                    const int gm = wrow0 + i * 16 + li;
+                    const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
+#pragma unroll
+                    for (int jp = 0; jp < NJ / 2; ++jp) {       // 16 bytes per lane in the layout of the widened stores
+                        const int gn = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                        dst[jp] = *reinterpret_cast<const u32x4*>((gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy);
+                    }
+                    if (NJ & 1) {
+                        const int gn = wcol0 + (NJ - 1) * 16 + g * 4;
+                        const u32x2 v = *reinterpret_cast<const u32x2*>((gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy);
+                        dst[NJ / 2] = u32x4{v[0], v[1], 0u, 0u};
+                    }
+                }
+            };
+            if constexpr (HAS_X) {
+#pragma unroll
+                for (int i = 0; i < LXD; ++i) lx_fetch(i, lx[i]);
+            }
+            constexpr bool ROT = MODE == 1;
+            f32x4 rotv[ROT ? 2 : 1][ROT ? NJ : 1];
+            auto rot_fetch = [&](int i, f32x4 (&dst)[ROT ? NJ : 1]) {
+                if constexpr (ROT) {
+                    const int gm = wrow0 + i * 16 + li;
+                    const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int gn0 = wcol0 + j * 16 + g * 4;      // the lane's 4 columns lie inside one head's first or second 32 dims
+                        const bool on = (gn0 & 63) < 32 && gn0 < e_rot_cols;
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(on ? (const void*)(e_rot + (int64_t)rr * 32 + (gn0 & 63)) : (const void*)e_rot);
+                        dst[j] = on ? tv : f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+                }
+            };
+            if constexpr (ROT) rot_fetch(0, rotv[0]);
+            constexpr bool CS = MODE == 4;
+            const bool f_cs = CS && e_cs != nullptr;
+            f32x4 cs[CS ? NJ : 1];
+            if constexpr (CS) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // Stores widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 of adjacent 16-column blocks; one v_permlane16_swap per
+            // dword leaves every lane with 8 contiguous columns (lane rows g = 0/2 own block 2jp, columns 0-7 / 8-15; g = 1/3 block 2jp+1)
+            auto store_pair = [&](const __amdgpu_buffer_rsrc_t& r, unsigned rowoff, bool mok, int jp, bf16x4 va, bf16x4 vb) {
+                u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+                const unsigned off = (mok && col < eN) ? rowoff + (unsigned)col * 2u : OOB;
+#ifndef MR_G3_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, off, 0, 0);
+#else
+                asm volatile("" ::"v"(s0), "v"(s1), "v"(off));
+#endif
+            };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gm = wrow0 + i * 16 + li;
+                const bool mok = gm < eM;
+                const unsigned rowoff = (unsigned)out_row(gm) * (unsigned)e_ldc * 2u;
+                bf16x4 oc[NJ], od[NJ], xs[NJ];
+                if constexpr (ROT) { if (i < 7) rot_fetch(i + 1, rotv[(i + 1) & 1]); }
+                if constexpr (HAS_X) {       // undo the 16-byte load layout
+#pragma unroll
+                    for (int jp = 0; jp < NJ / 2; ++jp) {
+                        const u32x4 v4 = lx[i % LXD][jp];
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(v4[0], v4[2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(v4[1], v4[3], false, false);
+                        xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
+                        xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
+                    }
+                    if (NJ & 1) xs[NJ - 1] = __builtin_bit_cast(bf16x4, u32x2{lx[i % LXD][NJ / 2][0], lx[i % LXD][NJ / 2][1]});
+                    if (i + LXD < 8) lx_fetch(i + LXD, lx[i % LXD]);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j];
+                    if constexpr (ROT) v *= rotv[i & 1][j];
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                    od[j] = o;
+                    if constexpr (MODE == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sg = sigmoid1702(v[r]);
+                            o[r] = (__bf16)(v[r] * sg);
+                            od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
+                        }
+                    }
+                    if constexpr (HAS_X) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = (MODE == 3) ? (__bf16)((float)o[r] + (float)xs[j][r]) : (__bf16)((float)o[r] * (float)xs[j][r]);
+                    }
+                    oc[j] = o;
+                    if constexpr (CS) {
+                        if (f_cs && mok) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cs[j][r] += (float)o[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    if constexpr (MODE == 2) store_pair(rc2, rowoff, mok, jp, od[2 * jp], od[2 * jp + 1]);
+                    store_pair(rc, rowoff, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
+                }
+                if (NJ & 1) {                                          // BN = 192: the odd block keeps 8-byte stores
+                    const int col = wcol0 + (NJ - 1) * 16 + g * 4;
+                    const unsigned off = (mok && col < eN) ? rowoff + (unsigned)col * 2u : OOB;
+#ifndef MR_G3_NOSTORE
+                    if constexpr (MODE == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, od[NJ - 1]), rc2, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oc[NJ - 1]), rc, off, 0, 0);
+#else
+                    asm volatile("" ::"v"(od[NJ - 1]), "v"(oc[NJ - 1]), "v"(off));
+#endif
+                }
+                if constexpr (CS) {
+                    // column sums of the stored tile per 64-row band (mr_gemm_args.colsum: partial row 4 * (m / 256) + (m % 256) / 64):
+                    // 4 row blocks summed in registers, the 16 rows of a block across the DPP row
+                    if ((i & 3) == 3 && f_cs) {
+                        float* const prow = e_cs + (int64_t)((cm0 / 256) * 4 + wr * 2 + (i >> 2)) * e_ldcs;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cs[j][r] = row16_sum(cs[j][r]);
+                            const int col = wcol0 + j * 16 + g * 4;
+                            if (li == 0 && col < eN) *reinterpret_cast<f32x4*>(prow + col) = cs[j];
+                            cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
+            }
+#ifndef MR_G3_NOSTORE
+            have_stores = true;
+#endif
+        }
+        G3_STAMP(2);
+#ifdef MR_G3_STAMPS
+        ++nstamp;
+#endif
+        if (EPI_SYNC && wr == 1) G3_BARRIER();
+        ++qc;
+        cm0 = item_m0(qc);
+        cn0 = item_n0(qc);
+    }
+    if (wr == 0) G3_BARRIER();          // pairs with group 1's last barrier
+}
+
+}  // namespace g3
+
+constexpr int64_t NUM_CU3 = 256;    // MI355X
+extern int g_mr_opt_gemm3;           // mr_set_option("gemm3"): 1 = on (default), 0 = off, 256 / 192 = on with that tile width forced
+
+// The ping-pong kernel takes: NT operands (A [M,K], B [N,K], K % 64 == 0), bf16 output, at least one full round of 256-row tiles'
+// worth of work, and one of the epilogue combinations the step uses -- bias; bias + "rotary"; bias + GELU with the gelu' copy;
+// residual; aux (with or without column sums).
+bool mr_gemm3_eligible(const mr_gemm_args* a) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MR_GEMM3"); env = e ? atoi(e) : 1; }
+    if (!env || !g_mr_opt_gemm3) return false;
+    if (a->transA || !a->transB || a->c_dtype != MR_DT_BF16) return false;
+    const bool forced = g_mr_opt_gemm3 == 256 || g_mr_opt_gemm3 == 192;      // tests: any shape the kernel can take
+    if (a->K % 64 != 0) return false;
+    if (!forced && (a->K < 128 || a->N < 192 || a->M < 1024)) return false;
+    if (a->M * a->lda * 2 >= (1LL << 31) || a->N * a->ldb * 2 >= (1LL << 31)) return false;    // 32-bit buffer offsets
+    {
+        const int64_t last = a->out_grp > 0 ? ((a->M - 1) / a->out_grp) * a->out_grp_stride + a->out_grp_off + (a->M - 1) % a->out_grp : a->M - 1;
+        if ((last * a->ldc + a->N) * 2 >= (1LL << 31)) return false;
+    }
+    const int n_extra = (a->rot_tab != nullptr) + (a->residual != nullptr) + (a->aux != nullptr) + (a->c2 != nullptr);
+    if (n_extra > 1) return false;
+    if ((a->c2 != nullptr) != (a->act == MR_ACT_GELU1702)) return false;
+    if (a->colsum && !a->aux) return false;
+    if (a->bias && (a->residual || a->aux)) return false;      // the bias rides in the accumulators of the bias modes only
+    // enough tiles to fill the chip (short-K problems with few tiles go to the split-K path of the one-barrier kernel)
+    const int64_t tm = (a->M + 255) / 256;
+    if (tm * ((a->N + 191) / 192) > 64 * 256) return false;     // <= 64 items per workgroup (the kernel keeps them one per lane)
+    if (!forced && tm * ((a->N + 255) / 256) < 128) return false;
+    return true;
+}
+
+int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
+    const int64_t tm = (a->M + 255) / 256;
+    // tile width: fewest CU-rounds, a 192-wide tile costing 3/4 of a 256-wide one
+    const int64_t t256 = tm * ((a->N + 255) / 256), t192 = tm * ((a->N + 191) / 192);
+    const int64_t c256 = ((t256 + NUM_CU3 - 1) / NUM_CU3) * 100, c192 = ((t192 + NUM_CU3 - 1) / NUM_CU3) * 78;
+    int bn = (c192 < c256) ? 192 : 256;
+    if (g_mr_opt_gemm3 == 256 || g_mr_opt_gemm3 == 192) bn = g_mr_opt_gemm3;
+    const int64_t tn = (a->N + bn - 1) / bn, nwork = tm * tn;
+    const int64_t gsz = nwork < NUM_CU3 ? nwork : NUM_CU3;
+    g256::G256Args ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.count = 1; ga.nwork = (int)nwork; ga.splits = 1; ga.kt_per_split = (int)(a->K / 64);
+    if (gsz == NUM_CU3 && nwork >= 2 * NUM_CU3) {
+        // XCD partition of the tile grid (see G256Args.xmode): fewest rounds first, then least traffic out of L2
+        const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
+        double best = 1e300;
+        for (int px = 1; px <= 8; px *= 2) {
+            const int py = 8 / px;
+            if (px > tm || py > tn) continue;
+            int64_t rounds = 0;
+            for (int xi = 0; xi < px; ++xi)
+                for (int xj = 0; xj < py; ++xj) {
+                    const int64_t hm = (xi + 1) * tm / px - xi * tm / px, hn = (xj + 1) * tn / py - xj * tn / py;
+                    const int64_t r = (hm * hn + NUM_CU3 / 8 - 1) / (NUM_CU3 / 8);
+                    if (r > rounds) rounds = r;
+                }
+            const bool b_fits = b_bytes / py < 2.5e6;
+            const double traffic = a_bytes * py + b_bytes * px * (b_fits ? 1.0 : (double)rounds);
+            const double cost = (double)rounds * 1e12 + traffic;
+            if (cost < best) { best = cost; ga.px = px; ga.py = py; }
+        }
+        if (best < 1e300) { ga.xmode = 1; ga.tm = (int)tm; ga.tn = (int)tn; }
+    }
+    ga.tiles_n[0] = (int)tn;
+    ga.tile_start[0] = 0;
+    for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
+    ga.p[0] = *a;
+    dim3 grid((unsigned)gsz), block(512);
+    int mode = 0;
+    if (a->c2) mode = 2;
+    else if (a->rot_tab) mode = 1;
+    else if (a->residual) mode = 3;
+    else if (a->aux) mode = 4;
+#define G3_LAUNCH(MODE)                                                                               \
+    do {                                                                                              \
+        if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE>), grid, block, 0, s, ga);      \
+        else hipLaunchKernelGGL((g3::gemm3_kernel<192, MODE>), grid, block, 0, s, ga);                \
+    } while (0)
+    switch (mode) {
+        case 0: G3_LAUNCH(0); break;
+        case 1: G3_LAUNCH(1); break;
+        case 2: G3_LAUNCH(2); break;
+        case 3: G3_LAUNCH(3); break;
+        default: G3_LAUNCH(4); break;
+    }
+#undef G3_LAUNCH
+    return 0;
+}

@@ -14,7 +14,9 @@ void mr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mr_last_error(void) { return g_err; }
-extern "C" int mr_version(void) { return 1; }
+// 2: mr_gemm_args grew colsum / ldcs, mr_attention_bwd / mr_unit_norm_scale_bwd / mr_contrastive_lse gained arguments (round 2);
+// 3: mr_transpose_leaves, mr_set_option("gemm3") (round 3)
+extern "C" int mr_version(void) { return 3; }
 
 // ---- process-wide knobs (include/mreserve_hip.h: mr_set_option) ----
 int g_mr_opt_tile_n = 0;
@@ -22,12 +24,14 @@ int g_mr_opt_v1_only = 0;
 int g_mr_opt_group_tile_n = 0;
 int g_mr_opt_group_streamk = -1;
 int g_mr_opt_group_headtail = -1;
+int g_mr_opt_gemm3 = 1;
 extern "C" int mr_set_option(const char* name, int value) {
     if (name && !strcmp(name, "gemm_tile_n")) { g_mr_opt_tile_n = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_v1_only")) { g_mr_opt_v1_only = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_group_tile_n")) { g_mr_opt_group_tile_n = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_group_streamk")) { g_mr_opt_group_streamk = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_group_headtail")) { g_mr_opt_group_headtail = value; return MR_OK; }
+    if (name && !strcmp(name, "gemm3")) { g_mr_opt_gemm3 = value; return MR_OK; }
     mr_set_error("mr_set_option: unknown option '%s'", name ? name : "(null)");
     return MR_EINVAL;
 }

@@ -83,6 +83,14 @@ class TowerEngine:
     def gemm(self, a, b, out, **kw):
         return ops.gemm(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
 
+    def fgemm(self, a, name, out, **kw):
+        """Forward Dense: out = a @ W[name].  The bf16 program reads the TRANSPOSED working copy where the store keeps one
+        (params.ParamStore.wT): both operands contraction-contiguous, the fast GEMM path; same values, same result."""
+        wT = getattr(self.p, 'wT', None) if self.dtype == BF16 else None
+        if wT and name in wT and os.environ.get('MR_NO_WT') != '1':
+            return self.gemm(a, wT[name], out, transB=True, **kw)
+        return self.gemm(a, self.W[name], out, **kw)
+
     def gemm_args(self, a, b, out, **kw):
         return ops.gemm_args(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
 
@@ -195,12 +203,12 @@ class TowerEngine:
             n = self._names(prefix, l)
             x = st.X[l]
             ops.layernorm_fwd(x, W[n['g1']], W[n['b1']], st.ln1[l], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1])
-            self.gemm(st.ln1[l], W[n['wqkv']], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
+            self.fgemm(st.ln1[l], n['wqkv'], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
             ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
-            self.gemm(st.att[l], W[n['wo']], st.xmid[l], residual=x)
+            self.fgemm(st.att[l], n['wo'], st.xmid[l], residual=x)
             ops.layernorm_fwd(st.xmid[l], W[n['g2']], W[n['b2']], st.ln2[l], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1])
-            self.gemm(st.ln2[l], W[n['w1']], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
-            self.gemm(st.hact[l], W[n['w2']], st.X[l + 1], residual=st.xmid[l])
+            self.fgemm(st.ln2[l], n['w1'], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
+            self.fgemm(st.hact[l], n['w2'], st.X[l + 1], residual=st.xmid[l])
         k = 2 * st.L + 1
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
@@ -260,13 +268,13 @@ class TowerEngine:
         W, nh = self.W, st.H // 64
         ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
         self.encoder_forward(st, prefix_t, rot, None)
-        self.gemm(self._cls_view(st.xf, st.nseq, st.S), W[f'{prefix_t}/cls_proj/kernel'], out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
+        self.fgemm(self._cls_view(st.xf, st.nseq, st.S), f'{prefix_t}/cls_proj/kernel', out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
         ops.rows_mean_fwd(st.xf, pool_rows, qin)
-        self.gemm(qin, W[f'{prefix_pool}/query/kernel'], q, bias=W[f'{prefix_pool}/query/bias'])
-        self.gemm(st.xf, W[f'{prefix_pool}/key/kernel'], k, bias=W[f'{prefix_pool}/key/bias'])
-        self.gemm(st.xf, W[f'{prefix_pool}/value/kernel'], v, bias=W[f'{prefix_pool}/value/bias'])
+        self.fgemm(qin, f'{prefix_pool}/query/kernel', q, bias=W[f'{prefix_pool}/query/bias'])
+        self.fgemm(st.xf, f'{prefix_pool}/key/kernel', k, bias=W[f'{prefix_pool}/key/bias'])
+        self.fgemm(st.xf, f'{prefix_pool}/value/kernel', v, bias=W[f'{prefix_pool}/value/bias'])
         ops.poolattn_fwd(q, k, v, pool_rows, po, probs, nh)
-        self.gemm(po, W[f'{prefix_pool}/out/kernel'], out_seq, bias=W[f'{prefix_pool}/out/bias'])
+        self.fgemm(po, f'{prefix_pool}/out/kernel', out_seq, bias=W[f'{prefix_pool}/out/bias'])
 
     def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D,
                                   layer_done=None, tr=None):
@@ -447,7 +455,7 @@ class PretrainEngine(TowerEngine):
                 a_view = self.a_in[:, :d.a_patch * 65]
             else:
                 a_view = audio
-            self.gemm(a_view, W['audio_encoder/embedding/kernel'], ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
+            self.fgemm(a_view, 'audio_encoder/embedding/kernel', ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
             self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                           self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
                                           self.a_probs, self.audio_seq, self.a_cls)
@@ -456,7 +464,7 @@ class PretrainEngine(TowerEngine):
         self._on_side(audio_fwd)
         # vision tower (modeling.py:379-430)
         images = self._images2d = batch['images'].reshape(d.Nv * d.hw, d.pp3)
-        self.gemm(images, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self.fgemm(images, 'vision_encoder/embedding/kernel', tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                       self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                       self.v_probs, self.imgs_seq, self.v_cls)
@@ -468,14 +476,14 @@ class PretrainEngine(TowerEngine):
             ops.segment_sum([emb], self._pl('span_gather_indptr'), self._pl('span_gather_idx'), ts.xin)
             ops.fill_rows(W['span_encoder/transformer/cls'], ts.xin, ts.nseq, ts.S, 0)
             self.encoder_forward(ts, 'span_encoder/transformer', self.tables['span_rot'], self._pl('span_code'))
-            self.gemm(self._cls_view(ts.xf, ts.nseq, ts.S), W['span_encoder/transformer/cls_proj/kernel'], self.s_cls,
+            self.fgemm(self._cls_view(ts.xf, ts.nseq, ts.S), 'span_encoder/transformer/cls_proj/kernel', self.s_cls,
                      bias=W['span_encoder/transformer/cls_proj/bias'])
         self.side_stream.wait_stream(main)
         self._on_side(span_fwd)
         # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
         self.encoder_forward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'))
-        self.gemm(tj.xf, W['head/kernel'], self.hj, bias=W['head/bias'])
+        self.fgemm(tj.xf, 'head/kernel', self.hj, bias=W['head/bias'])
         ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)
         ops.segment_sum([self.a_cls], self._pl('acls_indptr'), self._pl('acls_idx'), self.acls_g)
         main.wait_stream(self.side_stream)

@@ -141,7 +141,7 @@ class VCREngine(TowerEngine):
     def forward_device(self, image):
         d, W, tv, tj = self.d, self.W, self.tv, self.tj
         self._images2d = image.reshape(d.B * d.hw, d.pp3)
-        self.gemm(self._images2d, W['vision_encoder/embedding/kernel'], tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
+        self.fgemm(self._images2d, 'vision_encoder/embedding/kernel', tv.xin, bias=W['vision_encoder/embedding/bias'], row_map=(d.hw, d.Sv, 1))
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
                                       self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.imgs_seq, self.v_cls)
         ops.segment_sum([W['token_encoder/Embed_0/embedding'], self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
@@ -253,6 +253,7 @@ class FinetuneTrainState:
             bc1, bc2 = 1.0 - b1 ** (self.step + 1), 1.0 - b2 ** (self.step + 1)
         ops.adam_bf16_update_finetune(p.master, p.work, p.grad, p.mu, p.nu, p.orig, p.decay_flags, b1, b2, oc.get('eps', 1e-6),
                                       oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
+        p.update_transposed()
         self.step += 1
         return self
 

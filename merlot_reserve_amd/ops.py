@@ -407,6 +407,13 @@ def nan_to_num_(g):
 
 
 @_timed('optimizer')
+def transpose_leaves(work, workT, leaves_dev, nleaf, tile_lo, tile_hi):
+    """workT <- per-leaf transposes of work for the 64 x 64 tiles [tile_lo, tile_hi) of the leaf table (params.ParamStore)."""
+    check(_lib.load().mr_transpose_leaves(work.data_ptr(), workT.data_ptr(), leaves_dev.data_ptr(), nleaf, tile_lo, tile_hi, _stream()),
+          'mr_transpose_leaves')
+
+
+@_timed('optimizer')
 def cast_params(master, work):
     check(_lib.load().mr_cast_f32_to_bf16_params(master.data_ptr(), work.data_ptr(), master.numel(), _stream()),
           'mr_cast_f32_to_bf16_params')

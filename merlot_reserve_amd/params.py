@@ -169,6 +169,25 @@ class ParamStore:
             self.w[name] = self.work[o:o + n].view(*vshape)
             self.wm[name] = self.master[o:o + n].view(*vshape)
             self.g[name] = self.grad[o:o + n].view(*vshape)
+        # Transposed bf16 working copies of the Dense kernels ([in, out] -> [out, in]): what the FORWARD GEMMs read, so that
+        # both of a GEMM's operands are contraction-contiguous (the dgrads get that from the flax layout as it is).  Same
+        # offsets as `work`; rewritten after every change of `work` (update_transposed: one HBM-bound pass, 4 B / parameter).
+        self.wT, tr = {}, []
+        self.workT = None
+        if self.device.type == 'cuda':
+            ntile = 0
+            for name, fshape, vshape, kind, fan in self.specs:
+                if name.endswith('/kernel') and len(vshape) == 2 and vshape[0] % 64 == 0 and vshape[1] % 64 == 0:
+                    o, n = self.offsets[name]
+                    tr.append((o, vshape[0], vshape[1], ntile, name))
+                    ntile += (vshape[0] // 64) * (vshape[1] // 64)
+            if tr:
+                self.workT = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+                self._tr = tr
+                self._tr_ntile = ntile
+                self._tr_dev = torch.tensor([t[:4] for t in tr], dtype=torch.int32, device=self.device)
+                for o, rows, cols, _, name in tr:
+                    self.wT[name] = self.workT[o:o + rows * cols].view(cols, rows)
         if init:
             self.load_tree(self.random_tree(seed))
 
@@ -197,8 +216,21 @@ class ParamStore:
         if self.master.is_cuda:
             from . import ops
             ops.cast_params(self.master, self.work)
+            self.update_transposed()
         else:
             self.work.copy_(self.master.to(torch.bfloat16))
+
+    def update_transposed(self, lo=0, hi=None):
+        """Rewrite the transposed copies of the Dense kernels lying in [lo, hi) of the flat buffers (call after `work` changed)."""
+        if self.workT is None:
+            return
+        from . import ops
+        hi = self.total if hi is None else hi
+        sel = [t for t in self._tr if lo <= t[0] < hi]
+        if not sel:
+            return
+        last = sel[-1]
+        ops.transpose_leaves(self.work, self.workT, self._tr_dev, len(self._tr), sel[0][3], last[3] + (last[1] // 64) * (last[2] // 64))
 
     def _to_tree(self, flat):
         host = flat.detach().to('cpu')

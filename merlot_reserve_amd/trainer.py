@@ -60,6 +60,7 @@ class TrainState:
         sched, neg_lr, bc1, bc2 = self._scalars()
         ops.adam_bf16_update(p.master, p.work, p.grad, p.mu, p.nu, p.decay_flags, oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                              oc.get('eps', 1e-8), oc['weight_decay_rate'], sched, neg_lr, bc1, bc2)
+        p.update_transposed()
         self.step += 1
 
     # ---- the same update in pieces: per-step scalars in a device vector (so the launches can sit inside a hipGraph) and
@@ -89,6 +90,7 @@ class TrainState:
         ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], None,
                                  p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                                  oc.get('eps', 1e-8), oc['weight_decay_rate'], self.hyper)
+        p.update_transposed(lo, hi)
 
     def finish_step(self):
         self.step += 1

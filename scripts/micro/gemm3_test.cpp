@@ -1,0 +1,245 @@
+// Standalone check + timing of the NT GEMM paths of libmreserve_hip.so (no torch): every epilogue mode of the ping-pong kernel
+// (gemm3.hip) against a naive device reference, and its time beside the one-barrier kernel (gemm256.hip) on the step's shapes.
+//   hipcc --offload-arch=gfx950 -O2 scripts/micro/gemm3_test.cpp -o scripts/micro/gemm3_test -Lmerlot_reserve_amd -lmreserve_hip
+//   LD_LIBRARY_PATH=merlot_reserve_amd scripts/micro/gemm3_test [check|time|all] [reps]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/mreserve_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef uint16_t bf16_t;
+__host__ __device__ static inline float bf2f(bf16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+__host__ __device__ static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
+
+__global__ void fill_kernel(bf16_t* p, int64_t n, uint32_t seed, float scale, float offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float u = (float)(x >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+        p[i] = f2bf(u * scale + offset);
+    }
+}
+__global__ void fill_f32_kernel(float* p, int64_t n, uint32_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+        p[i] = 0.5f + (float)(x >> 8) * (1.0f / 16777216.0f);
+    }
+}
+
+// reference: fp32 accumulation in k order, the epilogue of include/mreserve_hip.h (mr_gemm) in fp32 / bf16 roundings as documented
+__global__ void ref_kernel(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                           const bf16_t* bias, const float* rot, int64_t rot_rows, int64_t rot_cols, int act, const bf16_t* residual,
+                           const bf16_t* aux, int64_t ldx, int64_t grp, int64_t gstride, int64_t goff, bf16_t* C, bf16_t* C2, int64_t ldc) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N || m >= M) return;
+    float acc = 0.f;
+    const bf16_t* a = A + m * lda;
+    const bf16_t* b = B + n * ldb;
+    for (int64_t k = 0; k < K; ++k) acc += bf2f(a[k]) * bf2f(b[k]);
+    float v = acc + (bias ? bf2f(bias[n]) : 0.f);
+    if (rot && n < rot_cols && (n & 63) < 32) v *= rot[(m % rot_rows) * 32 + (n & 63)];
+    const int64_t orow = grp > 0 ? (m / grp) * gstride + goff + m % grp : m;
+    float o = v;
+    if (act == MR_ACT_GELU1702) {
+        const float sg = 1.0f / (1.0f + exp2f(-1.702f * 1.4426950408889634f * v));
+        o = v * sg;
+        if (C2) C2[orow * ldc + n] = f2bf(sg + 1.702f * v * sg * (1.0f - sg));
+    }
+    bf16_t ob = f2bf(o);
+    if (residual) ob = f2bf(bf2f(ob) + bf2f(residual[orow * ldx + n]));
+    if (aux) ob = f2bf(bf2f(ob) * bf2f(aux[orow * ldx + n]));
+    C[orow * ldc + n] = ob;
+}
+
+struct Case { int64_t M, N, K; int mode; const char* name; };   // mode 0 bias | 1 rot | 2 gelu + c2 | 3 residual | 4 aux + colsum | 5 plain (no bias) | 6 bias + row map
+
+static bf16_t *dA[3], *dB, *dC[3], *dC2[3], *dX, *dBias, *dRefC, *dRefC2;
+static float *dRot, *dCs, *dWs;
+static int64_t capA, capB, capC;
+
+static void setup_args(mr_gemm_args* g, const Case& c, int set, bool colsum) {
+    memset(g, 0, sizeof(*g));
+    g->M = c.M; g->N = c.N; g->K = c.K;
+    g->A = dA[set]; g->lda = c.K; g->transA = 0;
+    g->B = dB; g->ldb = c.K; g->transB = 1;
+    g->C = dC[set]; g->ldc = c.N; g->c_dtype = MR_DT_BF16;
+    g->act = MR_ACT_NONE;
+    if (c.mode != 5) g->bias = dBias;
+    if (c.mode == 1) { g->rot_tab = dRot; g->rot_rows = 241 * 16; g->rot_cols = (c.N / 3) * 2; }
+    if (c.mode == 2) { g->c2 = dC2[set]; g->act = MR_ACT_GELU1702; }
+    if (c.mode == 3) { g->residual = dX; g->ldr = c.N; g->bias = nullptr; }
+    if (c.mode == 4) { g->aux = dX; g->ldaux = c.N; g->bias = nullptr; if (colsum) { g->colsum = dCs; g->ldcs = c.N; } }
+    if (c.mode == 6) { g->out_grp = 240; g->out_grp_stride = 241; g->out_grp_off = 1; }
+    g->workspace = dWs; g->workspace_bytes = 64LL << 20;
+}
+
+static double time_case(const Case& c, int reps, bool colsum) {
+    mr_gemm_args g;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; ++w) { setup_args(&g, c, w % 3, colsum); if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); } }
+    CK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int round = 0; round < 3; ++round) {
+        CK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) { setup_args(&g, c, r % 3, colsum); mr_gemm(&g, nullptr); }
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / reps;
+        if (us < best) best = us;
+    }
+    return best;
+}
+
+static int check_case(const Case& c, const char* label) {
+    const int64_t rows_out = c.mode == 6 ? (c.M / 240 + 1) * 241 : c.M;
+    if (rows_out * c.N > capC) { printf("  (skip check: output too large)\n"); return 0; }
+    mr_gemm_args g;
+    setup_args(&g, c, 0, true);
+    CK(hipMemset(dC[0], 0xFF, rows_out * c.N * 2)); CK(hipMemset(dRefC, 0xFF, rows_out * c.N * 2));
+    if (c.mode == 2) { CK(hipMemset(dC2[0], 0xFF, rows_out * c.N * 2)); CK(hipMemset(dRefC2, 0xFF, rows_out * c.N * 2)); }
+    if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); return 1; }
+    dim3 grid((unsigned)((c.N + 255) / 256), (unsigned)c.M);
+    hipLaunchKernelGGL(ref_kernel, grid, dim3(256), 0, nullptr, dA[0], c.K, dB, c.K, c.M, c.N, c.K, (const bf16_t*)g.bias, g.rot_tab, g.rot_rows, g.rot_cols,
+                       g.act, (const bf16_t*)g.residual, (const bf16_t*)g.aux, c.N, g.out_grp, g.out_grp_stride, g.out_grp_off, dRefC,
+                       c.mode == 2 ? dRefC2 : nullptr, c.N);
+    CK(hipDeviceSynchronize());
+    std::vector<bf16_t> got(rows_out * c.N), ref(rows_out * c.N);
+    int bad = 0;
+    double maxerr = 0;
+    for (int pass = 0; pass < (c.mode == 2 ? 2 : 1); ++pass) {
+        CK(hipMemcpy(got.data(), pass ? dC2[0] : dC[0], got.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ref.data(), pass ? dRefC2 : dRefC, ref.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < got.size(); ++i) {
+            if (got[i] == ref[i]) continue;                        // (also the untouched 0xFFFF rows of a row map)
+            const float a = bf2f(got[i]), b = bf2f(ref[i]);
+            const double err = fabs((double)a - b), tol = 0.01 * fabs((double)b) + (c.mode == 3 ? 0.017 : 0.004);   // residual: the 1-ulp spread of bf16(acc) survives the add
+            if (!(err <= tol)) { if (bad < 5) printf("    MISMATCH %s[%zu] (row %zu col %zu): got %g ref %g\n", pass ? "c2" : "C", i, i / c.N, i % c.N, a, b); ++bad; }
+            if (err > maxerr) maxerr = err;
+        }
+    }
+    if (c.mode == 4) {        // column sums per 64-row band of the stored output
+        const int64_t nrows = mr_gemm_colsum_rows(c.M);
+        std::vector<float> cs(nrows * c.N);
+        CK(hipMemcpy(cs.data(), dCs, cs.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t band = 0; band < nrows; ++band)
+            for (int64_t n = 0; n < c.N; n += 37) {
+                double s = 0;
+                for (int64_t m = band * 64; m < band * 64 + 64 && m < c.M; ++m) s += bf2f(got[m * c.N + n]);
+                if (fabs(s - cs[band * c.N + n]) > 1e-3 * (1 + fabs(s))) { if (bad < 5) printf("    COLSUM mismatch band %ld col %ld: got %g ref %g\n", (long)band, (long)n, cs[band * c.N + n], s); ++bad; }
+            }
+    }
+    printf("  check %-10s %-28s M=%ld N=%ld K=%ld: %s (max abs err %.4g, %d bad)\n", label, c.name, (long)c.M, (long)c.N, (long)c.K, bad ? "FAIL" : "ok", maxerr, bad);
+    return bad != 0;
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "all";
+    const int reps = argc > 2 ? atoi(argv[2]) : 12;
+    capA = 15424LL * 4096; capB = 8192LL * 8192; capC = 15488LL * 4096;
+    if (capA < 8192LL * 8192) capA = 8192LL * 8192;
+    if (capC < 8192LL * 8192) capC = 8192LL * 8192;
+    for (int s = 0; s < 3; ++s) { CK(hipMalloc(&dA[s], capA * 2)); CK(hipMalloc(&dC[s], capC * 2)); CK(hipMalloc(&dC2[s], capC * 2)); }
+    CK(hipMalloc(&dB, capB * 2)); CK(hipMalloc(&dX, capC * 2)); CK(hipMalloc(&dBias, 8192 * 2)); CK(hipMalloc(&dRefC, capC * 2)); CK(hipMalloc(&dRefC2, capC * 2));
+    CK(hipMalloc(&dRot, 241 * 16 * 32 * 4)); CK(hipMalloc(&dCs, 4 * 64 * 8192 * 4)); CK(hipMalloc(&dWs, 64LL << 20));
+    for (int s = 0; s < 3; ++s) hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, nullptr, dA[s], capA, 1234u + s, 1.0f, 0.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, nullptr, dB, capB, 99u, 0.03f, 0.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, nullptr, dX, capC, 7u, 1.0f, 0.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, nullptr, dBias, (int64_t)8192, 5u, 0.5f, 0.0f);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(64), dim3(256), 0, nullptr, dRot, (int64_t)241 * 16 * 32, 3u);
+    CK(hipDeviceSynchronize());
+
+    int fails = 0;
+    if (!strcmp(what, "check") || !strcmp(what, "all")) {
+        const Case checks[] = {
+            {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 3072, 768, 4, "fc1 dgrad aux+colsum"}, {15424, 768, 3072, 3, "fc2 fwd residual"},
+            {15424, 768, 3072, 5, "d ln2 plain"}, {15424, 2304, 768, 1, "qkv fwd bias+rot"}, {15424, 768, 2304, 0, "bias"},
+            {15360, 768, 768, 6, "patch embed row map"}, {5952, 3072, 768, 2, "audio fc1"}, {5952, 768, 768, 3, "audio proj"},
+            {3072, 2304, 768, 1, "span qkv"}, {4616, 4096, 1024, 4, "ragged M aux"}, {2000, 1000, 192, 0, "ragged M N"},
+            {1024, 256, 128, 3, "small"}, {1312, 3072, 64, 0, "one k-tile"}, {40000, 192, 128, 5, "two k-tiles, narrow"},
+        };
+        const int widths[] = {256, 192};
+        for (int w : widths) {
+            mr_set_option("gemm3", w);
+            char label[32]; snprintf(label, sizeof label, "g3/%d", w);
+            for (const Case& c : checks) fails += check_case(c, label);
+        }
+        mr_set_option("gemm3", 0);
+        fails += check_case(checks[0], "old");       // the harness itself against the shipped kernel
+        fails += check_case(checks[4], "old");
+        mr_set_option("gemm3", 1);
+    }
+    if (!strcmp(what, "time") || !strcmp(what, "all")) {
+        const Case shapes[] = {
+            {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 3072, 768, 4, "fc1 dgrad aux+colsum"}, {15424, 3072, 768, 5, "fc1 plain"},
+            {15424, 768, 3072, 3, "fc2 fwd residual"}, {15424, 768, 3072, 5, "d ln2 plain"}, {15424, 2304, 768, 1, "qkv fwd bias+rot"},
+            {15424, 2304, 768, 5, "qkv plain"}, {15424, 768, 2304, 5, "d ln1 plain"}, {15424, 768, 768, 3, "proj fwd residual"}, {15424, 768, 768, 5, "d att plain"},
+            {5952, 3072, 768, 2, "audio fc1 fwd"}, {5952, 768, 3072, 3, "audio fc2 fwd"}, {5952, 2304, 768, 1, "audio qkv"}, {5952, 768, 768, 3, "audio proj"},
+            {3072, 3072, 768, 2, "span fc1 fwd"}, {3072, 768, 3072, 3, "span fc2 fwd"},
+            {15424, 4096, 1024, 2, "large fc1 fwd"}, {15424, 4096, 1024, 5, "large fc1 plain"}, {15424, 1024, 4096, 3, "large fc2 fwd"}, {15424, 1024, 4096, 5, "large fc2 plain"},
+            {15424, 3072, 1024, 1, "large qkv"}, {15424, 1024, 1024, 3, "large proj"}, {8192, 8192, 8192, 5, "8192^3"},
+        };
+        printf("%-26s %18s | %10s %10s %10s | TF/s old -> best\n", "shape", "M x N x K", "old us", "g3/256 us", "g3/192 us");
+        for (const Case& c : shapes) {
+            const bool cs = c.mode == 4;
+            mr_set_option("gemm3", 0);
+            const double t0 = time_case(c, reps, cs);
+            mr_set_option("gemm3", 256);
+            const double t1 = time_case(c, reps, cs);
+            mr_set_option("gemm3", 192);
+            const double t2 = time_case(c, reps, cs);
+            const double fl = 2.0 * c.M * c.N * c.K, tb = t1 < t2 ? t1 : t2;
+            printf("%-26s %6ldx%5ldx%5ld | %10.1f %10.1f %10.1f | %7.0f -> %7.0f\n", c.name, (long)c.M, (long)c.N, (long)c.K, t0, t1, t2, fl / t0 * 1e-6, fl / tb * 1e-6);
+        }
+        mr_set_option("gemm3", 1);
+    }
+    if (!strcmp(what, "stamps")) {       // needs the MR_G3_STAMPS build of the library
+        const Case shapes[] = {{15424, 3072, 768, 5, "fc1 plain"}, {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 768, 3072, 3, "fc2 fwd residual"}, {8192, 8192, 8192, 5, "8192^3"}};
+        const int widths[] = {256, 192};
+        for (const Case& c : shapes) for (int w : widths) {
+            mr_set_option("gemm3", w);
+            mr_gemm_args g;
+            for (int r = 0; r < 3; ++r) { setup_args(&g, c, r, false); mr_gemm(&g, nullptr); }
+            CK(hipMemset(dWs, 0, 2 << 20));
+            setup_args(&g, c, 0, false);
+            mr_gemm(&g, nullptr);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> st(256 * 2 * 8 * 4);
+            CK(hipMemcpy(st.data(), dWs, st.size() * 8, hipMemcpyDeviceToHost));
+            const int nkt = (int)(c.K / 64);
+            double kl[2] = {0, 0}, ep[2] = {0, 0}, gap[2] = {0, 0}, span = 0; int n[2] = {0, 0}, ng[2] = {0, 0}, nb = 0;
+            for (int b = 0; b < 256; ++b) for (int wr = 0; wr < 2; ++wr) {
+                const unsigned long long* q = &st[((b * 2 + wr) * 8) * 4];
+                int last = -1;
+                for (int i = 0; i < 8 && q[i * 4]; ++i) {
+                    kl[wr] += (double)(q[i * 4 + 1] - q[i * 4]); ep[wr] += (double)(q[i * 4 + 2] - q[i * 4 + 1]); ++n[wr];
+                    if (i > 0) { gap[wr] += (double)(q[i * 4] - q[(i - 1) * 4 + 2]); ++ng[wr]; }
+                    last = i;
+                }
+                if (wr == 0 && last >= 0) { span += (double)(q[last * 4 + 2] - q[0]); ++nb; }
+            }
+            if (w == 256) {
+                std::vector<unsigned long long> ks(8 * 4 * 16);
+                CK(hipMemcpy(ks.data(), (unsigned long long*)dWs + 65536, ks.size() * 8, hipMemcpyDeviceToHost));
+                for (int b = 0; b < 2; ++b) for (int i = 0; i < 3; ++i) {
+                    printf("   k-tile cycles, block %d tile %d:", b, i);
+                    for (int t = 1; t < 16 && t < nkt && ks[(b * 4 + i) * 16 + t]; ++t) printf(" %5llu", ks[(b * 4 + i) * 16 + t] - ks[(b * 4 + i) * 16 + t - 1]);
+                    printf("\n");
+                }
+            }
+            printf("stamps %-18s g3/%d: per tile  k-loop %8.0f / %8.0f cyc (%5.0f per k-tile)  epilogue %7.0f / %7.0f  gap %6.0f / %6.0f   (group 0 / 1; s_memtime ticks = 10 ns);  block span %8.0f\n",
+                   c.name, w, kl[0] / n[0], kl[1] / n[1], kl[0] / n[0] / nkt, ep[0] / n[0], ep[1] / n[1], ng[0] ? gap[0] / ng[0] : 0., ng[1] ? gap[1] / ng[1] : 0., span / nb);
+        }
+        mr_set_option("gemm3", 1);
+    }
+    printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
+    return fails ? 1 : 0;
+}
