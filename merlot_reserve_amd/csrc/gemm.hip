@@ -303,6 +303,7 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s);
 // gemm3.hip
 bool mr_gemm3_eligible(const mr_gemm_args* a);
 int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s);
+bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s);
 
 extern int g_mr_opt_v1_only;        // mr_set_option("gemm_v1_only")
 static int use_gemm256() {
@@ -374,6 +375,17 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
 extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream) {
     MR_CHECK_ARG(list != nullptr && count >= 1, "mr_gemm_grouped: empty list");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (use_gemm256() && count <= 8 && mr_gemm3_tn_grouped(list, count, s)) {      // weight gradients: the TN ping-pong kernel
+        MR_CHECK_LAUNCH("mr_gemm_grouped (ping-pong kernel)");
+        return MR_OK;
+    }
+    if (count > 4) {        // the one-barrier kernel groups <= 4 problems per launch
+        for (int k = 0; k < count; k += 4) {
+            const int rc = mr_gemm_grouped(list + k, count - k < 4 ? count - k : 4, stream);
+            if (rc != MR_OK) return rc;
+        }
+        return MR_OK;
+    }
     bool all_big = use_gemm256() && count > 1 && count <= 4;
     for (int k = 0; all_big && k < count; ++k) all_big = list[k].M > 0 && list[k].N % 128 == 0;     // (256-wide tiles: N % 256, checked inside)
     if (all_big && mr_gemm256_grouped(list, count, s)) {

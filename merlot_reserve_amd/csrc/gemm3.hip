@@ -514,6 +514,155 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     if (wr == 0) G3_BARRIER();          // pairs with group 1's last barrier
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "TN" variant for the weight gradients:  C[M,N] = A^T . B with A stored [K, M] and B stored [K, N] (activations x upstream
+// gradients, the contraction index = tokens is the ROW index of both).  Same two-group ping-pong k-loop; the operand tiles are
+// [64 k][256] images read with ds_read_b64_tr_b16 (two per MFMA operand).  One 256 x 256 output tile per workgroup, no
+// persistence (K = tokens is long: 93-241 k-tiles, the prologue and the plain bf16 epilogue are < 2 % of a tile), up to 8
+// problems per launch: the weight gradients of TWO transformer layers fill the chip without split-K (216 tiles for the base
+// model) where one layer's four are 108.
+struct TNProb { const void* A; const void* B; void* C; int M, N, lda, ldb, ldc, pad; };
+constexpr int TN_MAXG = 8;
+struct TNArgs { int count, K; int tile_start[TN_MAXG + 1]; int tiles_n[TN_MAXG]; TNProb p[TN_MAXG]; };
+
+__global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
+    constexpr int NJ = 4, STAGE = 64 * 512, NSTAGE_A = 3, NSTAGE_B = 2, OFF_B = NSTAGE_A * STAGE, WAITN = 8;
+    __shared__ __attribute__((aligned(16))) char smem[(NSTAGE_A + NSTAGE_B) * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
+    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < TN_MAXG; ++k) pi += (k < ta.count && tile >= ta.tile_start[k]) ? 1 : 0;
+    const TNProb& pr = ta.p[pi];
+    const int lt = tile - ta.tile_start[pi], tn = ta.tiles_n[pi];
+    const int m0 = (lt / tn) * 256, n0 = (lt % tn) * 256;
+    const int M = pr.M, N = pr.N, K = ta.K;
+    const int nkt = (K + 63) >> 6;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pr.A), 0, (int)(((int64_t)(K - 1) * pr.lda + M) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pr.B), 0, (int)(((int64_t)(K - 1) * pr.ldb + N) * 2), 0x00020000);
+    const unsigned a_step = 64u * (unsigned)pr.lda * 2u, b_step = 64u * (unsigned)pr.ldb * 2u;
+    unsigned ao[4], bo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ao[j] = piece_src<true, 256, 64>(wave * 4 + j, lane, pr.lda, m0, M);
+        bo[j] = piece_src<true, 256, 64>(wave * 4 + j, lane, pr.ldb, n0, N);
+    }
+    int ik = 0, ista = 0, istb = 0;
+    bool issued = false;
+#define TN_ISSUE_A()                                                                                                    \
+    do {                                                                                                                \
+        issued = ik < nkt;                                                                                              \
+        if (issued) {                                                                                                   \
+            char* st_ = smem + ista * STAGE + wave * 4096;                                                              \
+            const unsigned sa = (unsigned)ik * a_step;                                                                  \
+            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, ao[0], sa, 0, 0);                                                     \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, ao[1], sa, 0, 0);                                              \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 2048), 16, ao[2], sa, 0, 0);                                              \
+            MR_DMA(ra, MR_LDS_PTR(void, st_ + 3072), 16, ao[3], sa, 0, 0);                                              \
+            ista = (ista == NSTAGE_A - 1) ? 0 : ista + 1;                                                               \
+        }                                                                                                               \
+    } while (0)
+#define TN_ISSUE_B()                                                                                                    \
+    do {                                                                                                                \
+        if (ik < nkt) {                                                                                                 \
+            char* sb_ = smem + OFF_B + istb * STAGE + wave * 4096;                                                      \
+            const unsigned sb = (unsigned)ik * b_step;                                                                  \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_), 16, bo[0], sb, 0, 0);                                                     \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_ + 1024), 16, bo[1], sb, 0, 0);                                              \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_ + 2048), 16, bo[2], sb, 0, 0);                                              \
+            MR_DMA(rb, MR_LDS_PTR(void, sb_ + 3072), 16, bo[3], sb, 0, 0);                                              \
+            istb = (istb == NSTAGE_B - 1) ? 0 : istb + 1;                                                               \
+            ++ik;                                                                                                       \
+        }                                                                                                               \
+    } while (0)
+    TN_ISSUE_A(); TN_ISSUE_B();
+    TN_ISSUE_A(); TN_ISSUE_B();
+    if (issued) wait_vmcnt<WAITN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G3_BARRIER();
+    if (wr == 1) G3_BARRIER();
+
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int csa = 0, csb = 0;
+    for (int t = 0; t < nkt; ++t) {
+        const char* As = smem + csa * STAGE;
+        const char* Bs = smem + OFF_B + csb * STAGE;
+        bf16x8 a[4][2], b[NJ][2];
+        auto read_a = [&](int half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a[i][kk] = frag<true, 256, 64>(As, wr * 128 + half * 64 + i * 16, kk, lane);
+        };
+        auto mfmas = [&](int half) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[half * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // phase 0: A0 x B; every read of the phase is retired AHEAD of the barrier (phase 1 restages B; lgkmcnt counts to 15 only)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b[j][kk] = frag<true, 256, 64>(Bs, wc * 64 + j * 16, kk, lane);
+        read_a(0);
+        __builtin_amdgcn_sched_barrier(0);
+        TN_ISSUE_A();
+        G3_LGKM(0);
+        G3_BARRIER();
+        mfmas(0);
+        G3_BARRIER();
+        // phase 1: A1 x B
+        read_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+        TN_ISSUE_B();
+        G3_LGKM(0);
+        if (issued) wait_vmcnt<WAITN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G3_BARRIER();
+        mfmas(1);
+        G3_BARRIER();
+        csa = (csa == NSTAGE_A - 1) ? 0 : csa + 1;
+        csb = (csb == NSTAGE_B - 1) ? 0 : csb + 1;
+    }
+    if (wr == 0) G3_BARRIER();          // pairs with group 1's last barrier
+
+    // epilogue: bf16 stores, widened to 16 B (see the NT kernel's store_pair)
+    const unsigned c_bytes = (unsigned)(((int64_t)(M - 1) * pr.ldc + N) * 2);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)c_bytes, 0x00020000);
+    const int wrow0 = m0 + wr * 128, wcol0 = n0 + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gm = wrow0 + i * 16 + li;
+        const unsigned rowoff = (unsigned)gm * (unsigned)pr.ldc * 2u;
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            bf16x4 va, vb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[r] = (__bf16)acc[i][2 * jp][r]; vb[r] = (__bf16)acc[i][2 * jp + 1][r]; }
+            u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+            const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+            const unsigned off = (gm < M && col < N) ? rowoff + (unsigned)col * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc, off, 0, 0);
+        }
+    }
+}
+
 }  // namespace g3
 
 constexpr int64_t NUM_CU3 = 256;    // MI355X
@@ -604,4 +753,35 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     }
 #undef G3_LAUNCH
     return 0;
+}
+
+// Grouped weight gradients on the TN ping-pong kernel: <= 8 problems, all transA = 1 / transB = 0 with one K, bf16 outputs, no
+// epilogue.  Returns false when the group does not qualify (the caller falls back to the one-barrier kernel's grouped launch).
+bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MR_GEMM3_TN"); env = e ? atoi(e) : 1; }
+    if (!env || !g_mr_opt_gemm3 || count < 1 || count > g3::TN_MAXG) return false;
+    g3::TNArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    int64_t tiles = 0;
+    for (int k = 0; k < count; ++k) {
+        const mr_gemm_args* a = &list[k];
+        if (!a->transA || a->transB || a->c_dtype != MR_DT_BF16 || a->K != list[0].K) return false;
+        if (a->bias || a->rot_tab || a->c2 || a->act != MR_ACT_NONE || a->residual || a->aux || a->out_grp != 0 || a->colsum) return false;
+        if (a->M % 8 || a->N % 8 || a->lda % 8 || a->ldb % 8 || a->ldc % 8) return false;
+        if (a->K * a->lda * 2 >= (1LL << 31) || a->K * a->ldb * 2 >= (1LL << 31) || a->M * a->ldc * 2 >= (1LL << 31)) return false;
+        const int64_t tm = (a->M + 255) / 256, tn = (a->N + 255) / 256;
+        ta.tile_start[k] = (int)tiles;
+        ta.tiles_n[k] = (int)tn;
+        tiles += tm * tn;
+        ta.p[k] = g3::TNProb{a->A, a->B, a->C, (int)a->M, (int)a->N, (int)a->lda, (int)a->ldb, (int)a->ldc, 0};
+    }
+    ta.tile_start[count] = (int)tiles;
+    ta.count = count;
+    ta.K = (int)list[0].K;
+    // worth it when the tiles fill most of the chip (one tile per workgroup, one workgroup per CU) and K is long
+    const bool forced = g_mr_opt_gemm3 == 256;
+    if (!forced && (tiles < 160 || tiles > 2 * NUM_CU3 || list[0].K < 2048)) return false;
+    hipLaunchKernelGGL(g3::gemm3_tn_kernel, dim3((unsigned)tiles), dim3(512), 0, s, ta);
+    return true;
 }

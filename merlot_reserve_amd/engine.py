@@ -56,6 +56,10 @@ class TowerEngine:
         sc = Scratch()
         sc.T_a, sc.T_d1, sc.T_d2 = z(Ms, H), z(Ms, H), z(Ms, H)
         sc.T_q, sc.T_h = z(Ms, 3 * H), z(Ms, 4 * H)
+        # second set: the weight gradients of TWO layers share one launch (encoder_backward), so a layer's upstream gradients
+        # stay alive while the next layer's are produced
+        sc.T_d3, sc.T_d4 = z(Ms, H), z(Ms, H)
+        sc.T_q2, sc.T_h2 = z(Ms, 3 * H), z(Ms, 4 * H)
         sc.delta = f(Ms * nh)
         sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
         sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
@@ -212,15 +216,33 @@ class TowerEngine:
         k = 2 * st.L + 1
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
+    def _wgrad_group(self, M, H):
+        """Layers whose weight gradients share one grouped launch: 2 when two layers' 256 x 256 output tiles fill the chip better
+        than one layer's (base model: 108 -> 216 of 256 CUs; large: 192 of 256 either way -> 1).  The one-tile-per-workgroup
+        TN kernel (csrc/gemm3.hip) needs K = M tokens long enough to amortise a tile's prologue."""
+        if os.environ.get('MR_WGRAD_PAIR') == '0' or M < 2048:
+            return 1
+        t = lambda m, n: ((m + 255) // 256) * ((n + 255) // 256)
+        tiles = t(4 * H, H) + t(H, 4 * H) + t(H, H) + t(H, 3 * H)
+        eff = lambda n: n / (((n + 255) // 256) * 256)
+        return 2 if eff(2 * tiles) > eff(tiles) + 0.05 else 1
+
     def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None):
-        """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (one of D / two scratch
+        """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (D or one of the scratch
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
-        gradients of a layer are deferred to ONE grouped GEMM launch (they fill the 256 CUs together, no split-K).
-        layer_done(l): called once layer l's backward is enqueued, i.e. every parameter gradient of layers >= l is final on
-        the issuing stream (the data-parallel trainer reduces gradient buckets from there while backward continues)."""
+        gradients of a layer -- of TWO layers when that fills the chip better (_wgrad_group) -- are deferred to ONE grouped
+        GEMM launch (no split-K).
+        layer_done(l): called once every parameter gradient of layers >= l is final on the issuing stream (the data-parallel
+        trainer reduces gradient buckets from there while backward continues)."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
-        T_a, T_q, T_h = self.cur.T_a[:M], self.cur.T_q[:M], self.cur.T_h[:M]
-        Dcur, Dmid, Dnext = D, self.cur.T_d1[:M], self.cur.T_d2[:M]
+        T_a = self.cur.T_a[:M]
+        T_qs, T_hs = (self.cur.T_q[:M], self.cur.T_q2[:M]), (self.cur.T_h[:M], self.cur.T_h2[:M])
+        # [M, H] gradient buffers: a layer reads Dcur, writes Dmid and Dnext; Dcur / Dmid (and T_q / T_h) stay untouched until
+        # the layer's weight gradients have been issued
+        free = [self.cur.T_d1[:M], self.cur.T_d2[:M], self.cur.T_d3[:M], self.cur.T_d4[:M]]
+        Dcur = D
+        group = self._wgrad_group(M, H)
+        pending, held, done_layers = [], [], []
         k = 2 * st.L + 1
         self._t_ln_bwd(tr, Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
                        G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'])
@@ -230,6 +252,8 @@ class TowerEngine:
         jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
+            T_q, T_h = T_qs[l & 1], T_hs[l & 1]
+            Dmid, Dnext = free.pop(), free.pop()
             fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']],
                                             jobs if os.environ.get('MR_NO_GEMM_COLSUM') != '1' else None, transB=True,
                                             aux=st.hpre[l], ws=self.cur.gemm_ws)            # d hpre (+ its column sums = d bias)
@@ -245,17 +269,24 @@ class TowerEngine:
             if not fuse_q:
                 ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
             self.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
-            ops.gemm_grouped([self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
-                              self.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
-                              self.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
-                              self.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)])
+            pending += [self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
+                        self.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
+                        self.gemm_args(st.att[l], Dmid, G[n['wo']], transA=True),
+                        self.gemm_args(st.ln1[l], T_q, G[n['wqkv']], transA=True)]
+            held += [Dcur, Dmid]          # (the caller's D joins the rotation once its layer's weight gradients are issued)
+            done_layers.append(l)
             ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
                               G[n['g1']], G[n['b1']], self.cur.ln_ws2, dx_add=Dmid, jobs=jobs)   # Dnext = d X[l]
             if jobs is not None:
                 ops.reduce_partials(jobs)          # the layer's 2 LayerNorm + 2 bias gradients: one launch
-            if layer_done is not None:
-                layer_done(l)
-            Dcur, Dmid, Dnext = Dnext, Dcur, Dmid
+            if len(done_layers) == group or l == 0:
+                ops.gemm_grouped(pending)
+                free += held
+                if layer_done is not None:
+                    for dl in done_layers:
+                        layer_done(dl)
+                pending, held, done_layers = [], [], []
+            Dcur = Dnext
         self._t_ln_bwd(tr, Dcur, st.xin, W[f'{prefix}/pre_ln/scale'], st.stats[0, 0], st.stats[0, 1], Dcur,
                        G[f'{prefix}/pre_ln/scale'], G[f'{prefix}/pre_ln/bias'])
         return Dcur

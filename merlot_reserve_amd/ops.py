@@ -135,7 +135,6 @@ def gemm_grouped(arg_list):
     check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 
 
-@_timed('layernorm+reductions')
 def gemm_colsum_job(a, b, out, colsum_ws, bias_grad, jobs, **kw):
     """out = op(a) @ op(b) * aux with the bias gradient colsum(out) folded into the GEMM's epilogue when the library supports it
     for this problem (per-tile partial rows in colsum_ws, reduced later with the other deferred jobs); otherwise the GEMM

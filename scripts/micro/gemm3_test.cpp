@@ -58,17 +58,26 @@ __global__ void ref_kernel(const bf16_t* A, int64_t lda, const bf16_t* B, int64_
     C[orow * ldc + n] = ob;
 }
 
+__global__ void ref_tn_kernel(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int64_t M, int64_t N, int64_t K, bf16_t* C, int64_t ldc) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N || m >= M) return;
+    float acc = 0.f;
+    for (int64_t k = 0; k < K; ++k) acc += bf2f(A[k * lda + m]) * bf2f(B[k * ldb + n]);
+    C[m * ldc + n] = f2bf(acc);
+}
+
 struct Case { int64_t M, N, K; int mode; const char* name; };   // mode 0 bias | 1 rot | 2 gelu + c2 | 3 residual | 4 aux + colsum | 5 plain (no bias) | 6 bias + row map
 
 static bf16_t *dA[3], *dB, *dC[3], *dC2[3], *dX, *dBias, *dRefC, *dRefC2;
 static float *dRot, *dCs, *dWs;
 static int64_t capA, capB, capC;
 
+static bool g_nn = false;        // time the [K, N] (flax forward) operand layout instead: the one-barrier kernel's NN variants
 static void setup_args(mr_gemm_args* g, const Case& c, int set, bool colsum) {
     memset(g, 0, sizeof(*g));
     g->M = c.M; g->N = c.N; g->K = c.K;
     g->A = dA[set]; g->lda = c.K; g->transA = 0;
-    g->B = dB; g->ldb = c.K; g->transB = 1;
+    g->B = dB; g->ldb = g_nn ? c.N : c.K; g->transB = g_nn ? 0 : 1;
     g->C = dC[set]; g->ldc = c.N; g->c_dtype = MR_DT_BF16;
     g->act = MR_ACT_NONE;
     if (c.mode != 5) g->bias = dBias;
@@ -80,23 +89,37 @@ static void setup_args(mr_gemm_args* g, const Case& c, int set, bool colsum) {
     g->workspace = dWs; g->workspace_bytes = 64LL << 20;
 }
 
-static double time_case(const Case& c, int reps, bool colsum) {
+// Sustained, interleaved timing: the variants take turns (one launch each, round robin) for ~`budget_ms` of GPU time after a
+// warm-up of the same length, so that they share the clock the chip settles at under load (a cold 3-ms burst runs ~15 % faster
+// than the same kernel inside a training step).  variants: 0 = one-barrier kernel NT, 1 = ping-pong 256, 2 = ping-pong 192,
+// 3 = one-barrier kernel NN (flax forward layout).
+static void time_variants(const Case& c, bool colsum, double budget_ms, double out_us[4]) {
     mr_gemm_args g;
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w) { setup_args(&g, c, w % 3, colsum); if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); } }
-    CK(hipDeviceSynchronize());
-    double best = 1e30;
-    for (int round = 0; round < 3; ++round) {
-        CK(hipEventRecord(e0, nullptr));
-        for (int r = 0; r < reps; ++r) { setup_args(&g, c, r % 3, colsum); mr_gemm(&g, nullptr); }
-        CK(hipEventRecord(e1, nullptr));
-        CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = ms * 1000.0 / reps;
-        if (us < best) best = us;
+    hipEvent_t e0[4], e1[4];
+    for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
+    auto launch = [&](int v, int set) {
+        g_nn = v == 3;
+        mr_set_option("gemm3", v == 1 ? 256 : v == 2 ? 192 : 0);
+        setup_args(&g, c, set, colsum);
+        if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); }
+    };
+    double tot[4] = {0, 0, 0, 0}; int n[4] = {0, 0, 0, 0};
+    for (int phase = 0; phase < 2; ++phase) {           // phase 0 = warm-up (discarded)
+        double spent = 0; int it = 0;
+        while (spent < budget_ms) {
+            for (int v = 0; v < 4; ++v) {
+                CK(hipEventRecord(e0[v], nullptr));
+                for (int r = 0; r < 4; ++r) launch(v, (it + r) % 3);
+                CK(hipEventRecord(e1[v], nullptr));
+            }
+            CK(hipEventSynchronize(e1[3]));
+            for (int v = 0; v < 4; ++v) { float ms; CK(hipEventElapsedTime(&ms, e0[v], e1[v])); spent += ms; if (phase) { tot[v] += ms; n[v] += 4; } }
+            ++it;
+        }
     }
-    return best;
+    for (int v = 0; v < 4; ++v) out_us[v] = tot[v] * 1000.0 / n[v];
+    g_nn = false;
+    mr_set_option("gemm3", 1);
 }
 
 static int check_case(const Case& c, const char* label) {
@@ -187,17 +210,78 @@ int main(int argc, char** argv) {
             {15424, 4096, 1024, 2, "large fc1 fwd"}, {15424, 4096, 1024, 5, "large fc1 plain"}, {15424, 1024, 4096, 3, "large fc2 fwd"}, {15424, 1024, 4096, 5, "large fc2 plain"},
             {15424, 3072, 1024, 1, "large qkv"}, {15424, 1024, 1024, 3, "large proj"}, {8192, 8192, 8192, 5, "8192^3"},
         };
-        printf("%-26s %18s | %10s %10s %10s | TF/s old -> best\n", "shape", "M x N x K", "old us", "g3/256 us", "g3/192 us");
+        printf("%-26s %18s | %9s %9s %9s %9s | TF/s: old NT, old NN -> best new   (sustained, interleaved)\n", "shape", "M x N x K", "old NT us", "old NN us", "g3/256 us", "g3/192 us");
         for (const Case& c : shapes) {
-            const bool cs = c.mode == 4;
-            mr_set_option("gemm3", 0);
-            const double t0 = time_case(c, reps, cs);
+            double t[4];
+            time_variants(c, c.mode == 4, reps * 10.0, t);
+            const double fl = 2.0 * c.M * c.N * c.K, tb = t[1] < t[2] ? t[1] : t[2];
+            printf("%-26s %6ldx%5ldx%5ld | %9.1f %9.1f %9.1f %9.1f | %7.0f %7.0f -> %7.0f\n", c.name, (long)c.M, (long)c.N, (long)c.K, t[0], t[3], t[1], t[2],
+                   fl / t[0] * 1e-6, fl / t[3] * 1e-6, fl / tb * 1e-6);
+        }
+        mr_set_option("gemm3", 1);
+    }
+    if (!strcmp(what, "tn") || !strcmp(what, "all")) {
+        // weight gradients of a layer (x 2 layers): A = activations [K = tokens, in], B = upstream gradients [K, out]
+        struct WG { int64_t M, N; };
+        const int64_t H = 768, Ks[] = {15424, 5952, 1000};
+        for (int64_t K : Ks) {
+            const WG one[4] = {{4 * H, H}, {H, 4 * H}, {H, H}, {H, 3 * H}};
+            mr_gemm_args list[8];
+            bf16_t* outs[8];
+            int64_t coff = 0;
+            for (int k = 0; k < 8; ++k) {
+                const WG w = one[k % 4];
+                mr_gemm_args* g = &list[k];
+                memset(g, 0, sizeof(*g));
+                g->M = w.M; g->N = w.N; g->K = K;
+                g->A = dA[k / 4] + (k % 4) * 1000; g->lda = w.M; g->transA = 1;         // distinct (overlapping, read-only) operands
+                g->B = dX + (k % 4) * 3000; g->ldb = w.N; g->transB = 0;
+                outs[k] = dC[0] + coff; coff += w.M * w.N;
+                g->C = outs[k]; g->ldc = w.N; g->c_dtype = MR_DT_BF16;
+                g->workspace = dWs; g->workspace_bytes = 64LL << 20;
+            }
+            // check every problem against the naive reference
+            CK(hipMemset(dC[0], 0xFF, coff * 2));
             mr_set_option("gemm3", 256);
-            const double t1 = time_case(c, reps, cs);
-            mr_set_option("gemm3", 192);
-            const double t2 = time_case(c, reps, cs);
-            const double fl = 2.0 * c.M * c.N * c.K, tb = t1 < t2 ? t1 : t2;
-            printf("%-26s %6ldx%5ldx%5ld | %10.1f %10.1f %10.1f | %7.0f -> %7.0f\n", c.name, (long)c.M, (long)c.N, (long)c.K, t0, t1, t2, fl / t0 * 1e-6, fl / tb * 1e-6);
+            if (mr_gemm_grouped(list, 8, nullptr) != 0) { printf("mr_gemm_grouped failed: %s\n", mr_last_error()); return 1; }
+            int bad = 0; double maxerr = 0;
+            for (int k = 0; k < 8; ++k) {
+                const mr_gemm_args& g = list[k];
+                dim3 grid((unsigned)((g.N + 255) / 256), (unsigned)g.M);
+                hipLaunchKernelGGL(ref_tn_kernel, grid, dim3(256), 0, nullptr, (const bf16_t*)g.A, g.lda, (const bf16_t*)g.B, g.ldb, g.M, g.N, g.K, dRefC, g.N);
+                CK(hipDeviceSynchronize());
+                std::vector<bf16_t> got(g.M * g.N), ref(g.M * g.N);
+                CK(hipMemcpy(got.data(), g.C, got.size() * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(ref.data(), dRefC, ref.size() * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < got.size(); ++i) {
+                    const float a = bf2f(got[i]), b = bf2f(ref[i]);
+                    const double err = fabs((double)a - b), tol = 0.01 * fabs((double)b) + 0.02 * sqrt((double)K / 1000.0);
+                    if (!(err <= tol)) { if (bad < 5) printf("    TN MISMATCH problem %d [%zu]: got %g ref %g\n", k, i, a, b); ++bad; }
+                    if (err > maxerr) maxerr = err;
+                }
+            }
+            printf("  check TN grouped x8, K=%ld: %s (max abs err %.4g, %d bad)\n", (long)K, bad ? "FAIL" : "ok", maxerr, bad);
+            fails += bad != 0;
+            // time: one-barrier kernel (two launches of 4) vs ping-pong (one launch of 8), sustained + interleaved
+            hipEvent_t e0[2], e1[2];
+            for (int v = 0; v < 2; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
+            double tot[2] = {0, 0}; int n[2] = {0, 0};
+            for (int phase = 0; phase < 2; ++phase) {
+                double spent = 0;
+                while (spent < 150.0) {
+                    for (int v = 0; v < 2; ++v) {
+                        mr_set_option("gemm3", v ? 256 : 0);
+                        CK(hipEventRecord(e0[v], nullptr));
+                        for (int r = 0; r < 3; ++r) mr_gemm_grouped(list, 8, nullptr);
+                        CK(hipEventRecord(e1[v], nullptr));
+                    }
+                    CK(hipEventSynchronize(e1[1]));
+                    for (int v = 0; v < 2; ++v) { float ms; CK(hipEventElapsedTime(&ms, e0[v], e1[v])); spent += ms; if (phase) { tot[v] += ms; n[v] += 3; } }
+                }
+            }
+            const double fl = 2.0 * K * 2 * (4 * H * H * 2 + H * H + 3 * H * H);
+            printf("  time  TN grouped x8, K=%ld: one-barrier %.1f us (%.0f TF/s)   ping-pong %.1f us (%.0f TF/s)\n", (long)K, tot[0] * 1e3 / n[0], fl / (tot[0] / n[0]) * 1e-9,
+                   tot[1] * 1e3 / n[1], fl / (tot[1] / n[1]) * 1e-9);
         }
         mr_set_option("gemm3", 1);
     }

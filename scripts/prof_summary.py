@@ -25,7 +25,7 @@ def family(n):
     if 'gemm' in n or 'splitk' in n: return 'gemm'
     if 'attn' in n: return 'attention'
     if 'ln_' in n or 'colsum' in n or 'reduce_' in n: return 'layernorm+reductions'
-    if 'adam' in n or 'nan_to_num' in n or 'cast_params' in n: return 'optimizer'
+    if 'adam' in n or 'nan_to_num' in n or 'cast_params' in n or 'transpose_leaves' in n: return 'optimizer'
     if 'ccl' in n.lower() or 'Reduce' in n: return 'rccl'
     return 'rowops+other'
 for r in rows:
