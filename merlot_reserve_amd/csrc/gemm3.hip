@@ -666,6 +666,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
 }  // namespace g3
 
 constexpr int64_t NUM_CU3 = 256;    // MI355X
+extern int g_mr_opt_group_streamk, g_mr_opt_group_headtail, g_mr_opt_group_tile_n;
 extern int g_mr_opt_gemm3;           // mr_set_option("gemm3"): 1 = on (default), 0 = off, 256 / 192 = on with that tile width forced
 
 // The ping-pong kernel takes: NT operands (A [M,K], B [N,K], K % 64 == 0), bf16 output, at least one full round of 256-row tiles'
@@ -761,6 +762,7 @@ bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MR_GEMM3_TN"); env = e ? atoi(e) : 1; }
     if (!env || !g_mr_opt_gemm3 || count < 1 || count > g3::TN_MAXG) return false;
+    if (g_mr_opt_group_streamk > 0 || g_mr_opt_group_headtail > 0 || g_mr_opt_group_tile_n != 0) return false;   // an explicitly requested schedule of the one-barrier kernel
     g3::TNArgs ta;
     memset(&ta, 0, sizeof(ta));
     int64_t tiles = 0;
