@@ -72,6 +72,63 @@ def cpu_baseline(config, threads=None):
                       f'layers): {dt:.1f} s measured, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
+def secondary_configs(dev, replays=4):
+    """BASELINE configs 3-5 on ONE GPU of their eight (driver-timed evidence beside the headline, never `value`): `replays` hipGraph
+    replays each of the large pretraining step (4 records / GPU), the large resolution-adaptation step (grid 18x32, 2 records / GPU)
+    and the VCR finetuning step (large, 4 examples / GPU), after one eager step, the capture and one warm-up replay."""
+    import torch
+    from merlot_reserve_amd import finetune as F
+    from merlot_reserve_amd.config import load_config, resadapt_config
+    from merlot_reserve_amd.synthetic import make_batch
+    from merlot_reserve_amd.trainer import Trainer
+    res = {}
+    for key, cfg, B in (('large_b4', load_config('large'), 4), ('large_resadapt_b2', resadapt_config('large'), 2)):
+        tr = Trainer(cfg, B, dev, seed=0)
+        batches = [make_batch(cfg, B, seed=1234 + 1000 * i, device=dev) for i in range(2)]
+        plans = [tr.plan(b) for b in batches]
+        tr.train_step(batches[0], plan=plans[0])
+        tr.capture(batches[0])
+        tr.train_step_graph(batches[1], plans[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(replays):
+            tr.train_step_graph(batches[i % 2], plans[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / replays
+        fl = algorithmic_flops_per_record(cfg) * B
+        res[key] = {'workload': f'large pretrain step, {B} records per GPU, frames {cfg["model"]["output_grid"][0] * 16}x{cfg["model"]["output_grid"][1] * 16}',
+                    'ms_per_step': dt * 1e3, 'video_segments_per_sec': 2 * B / dt, 'step_mfma_frac': fl / dt / MFMA_BF16_PEAK, 'replays': replays}
+        del tr, batches, plans
+        torch.cuda.empty_cache()
+    cfg = load_config('large')
+    cfg['model']['output_grid'] = [18, 32]
+    cfg['data'].update(lang_seq_len=144, num_answers=4)
+    cfg['optimizer'] = {'beta_2': 0.98, 'eps': 1e-6, 'learning_rate': 5e-6, 'num_train_steps': 1000, 'num_warmup_steps': 100,
+                        'use_bfloat16_adam': True, 'weight_decay_rate': 0.1, 'do_bias_correction': True}
+    B = 4
+    model = F.MerlotReserveVCR.from_config(cfg, device=dev)
+    batches = [F.make_vcr_batch(cfg, B, seed=i, device=dev) for i in range(2)]
+    model.init_from_dummy_batch(batches[0])
+    state, _ = F.construct_finetuning_train_state(cfg['optimizer'], model)
+    step = F.VCRGraphStep(state, batches[0])
+    plans = [F.build_vcr_plan(b['answers'], model.engine.d) for b in batches]
+    step(batches[1], plans[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(replays):
+        step(batches[i % 2], plans[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / replays
+    H, Lv, Lj = cfg['model']['hidden_size'], cfg['model']['vit_num_layers'], cfg['model']['joint_num_layers']
+    enc = lambda n, S, L: n * S * L * (24 * H * H + 4 * S * H)
+    fl = 3 * (enc(1, 577, Lv) + enc(8, 288, Lj) + 576 * 2 * 768 * H + 144 * 20 * H * H) * B           # SURVEY 8d, VCR per example
+    res['vcr_large_b4'] = {'workload': 'VCR finetuning step (finetune/vcr), large, 4 examples per GPU, image grid 18x32', 'ms_per_step': dt * 1e3,
+                           'examples_per_sec': B / dt, 'step_mfma_frac': fl / dt / MFMA_BF16_PEAK, 'replays': replays}
+    del step, state, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def _self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh ranks under torch.distributed.run as a
     CHILD process (this process has not touched the GPU and never execs), pass rank 0's JSON line through, return its code."""
@@ -100,6 +157,8 @@ def main():
     ap.add_argument('--no-h2d', action='store_true', help='skip the extra pass that feeds the inputs from host memory every step')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the hipGraph')
     ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL communicator, collectives inside the graph -- with a single rank')
+    ap.add_argument('--strict-graph', action='store_true', help='exit non-zero (value null) instead of timing eager steps when the hipGraph capture fails')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the short timings of BASELINE configs 3-5 (large, large resadapt, VCR large) at N = 1')
     ap.add_argument('--comm', default='native', choices=['native', 'torch'], help="native: the library's RCCL communicator (captured into the hipGraph); torch: torch.distributed nccl (eager step)")
     args = ap.parse_args()
 
@@ -120,6 +179,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     comm, comm_kind, dist = None, None, None
+    degraded = []          # anything that makes `value` NOT the intended program: reported at the top level of the JSON line
     if world > 1 or args.force_comm:
         import torch.distributed as dist
         from merlot_reserve_amd.dist import Comm, NativeComm
@@ -128,17 +188,11 @@ def main():
         # control plane (rendezvous, barriers, the max over ranks of the timed region): gloo, no GPU resources
         dist.init_process_group('gloo', rank=rank, world_size=world)
         if args.comm == 'native':
-            ok = 1
-            try:
+            try:            # symmetric: every rank returns a communicator or every rank raises (dist.NativeComm.from_torch_distributed)
                 comm = NativeComm.from_torch_distributed(dev)
-            except Exception as e:                                   # every rank must take the same branch below
+            except Exception as e:
                 print(f'[rank {rank}] native RCCL communicator unavailable ({e}); falling back to torch.distributed nccl', file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok])
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag) == 0:
-                if comm is not None:
-                    comm.close()
+                degraded.append(f'native RCCL communicator unavailable ({e}): torch.distributed nccl, eager steps')
                 comm = None
         if comm is None:
             comm = Comm(dist.new_group(backend='nccl', device_id=dev))
@@ -181,12 +235,20 @@ def main():
             if comm is None:
                 raise
             print(f'[rank {rank}] hipGraph capture of the step failed ({e}); stepping eagerly', file=sys.stderr)
+            degraded.append(f'hipGraph capture of the {world}-rank step failed on rank {rank} ({type(e).__name__}: {e}): EAGER steps were timed')
             ok = 0
         if dist is not None:                                     # every rank must take the same path
             flag = torch.tensor([ok])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag)
         if not ok:
+            if not degraded:
+                degraded.append('hipGraph capture of the step failed on another rank: EAGER steps were timed')
+            if args.strict_graph:
+                if rank == 0:
+                    print(json.dumps({'metric': 'video-segments/sec (whole node) pretrain step', 'value': None, 'unit': 'video-segments/sec',
+                                      'n_gpus': world, 'error': degraded}), flush=True)
+                sys.exit(3)
             use_graph, trainer.graph = False, None
             trainer.engine.plan_frozen = False
             torch.cuda.synchronize()
@@ -259,7 +321,7 @@ def main():
                              'so ms_per_step <= sum_ms'}
         ach_x = fl_x / (ms_x * 1e-3) / 1e12
         traffic, traffic_src = None, None       # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
-        for cand in ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
+        for cand in ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
             pmc = os.path.join(ROOT, 'profiles', cand)
             if not os.path.exists(pmc):
                 continue
@@ -272,7 +334,7 @@ def main():
         # `achieved` = the launches timed one at a time (side stream off): that is the kernel's own duration and what rocprofv3's
         # per-kernel average of the graph-replayed step shows (profiles/); `achieved_concurrent` = the same launches timed while
         # the other tower's kernels share the GPU on the second stream (durations then include the CUs yielded to them)
-        roof = {'bound': 'mfma', 'kernel': 'g256::gemm256_kernel<*> (+ gemm_bf16_kernel for small shapes)', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+        roof = {'bound': 'mfma', 'kernel': 'g3::gemm3_kernel<*> / gemm3_tn_kernel (ping-pong), g256::gemm256_kernel<*>, gemm_bf16_kernel for small shapes', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic,
                 'traffic_unit': f'HBM-side bytes per GEMM launch (PMC, profiles/{traffic_src})', 'launches': n,
                 'avg_launch_us': ms_x * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
@@ -295,6 +357,20 @@ def main():
                        'step_mfma_frac': step_flops / (dt / args.steps) / MFMA_BF16_PEAK},
             'roofline': roof, 'breakdown': breakdown,
         }
+        if degraded:
+            out['degraded'] = degraded
+        if comm is not None:
+            # RCCL chooses algorithm / protocol per call (its tuner, from message size and topology) unless the environment pins
+            # them; what this run allowed it, and the message sizes it chose for
+            import torch.cuda.nccl as _nccl
+            out['config']['rccl'] = {'version': '.'.join(str(v) for v in _nccl.version()), 'NCCL_ALGO': os.environ.get('NCCL_ALGO', 'auto (RCCL tuner)'),
+                                     'NCCL_PROTO': os.environ.get('NCCL_PROTO', 'auto (RCCL tuner)'),
+                                     'allreduce_bucket_mbytes': [round((b[2] - b[1]) * 2 / 1e6, 1) for b in trainer.buckets],
+                                     'allgather_mbytes_per_rank': round(trainer.engine.R * trainer.engine.d.H * 2 / 1e6, 3)}
+        if world == 1 and not args.no_secondary and comm is None:
+            del trainer
+            torch.cuda.empty_cache()
+            out['config']['secondary'] = secondary_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(config)
         print(json.dumps(out), flush=True)

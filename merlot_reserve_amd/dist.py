@@ -63,18 +63,23 @@ class NativeComm:
     capturable = True
     backend = 'rccl-native'
 
-    def __init__(self, rank=0, world=1, unique_id=None):
+    def __init__(self, rank=0, world=1, unique_id=None, device=None):
         from . import _lib
         self._lib = _lib
+        self._h = None
         lib = _lib.load()
         if unique_id is None:
             assert world == 1, 'world > 1: rank 0 creates the id (NativeComm.new_unique_id) and every rank passes the same bytes'
             unique_id = self.new_unique_id()
         assert len(unique_id) == 128
         self.rank, self.world = rank, world
+        # the communicator binds to the device that is current inside mr_comm_init: make that the caller's device, and keep it
+        # for the collectives (two ranks that both initialise on device 0 hang inside RCCL)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         h = C.c_void_p()
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
-        _lib.check(lib.mr_comm_init(rank, world, buf, C.byref(h)), 'mr_comm_init')
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mr_comm_init(rank, world, buf, C.byref(h)), 'mr_comm_init')
         self._h = h
         assert lib.mr_comm_world(h) == world and lib.mr_comm_rank(h) == rank
 
@@ -87,14 +92,49 @@ class NativeComm:
 
     @classmethod
     def from_torch_distributed(cls, device, group=None):
-        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast to every rank."""
+        """Bootstrap over an initialised torch.distributed group (any backend).  SYMMETRIC: every rank makes the same sequence of
+        control-plane collectives whatever fails where, and either every rank returns a communicator or every rank raises --
+        (1) rank 0 creates the id and broadcasts (ok, id | error text); (2) every rank initialises; (3) a MIN all-reduce of the
+        per-rank outcome.  (A rank-0 failure used to skip the broadcast the other ranks were waiting in.)"""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group, device=torch.device(device) if dist.get_backend(group) == 'nccl' else None)
-        return cls(rank, world, box[0])
+        obj_dev = torch.device(device) if dist.get_backend(group) == 'nccl' else None
+        box = [None]
+        if rank == 0:
+            try:
+                box = [(True, cls.new_unique_id())]
+            except Exception as e:                                   # noqa: BLE001 -- reported to every rank below
+                box = [(False, f'{type(e).__name__}: {e}')]
+        dist.broadcast_object_list(box, src=0, group=group, device=obj_dev)
+        ok, payload = box[0]
+        if not ok:
+            raise RuntimeError(f'rank 0 could not create the RCCL unique id: {payload}')
+        comm, err = None, ''
+        try:
+            comm = cls(rank, world, payload, device=device)
+        except Exception as e:                                       # noqa: BLE001
+            err = f'{type(e).__name__}: {e}'
+        flag = torch.tensor([1 if comm is not None else 0], device=obj_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag) == 0:
+            if comm is not None:
+                comm.close()
+            raise RuntimeError(f'RCCL communicator initialisation failed on some rank (this rank: {err or "ok"})')
+        return comm
 
-    @staticmethod
-    def _stream():
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _stream(self):
+        assert torch.cuda.current_device() == self.device.index, f'NativeComm is bound to {self.device}; current device is cuda:{torch.cuda.current_device()}'
         return torch.cuda.current_stream().cuda_stream
 
     def gather_embeddings(self, E, E_all):
@@ -122,6 +162,6 @@ class NativeComm:
         return t
 
     def close(self):
-        if self._h is not None:
+        if getattr(self, '_h', None) is not None:
             self._lib.load().mr_comm_destroy(self._h)
             self._h = None

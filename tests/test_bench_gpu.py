@@ -30,6 +30,14 @@ def test_bench_line_contract(dev):
     assert r['traffic'] is None or r['traffic'] > 0
     b = d['breakdown']
     assert set(b['ms_per_step']) >= {'gemm', 'attention', 'layernorm+reductions', 'optimizer'} and b['sum_ms'] > 0
+    assert 'degraded' not in d
+    # BASELINE configs 3-5 ride on the same line (one GPU of their eight): ms / step, throughput, whole-step MFMA fraction
+    sec = d['config']['secondary']
+    assert set(sec) == {'large_b4', 'large_resadapt_b2', 'vcr_large_b4'}
+    for k, v in sec.items():
+        assert v['ms_per_step'] > 0 and 0.05 < v['step_mfma_frac'] < 1.0 and v['replays'] >= 3, (k, v)
+    assert abs(sec['large_b4']['video_segments_per_sec'] - 8 * 1000.0 / sec['large_b4']['ms_per_step']) < 1e-6 * sec['large_b4']['video_segments_per_sec']
+    assert abs(sec['vcr_large_b4']['examples_per_sec'] - 4 * 1000.0 / sec['vcr_large_b4']['ms_per_step']) < 1e-6 * sec['vcr_large_b4']['examples_per_sec']
 
 
 def test_bench_multi_rank_code_path_with_one_rank(dev):
@@ -46,6 +54,7 @@ def test_bench_multi_rank_code_path_with_one_rank(dev):
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     c = d['config']
-    assert c['comm'] == 'rccl-native' and c['rccl_ranks'] == 1 and c['hipgraph'] is True
+    assert c['comm'] == 'rccl-native' and c['rccl_ranks'] == 1 and c['hipgraph'] is True and 'degraded' not in d
+    assert len(c['rccl']['allreduce_bucket_mbytes']) == 5 and c['rccl']['version'] and 'NCCL_ALGO' in c['rccl']
     assert len(c['gradient_buckets']) == 5 and 0.0 < c['exposed_gradient_fraction'] < 0.2
     assert d['value'] > 0 and d['n_gpus'] == 1

@@ -137,6 +137,82 @@ def test_two_rank_reduced_gradients_match_oracle_mean(dev):
         assert not ret[r]['bad'], ret[r]['bad']
         assert ret[r]['nleaves'] > 50
 
+def _mixed_grid_worker(rank, world, port, ret):
+    """pretrain/train_fixres.py:78-90: processes alternate between two frame grids (18 x 32 / 24 x 24 in the reference; 4 x 6 /
+    6 x 4... here two tiny grids with different patch counts, hence different ViT and joint lengths) while all-reducing the
+    gradients of ONE parameter set.  Same check as _grad_worker: reduced gradients = mean of the oracle's per-rank gradients."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from merlot_reserve_amd.config import tiny_config
+    from merlot_reserve_amd.dist import Comm
+    from merlot_reserve_amd.synthetic import make_batch, make_draws
+    from merlot_reserve_amd.trainer import Trainer
+    from oracle import ref_torch as R
+    from tests.test_pretrain_gpu import SECTIONS
+    from tests.util import oracle_batch, oracle_draws, tree_to
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    grids = [(4, 6), (6, 6)]                               # 24 / 36 patches per frame: joint lengths differ between the ranks
+
+    def cfg_of(r):
+        c = tiny_config(grid=grids[r], lang_seq_len=40, seq_len=40 + 2 * (grids[r][0] * grids[r][1]) // 4 + 8)
+        c['model']['vit_num_layers'] = 3
+        return c
+    cfgs = [cfg_of(r) for r in range(world)]
+    B = 2
+    tr = Trainer(cfgs[rank], B, dev, rank=rank, world=world, seed=0, comm=Comm())
+    batches = [make_batch(cfgs[r], B, seed=400 + r, device=dev) for r in range(world)]
+    draws = [make_draws(cfgs[r], B, seed=400 + r) for r in range(world)]
+    assert batches[0]['images'].shape != batches[1]['images'].shape
+    R_, H = tr.engine.R, tr.engine.d.H
+    dEs = [(torch.randn(R_, H, generator=torch.Generator().manual_seed(500 + r)) * 1e-2).to(torch.bfloat16) for r in range(world)]
+    tr.forward_and_loss(batches[rank], tr.plan(batches[rank], draws[rank]))
+    local_loss = tr.loss_info(reduce=False)['loss']
+    tr.engine.dE.copy_(dEs[rank].to(dev))
+    tr.backward_and_reduce(update=False)
+    torch.cuda.synchronize()
+    gt = tr.params.grad_tree()
+    params = R.tree_map(lambda t: t.clone().requires_grad_(True), tree_to(tr.params.work_tree(), torch.float32))
+    total = 0.0
+    for r in range(world):
+        osp, oz = oracle_draws(*draws[r])
+        preds = R.pretrain_forward(params, cfgs[r], oracle_batch(batches[r]), osp, oz)
+        for k, k2, name in SECTIONS:
+            o, n = tr.engine.sec[name]
+            total = total + (preds[k][k2] * dEs[r][o:o + n].float()).sum()
+    (total / world).backward()
+    leaves = [(n, t.grad if t.grad is not None else torch.zeros_like(t)) for n, t in R.tree_leaves(params)]
+    gmax = max(float(g.norm()) for _, g in leaves)
+    bad = []
+    for name, g in leaves:
+        mine = gt
+        for part in name.split('/'):
+            mine = mine[part]
+        gn, err = float(g.norm()), float((mine.double() - g.double()).norm())
+        cos = float((mine.double().flatten() @ g.double().flatten()) / (mine.double().norm() * g.double().norm() + 1e-30))
+        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+            bad.append((name, err, gn, cos))
+    flat = tr.params.grad.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ret[rank] = dict(bad=bad[:10], nleaves=len(leaves), replicas_equal=bool(torch.equal(gathered[0], gathered[1])),
+                     Sj=tr.engine.d.Sj, loss=local_loss)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_different_grids(dev):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mixed_grid_worker, args=(world, 30300 + (os.getpid() % 1000), ret), nprocs=world, join=True)
+    assert ret[0]['Sj'] != ret[1]['Sj'], 'the ranks must run different joint lengths'
+    for r in range(world):
+        assert ret[r]['replicas_equal'], 'ranks hold different reduced gradients'
+        assert not ret[r]['bad'], ret[r]['bad']
+        assert ret[r]['nleaves'] > 50 and ret[r]['loss'] == ret[r]['loss']
+
+
 
 def _native_single_rank(_i, ret):
     torch.cuda.set_device(0)

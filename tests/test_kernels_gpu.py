@@ -517,6 +517,42 @@ def test_adam_bf16(dev):
         assert torch.equal(work[sl].cpu(), d_master[sl].cpu().to(BF16))
 
 
+def test_adam_bf16_state_words_bit_exact(dev):
+    """The optimizer state is byte data: mu = bf16(m'), nu = the sign-coded bf16 of v'^3 (pretrain/optimization.py:36-51 defines the
+    code exactly).  The kernel's words must EQUAL the oracle's on >= 99.9 % of 65 536 elements; the rest -- an fp32 ulp from fma
+    contraction / the device cbrt landing on the other side of a bf16 rounding or sign-code boundary -- must be neighbouring codes
+    (one bf16 ulp in magnitude, or the same magnitude with the other sign code)."""
+    from merlot_reserve_amd import ops
+    from oracle import ref_torch as R
+    n = 2048 * 32
+    g = torch.Generator().manual_seed(1)
+    master = torch.randn(n, generator=g) * 0.05
+    grad = (torch.randn(n, generator=g) * 1e-3 * torch.exp(torch.randn(n, generator=g))).to(BF16)
+    mu = (torch.randn(n, generator=g) * 1e-3).to(BF16)
+    nu = R.unsigned_bf16_encode((torch.rand(n, generator=g) * 1e-3 * torch.exp(torch.randn(n, generator=g))).float())
+    nu[:64] = 0.0
+    flags = torch.ones(32, dtype=torch.uint8)
+    cfg = dict(learning_rate=4e-4, num_train_steps=750000, num_warmup_steps=3750, weight_decay_rate=0.1, beta_2=0.98,
+               eps=1e-6, use_bfloat16_adam=True)
+    count = 4000
+    sched = float(R.lr_scale_linearwarmup_cosinedecay(count, 3750, 750000, 0.02))
+    d_master, d_mu, d_nu = master.to(dev), mu.to(dev), nu.to(dev)
+    work = torch.zeros(n, dtype=BF16, device=dev)
+    ops.adam_bf16_update(d_master, work, grad.to(dev), d_mu, d_nu, flags.to(dev), 0.9, 0.98, 1e-6, 0.1, sched, -4e-4)
+    _, nm, nv = R.adam_bf16_apply(master.reshape(n, 1), grad.float().reshape(n, 1), mu.reshape(n, 1), nu.reshape(n, 1), count, cfg)
+    bits = lambda t: t.reshape(-1).contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+    for name, got, ref in (('mu', d_mu.cpu(), nm), ('nu', d_nu.cpu(), nv)):
+        gb, rb = bits(got), bits(ref)
+        neq = (gb != rb).nonzero().reshape(-1)
+        frac = 1.0 - neq.numel() / n
+        print(f'adam state {name}: {n - neq.numel()} of {n} bf16 words equal ({frac * 100:.4f} %); {neq.numel()} differ')
+        assert frac >= 0.999, (name, frac)
+        for i in neq.tolist():
+            a, b = int(gb[i]), int(rb[i])
+            mag = abs((a & 0x7FFF) - (b & 0x7FFF))
+            assert mag <= 1, (name, i, hex(a), hex(b))          # neighbouring magnitude codes; (nu) possibly the other sign code
+
+
 GEMM256_CASES = [
     # shapes that dispatch to the 256-row LDS-DMA kernel (M >= 512): ragged M, both tile widths, all layouts, split-K
     (15424 // 4, 768, 768, False, False),
