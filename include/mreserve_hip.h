@@ -226,13 +226,13 @@ int mr_split_f32_to_bf16_hilo_rows(const float* src, int64_t lds, void* hi, void
  * Writes master, the bf16 working copy (what the next forward reads, P:323-324), mu, nu.
  */
 int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                        const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2, float eps,
+                        const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2, float eps,
                         float weight_decay, float sched, float neg_lr, float bias_corr1, float bias_corr2, void* stream);
 /* Finetuning chain (finetune/optimization.py:77-90: Adam with bias correction, subtract_old_weights, add_decayed_weights,
  * linear schedule, -lr): as above plus `orig_bf16`, the bf16 copy of the initial parameters; under the decay mask
  * (leaf ndim > 1 and size > 4096: finetune/optimization.py:74-75) u = u - wd * orig + wd * param. */
 int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                                 const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                                 const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2,
                                  float eps, float weight_decay, float sched, float neg_lr, float bias_corr1,
                                  float bias_corr2, void* stream);
 /* Either chain with the four per-step scalars read from DEVICE memory: hyper_dev = {sched, neg_lr, 1/bias_corr1,
@@ -241,7 +241,7 @@ int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* gra
  * as soon as that range's gradients are final -- overlapped with the rest of backward.  orig_bf16 = NULL selects the
  * pretraining chain, non-NULL the finetuning chain. */
 int mr_adam_bf16_update_dev(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2,
                             float eps, float weight_decay, const float* hyper_dev, void* stream);
 /* ---- softmax cross-entropy over C <= 64 classes (finetune/vcr/qa_qar_joint_finetune.py:188-195) ----
  * logits[r * row_stride + c * class_stride] fp32; loss_out += coef * sum_r -log_softmax(logits[r])[labels[r]];

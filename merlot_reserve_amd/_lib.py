@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MR_LIB', os.path.join(HERE, 'libmreserve_hip.so'))    # MR_LIB: A/B a kernel variant in one run
 
-i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+i64, i32, f32, f64, vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
 
 
 class GemmArgs(C.Structure):
@@ -65,9 +65,9 @@ PROTOTYPES = {
     'mr_split_f32_to_bf16_hilo_rows': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_cast_f32_to_bf16': (i32, [vp, vp, i64, vp]),
     'mr_split_f32_to_bf16_hilo': (i32, [vp, vp, vp, i64, vp]),
-    'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
-    'mr_adam_bf16_update_finetune': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
-    'mr_adam_bf16_update_dev': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
+    'mr_adam_bf16_update': (i32, [vp, vp, vp, vp, vp, vp, i64, f64, f64, f32, f32, f32, f32, f32, f32, vp]),
+    'mr_adam_bf16_update_finetune': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f64, f64, f32, f32, f32, f32, f32, f32, vp]),
+    'mr_adam_bf16_update_dev': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f64, f64, f32, f32, vp, vp]),
     'mr_softmax_xent': (i32, [vp, i64, i64, vp, i64, i64, f32, vp, vp, vp, vp]),
     'mr_nan_to_num_bf16': (i32, [vp, i64, vp]),
     'mr_cast_f32_to_bf16_params': (i32, [vp, vp, i64, vp]),

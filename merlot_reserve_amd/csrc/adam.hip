@@ -116,57 +116,57 @@ __global__ __launch_bounds__(256) void transpose_leaves_kernel(const __bf16* __r
 }  // namespace
 
 extern "C" int mr_adam_bf16_update(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                                   const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2, float eps,
+                                   const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2, float eps,
                                    float weight_decay, float sched, float neg_lr, float bias_corr1, float bias_corr2,
                                    void* stream) {
     MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && decay_flag_per_block, "mr_adam_bf16_update: null pointer");
     MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update: n must be a positive multiple of 2048 (got %ld)", (long)n);
     MR_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "mr_adam_bf16_update: bias corrections must be > 0 (1 disables)");
     // (1 - b) evaluated like the reference: Python double subtraction, then cast to f32 (optimization.py:86, 91)
-    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    const float c1 = (float)(1.0 - b1), c2 = (float)(1.0 - b2);      // f32(1 - b) of the Python float b, as jnp evaluates (1 - b1) * g
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
                        static_cast<__bf16*>(work_bf16), static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16),
-                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, b1, c2, b2,
+                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, (float)b1, c2, (float)b2,
                        eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
     MR_CHECK_LAUNCH("mr_adam_bf16_update");
     return MR_OK;
 }
 
 extern "C" int mr_adam_bf16_update_finetune(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1,
-                                            float b2, float eps, float weight_decay, float sched, float neg_lr,
+                                            const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, double b1,
+                                            double b2, float eps, float weight_decay, float sched, float neg_lr,
                                             float bias_corr1, float bias_corr2, void* stream) {
     MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && orig_bf16 && decay_flag_per_block,
                  "mr_adam_bf16_update_finetune: null pointer");
     MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update_finetune: n must be a positive multiple of 2048 (got %ld)", (long)n);
     MR_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "mr_adam_bf16_update_finetune: bias corrections must be > 0");
-    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    const float c1 = (float)(1.0 - b1), c2 = (float)(1.0 - b2);      // f32(1 - b) of the Python float b, as jnp evaluates (1 - b1) * g
     hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
                        static_cast<__bf16*>(work_bf16), static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16),
-                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, b1, c2,
-                       b2, eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
+                       static_cast<__bf16*>(nu_bf16), static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, (float)b1, c2,
+                       (float)b2, eps, weight_decay, sched, neg_lr, 1.0f / bias_corr1, 1.0f / bias_corr2);
     MR_CHECK_LAUNCH("mr_adam_bf16_update_finetune");
     return MR_OK;
 }
 
 extern "C" int mr_adam_bf16_update_dev(float* master, void* work_bf16, const void* grad_bf16, void* mu_bf16, void* nu_bf16,
-                                       const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, float b1, float b2,
+                                       const void* orig_bf16, const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2,
                                        float eps, float weight_decay, const float* hyper_dev, void* stream) {
     MR_CHECK_ARG(master && work_bf16 && grad_bf16 && mu_bf16 && nu_bf16 && decay_flag_per_block && hyper_dev,
                  "mr_adam_bf16_update_dev: null pointer");
     MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_bf16_update_dev: n must be a positive multiple of 2048 (got %ld)", (long)n);
-    const float c1 = (float)(1.0 - (double)b1), c2 = (float)(1.0 - (double)b2);
+    const float c1 = (float)(1.0 - b1), c2 = (float)(1.0 - b2);      // f32(1 - b) of the Python float b, as jnp evaluates (1 - b1) * g
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)(n / 2048));
     if (orig_bf16 != nullptr)
         hipLaunchKernelGGL((adam_kernel<true, true>), grid, dim3(256), 0, st, master, static_cast<__bf16*>(work_bf16),
                            static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16), static_cast<__bf16*>(nu_bf16),
-                           static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, 0.f, 0.f,
+                           static_cast<const __bf16*>(orig_bf16), decay_flag_per_block, c1, (float)b1, c2, (float)b2, eps, weight_decay, 0.f, 0.f,
                            1.f, 1.f, hyper_dev);
     else
         hipLaunchKernelGGL((adam_kernel<false, true>), grid, dim3(256), 0, st, master, static_cast<__bf16*>(work_bf16),
                            static_cast<const __bf16*>(grad_bf16), static_cast<__bf16*>(mu_bf16), static_cast<__bf16*>(nu_bf16),
-                           static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, b1, c2, b2, eps, weight_decay, 0.f, 0.f,
+                           static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, (float)b1, c2, (float)b2, eps, weight_decay, 0.f, 0.f,
                            1.f, 1.f, hyper_dev);
     MR_CHECK_LAUNCH("mr_adam_bf16_update_dev");
     return MR_OK;

@@ -512,6 +512,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
         cn0 = item_n0(qc);
     }
     if (wr == 0) G3_BARRIER();          // pairs with group 1's last barrier
+#ifdef MR_DIAG_RELEASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 

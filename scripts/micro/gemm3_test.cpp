@@ -66,6 +66,16 @@ __global__ void ref_tn_kernel(const bf16_t* A, int64_t lda, const bf16_t* B, int
     C[m * ldc + n] = f2bf(acc);
 }
 
+__global__ void cmp_kernel(const uint4* a, const uint4* b, long n16, unsigned long long* bad) {
+    unsigned long long nb = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+        const long j = n16 - 1 - i;          // not the writer's block -> data mapping
+        const uint4 x = a[j], y = b[j];
+        if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) ++nb;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+
 struct Case { int64_t M, N, K; int mode; const char* name; };   // mode 0 bias | 1 rot | 2 gelu + c2 | 3 residual | 4 aux + colsum | 5 plain (no bias) | 6 bias + row map
 
 static bf16_t *dA[3], *dB, *dC[3], *dC2[3], *dX, *dBias, *dRefC, *dRefC2;
@@ -282,6 +292,36 @@ int main(int argc, char** argv) {
             const double fl = 2.0 * K * 2 * (4 * H * H * 2 + H * H + 3 * H * H);
             printf("  time  TN grouped x8, K=%ld: one-barrier %.1f us (%.0f TF/s)   ping-pong %.1f us (%.0f TF/s)\n", (long)K, tot[0] * 1e3 / n[0], fl / (tot[0] / n[0]) * 1e-9,
                    tot[1] * 1e3 / n[1], fl / (tot[1] / n[1]) * 1e-9);
+        }
+        mr_set_option("gemm3", 1);
+    }
+    if (!strcmp(what, "race")) {
+        // A consumer kernel right behind the GEMM in the SAME stream must see every store of the GEMM, also while another stream's
+        // GEMMs are resident: step t computes C = A[t % 2] . B into the same C buffer and a checker compares it with the reference
+        // output of A[t % 2] (computed once by the same kernel, alone on the GPU).
+        const Case c = {15424, 768, 3072, 3, "fc2 fwd residual"};
+        const int variants[] = {192, 256, 0};
+        unsigned long long* dBad; CK(hipMalloc(&dBad, 8));
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        for (int v : variants) for (int other = 0; other < 2; ++other) {
+            mr_set_option("gemm3", v);
+            mr_gemm_args g, g2;
+            const long n16 = c.M * c.N * 2 / 16;
+            for (int set = 0; set < 2; ++set) {          // references -> dC2[set]
+                setup_args(&g, c, set, false); g.C = dC2[set]; mr_gemm(&g, nullptr);
+            }
+            CK(hipDeviceSynchronize());
+            CK(hipMemset(dBad, 0, 8));
+            const Case o = {5952, 3072, 768, 2, "other"};
+            for (int t = 0; t < 400; ++t) {
+                if (other) { setup_args(&g2, o, 2, false); mr_gemm(&g2, s2); }
+                setup_args(&g, c, t % 2, false); g.C = dC[0];
+                mr_gemm(&g, s1);
+                hipLaunchKernelGGL(cmp_kernel, dim3(512), dim3(256), 0, s1, (const uint4*)dC[0], (const uint4*)dC2[t % 2], n16, dBad);
+            }
+            CK(hipDeviceSynchronize());
+            unsigned long long hb; CK(hipMemcpy(&hb, dBad, 8, hipMemcpyDeviceToHost));
+            printf("race: kernel %s, other stream %d: %llu stale 16-byte words in 400 steps\n", v == 0 ? "one-barrier" : v == 192 ? "ping-pong/192" : "ping-pong/256", other, hb);
         }
         mr_set_option("gemm3", 1);
     }
