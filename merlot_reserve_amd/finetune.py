@@ -161,6 +161,22 @@ class VCREngine(TowerEngine):
         self.backward_stage_joint()
         self.backward_stage_vision()
 
+    def gradient_buckets(self):
+        """Ranges of the flat gradient buffer in the order backward makes them final (like trainer.Trainer._make_buckets):
+        'joint' = [proj, joint tower, token table]; the vision tower cut at 2/3 and 1/3 of its depth; 'vision_end' = the rest."""
+        p, Lv = self.p, self.d.Lv
+        v0, v1 = p.tower_ranges['vision_encoder']
+        assert v1 == p.total
+        cuts = sorted({l for l in (Lv - Lv // 3, Lv - 2 * (Lv // 3)) if 0 < l < Lv}, reverse=True)
+        lo_of = lambda l: p.offsets[f'vision_encoder/transformer/layer_{l:02d}/pre_attn_ln/scale'][0]
+        buckets, hi = [('joint', 0, v0)], v1
+        for l in cuts:
+            buckets.append((('vision', l), lo_of(l), hi))
+            hi = lo_of(l)
+        buckets.append(('vision_end', v0, hi))
+        assert sum(b[2] - b[1] for b in buckets) == p.total and all(b[1] % 2048 == 0 and b[2] % 2048 == 0 for b in buckets)
+        return buckets, cuts
+
     def backward_stage_joint(self):
         d, W, G, tj = self.d, self.W, self.p.g, self.tj
         dl = self.dlogits[:, :1]
@@ -171,11 +187,11 @@ class VCREngine(TowerEngine):
         ops.segment_sum([Dj], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
         ops.segment_sum([Dj], self.visT[0], self.visT[1], self.d_imgs_seq)
 
-    def backward_stage_vision(self):
+    def backward_stage_vision(self, layer_done=None):
         d, G, tv = self.d, self.p.g, self.tv
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
                                             self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.d_imgs_seq,
-                                            self.d_v_cls, self.Dv)
+                                            self.d_v_cls, self.Dv, layer_done=layer_done)
         Dp = self.cur.Dpatch[:d.B * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
         ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
@@ -242,20 +258,52 @@ class FinetuneTrainState:
     def params(self):
         return self._model.params_store.master_tree()
 
-    def apply_gradients(self):
-        """FO:77-90 + apply_updates, one fused launch over the flat buffers."""
-        oc, p = self.opt_config, self._model.params_store
+    def _scalars(self):
+        oc = self.opt_config
         assert oc.get('use_bfloat16_adam', True)
         sched = lr_scale_linearwarmup_lineardecay(self.step, oc['num_warmup_steps'], oc['num_train_steps'])
         b1, b2 = oc.get('beta_1', 0.9), oc.get('beta_2', 0.98)
         bc1 = bc2 = 1.0
         if oc.get('do_bias_correction', True):
             bc1, bc2 = 1.0 - b1 ** (self.step + 1), 1.0 - b2 ** (self.step + 1)
-        ops.adam_bf16_update_finetune(p.master, p.work, p.grad, p.mu, p.nu, p.orig, p.decay_flags, b1, b2, oc.get('eps', 1e-6),
-                                      oc['weight_decay_rate'], sched, -oc['learning_rate'], bc1, bc2)
+        return sched, -oc['learning_rate'], bc1, bc2
+
+    def apply_gradients(self):
+        """FO:77-90 + apply_updates, one fused launch over the flat buffers."""
+        oc, p = self.opt_config, self._model.params_store
+        sched, neg_lr, bc1, bc2 = self._scalars()
+        ops.adam_bf16_update_finetune(p.master, p.work, p.grad, p.mu, p.nu, p.orig, p.decay_flags, oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
+                                      oc.get('eps', 1e-6), oc['weight_decay_rate'], sched, neg_lr, bc1, bc2)
         p.update_transposed()
         self.step += 1
         return self
+
+    # ---- the same update per gradient bucket with the step's scalars in a device vector, so that the launches can sit inside a
+    # hipGraph and overlap the rest of backward (like trainer.TrainState.prepare_step / apply_range)
+    def prepare_step(self):
+        dev = self._model.params_store.device
+        if getattr(self, 'hyper', None) is None:
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._hyper_host = [torch.zeros(4, dtype=torch.float32, pin_memory=dev.type == 'cuda') for _ in range(2)]
+            self._hyper_ev, self._hyper_turn = [None, None], 0
+        i = self._hyper_turn
+        self._hyper_turn ^= 1
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()
+        sched, neg_lr, bc1, bc2 = self._scalars()
+        f32 = np.float32         # 1 / bias_correction in fp32, as mr_adam_bf16_update_finetune forms it from its float arguments
+        self._hyper_host[i].copy_(torch.tensor([sched, neg_lr, float(f32(1.0) / f32(bc1)), float(f32(1.0) / f32(bc2))], dtype=torch.float32))
+        self.hyper.copy_(self._hyper_host[i], non_blocking=True)
+        if dev.type == 'cuda':
+            self._hyper_ev[i] = torch.cuda.Event()
+            self._hyper_ev[i].record()
+
+    def apply_range(self, lo, hi):
+        oc, p = self.opt_config, self._model.params_store
+        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], p.orig[lo:hi],
+                                 p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98), oc.get('eps', 1e-6),
+                                 oc['weight_decay_rate'], self.hyper)
+        p.update_transposed(lo, hi)
 
 
 def construct_finetuning_train_state(opt_config, model, params=None, only_state=False):
@@ -277,34 +325,81 @@ def train_loss_fn(state, params, batch):
     return info['loss'], info
 
 
+def _backward_reduce_update(state):
+    """Backward from the engine's dlogits with every finished gradient BUCKET handed to a second stream: nan_to_num ->
+    all-reduce(mean) over ranks (FO:148-149) -> the optimizer chain on that range (FO:77-90), while the main stream goes on with
+    the vision tower's backward.  Four buckets in ONE program order on ONE stream, the same on every rank; with the library's RCCL
+    communicator the whole sequence is capturable (VCRGraphStep)."""
+    model = state._model
+    eng, comm, p = model.engine, model.comm, model.params_store
+    main = torch.cuda.current_stream()
+    if getattr(eng, 'comm_stream', None) is None:
+        eng.comm_stream = torch.cuda.Stream(device=eng.dev)
+    cs = eng.comm_stream
+    buckets, cuts = eng.gradient_buckets()
+    eng.bucket_log = []
+
+    def finish(key):
+        _, lo, hi = next(b for b in buckets if b[0] == key)
+        eng.bucket_log.append(key)
+        cs.wait_stream(main)
+        with torch.cuda.stream(cs):
+            if comm is not None:
+                ops.nan_to_num_(p.grad[lo:hi])
+                comm.allreduce_mean(p.grad[lo:hi])
+            state.apply_range(lo, hi)
+    eng.backward_stage_joint()
+    finish('joint')
+    eng.backward_stage_vision(layer_done=lambda l: finish(('vision', l)) if l in cuts else None)
+    finish('vision_end')
+    main.wait_stream(cs)
+
+
 def finetune_train_step(state, batch, loss_fn=None, tx_fns=None, scan_minibatch=False):
-    """FO:106-191: bf16 parameter copy -> forward -> loss -> backward -> nan_to_num -> mean over ranks -> optimizer."""
-    if scan_minibatch:
-        raise NotImplementedError('scan_minibatch (a TPU memory measure) is not needed with 288 GB of HBM')
+    """FO:106-191: bf16 parameter copy -> forward -> loss -> backward -> nan_to_num -> mean over ranks -> optimizer.
+    scan_minibatch (FO:125-146): gradients of the examples taken one at a time and SUMMED in bf16 (not averaged: as the reference
+    notes, Adam rescales), the metrics averaged."""
     model = state._model
     eng = model._ensure(batch)
+    if scan_minibatch:
+        return _finetune_train_step_scanned(state, batch)
     eng.forward(batch)
     eng.loss_and_grad_logits()
-    comm, p = model.comm, model.params_store
-    if comm is not None:
-        v0, v1 = p.tower_ranges['vision_encoder']
-        assert v1 == p.total
-        main = torch.cuda.current_stream()
-        if getattr(eng, 'comm_stream', None) is None:
-            eng.comm_stream = torch.cuda.Stream(device=eng.dev)
-        eng.backward_stage_joint()
-        eng.comm_stream.wait_stream(main)
-        with torch.cuda.stream(eng.comm_stream):                 # overlaps the vision tower's backward
-            ops.nan_to_num_(p.grad[:v0])
-            comm.allreduce_mean(p.grad[:v0])
-        eng.backward_stage_vision()
-        ops.nan_to_num_(p.grad[v0:])
-        comm.allreduce_mean(p.grad[v0:])
-        main.wait_stream(eng.comm_stream)
-    else:
-        eng.backward()
-    state.apply_gradients()
+    state.prepare_step()
+    _backward_reduce_update(state)
+    state.step += 1
     info = eng.loss_info()
+    comm = model.comm
+    if comm is not None and comm.world > 1:
+        t = torch.tensor([info['loss'], info['is_right']], dtype=torch.float32, device=eng.dev)
+        comm.allreduce_mean(t)
+        info = {'loss': float(t[0]), 'is_right': float(t[1])}
+    return state, info
+
+
+def _finetune_train_step_scanned(state, batch):
+    model = state._model
+    eng, comm, p = model.engine, model.comm, model.params_store
+    if getattr(model, '_engine1', None) is None:              # an engine for ONE example on the same parameter store
+        model._engine1 = VCREngine(model.config, 1, p, model.device)
+    e1 = model._engine1
+    acc = torch.zeros_like(p.grad)
+    losses = []
+    for i in range(eng.d.B):
+        micro = {'image': batch['image'][i:i + 1], 'answers': np.asarray(batch['answers'])[i:i + 1], 'labels': np.asarray(batch['labels'])[i:i + 1]}
+        e1.forward(micro)
+        e1.loss_and_grad_logits()
+        e1.backward()
+        ops.add_(acc, p.grad)                                 # bf16 + bf16 -> bf16, like the scan's `a + b` on bf16 leaves
+        losses.append(e1.loss_info())
+    p.grad.copy_(acc)
+    if comm is not None:
+        ops.nan_to_num_(p.grad)
+        comm.allreduce_mean(p.grad)
+    state.prepare_step()
+    state.apply_range(0, p.total)
+    state.step += 1
+    info = {k: float(np.mean([l[k] for l in losses])) for k in losses[0]}
     if comm is not None and comm.world > 1:
         t = torch.tensor([info['loss'], info['is_right']], dtype=torch.float32, device=eng.dev)
         comm.allreduce_mean(t)
@@ -313,14 +408,17 @@ def finetune_train_step(state, batch, loss_fn=None, tx_fns=None, scan_minibatch=
 
 
 class VCRGraphStep:
-    """hipGraph replay of finetune_train_step (single rank): the step is a fixed launch sequence over fixed buffers, so
-    forward + loss + backward are captured once and replayed; per batch only the image, the labels and the plan's index
-    lists are copied into their persistent buffers.  Same results as finetune_train_step (tests/test_vcr_gpu.py)."""
+    """hipGraph replay of finetune_train_step: the step is a fixed launch sequence over fixed buffers, so forward + loss + backward +
+    the four bucket reductions + the optimizer are captured ONCE and replayed -- with the library's RCCL communicator
+    (dist.NativeComm) the collectives are stream-ordered launches inside the same graph (a torch.distributed comm is host-scheduled
+    and cannot be captured); per batch only the image, the labels, the plan's index lists and the step's four scalars are copied
+    into their persistent buffers.  Same results as finetune_train_step (tests/test_vcr_gpu.py)."""
 
     def __init__(self, state, batch):
         self.state, self.model = state, state._model
         eng = self.eng = self.model._ensure(batch)
-        assert self.model.comm is None, 'graph replay is the single-rank fast path'
+        comm = self.model.comm
+        assert comm is None or getattr(comm, 'capturable', False), 'only the library RCCL communicator (dist.NativeComm) can be captured'
         finetune_train_step(state, batch)                  # eager step: every buffer and plan capacity exists afterwards
         self.image_in = torch.zeros_like(batch['image'])
         eng.plan_frozen = True
@@ -329,15 +427,16 @@ class VCRGraphStep:
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             eng.forward_device(self.image_in)
             eng.loss_and_grad_logits()
-            eng.backward()
+            _backward_reduce_update(state)
 
     def __call__(self, batch, plan=None):
         eng = self.eng
+        self.state.prepare_step()
         self.image_in.copy_(batch['image'], non_blocking=True)
         eng.set_plan(plan if plan is not None else build_vcr_plan(batch['answers'], eng.d))
         eng.labels_dev.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(batch['labels']).astype(np.int32).reshape(-1))), non_blocking=True)
         self.graph.replay()
-        self.state.apply_gradients()
+        self.state.step += 1
         return self.state
 
 

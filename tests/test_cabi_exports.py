@@ -35,7 +35,7 @@ def test_errors_are_reported_not_thrown():
 
 
 def test_product_does_not_import_oracle():
-    for root, _d, files in os.walk(os.path.join(ROOT, 'merlot_reserve_amd')):
+    for root, _d, files in [w for pkg in ('merlot_reserve_amd', 'mreserve', 'pretrain', 'finetune') for w in os.walk(os.path.join(ROOT, pkg))]:
         for f in files:
             if f.endswith('.py'):
                 src = open(os.path.join(root, f)).read()

@@ -38,7 +38,24 @@ def _worker(rank, world, port, ret):
     dev = torch.device('cuda:0')
     cfg = _cfg()
     B = 3                                   # odd: no alignment requirement on the per-rank contrastive blocks
-    tr = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=Comm())
+    class RecordingComm(Comm):              # the collective PROGRAM of a step: every call and its size, in enqueue order
+        def __init__(self):
+            super().__init__()
+            self.calls = []
+
+        def gather_embeddings(self, E, E_all):
+            self.calls.append(('all_gather', E.numel()))
+            return super().gather_embeddings(E, E_all)
+
+        def scatter_grad(self, dE_all, out):
+            self.calls.append(('reduce_scatter', out.numel()))
+            return super().scatter_grad(dE_all, out)
+
+        def allreduce_mean(self, flat):
+            self.calls.append(('all_reduce', flat.numel(), str(flat.dtype)))
+            return super().allreduce_mean(flat)
+    comm = RecordingComm()
+    tr = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=comm)
     batches = [make_batch(cfg, B, seed=100 + rank + 10 * i, device=dev) for i in range(3)]
     local, reduced = [], []
     for b in batches:
@@ -51,7 +68,7 @@ def _worker(rank, world, port, ret):
     dist.all_gather(gathered, master)
     ret[rank] = dict(local=local, reduced=reduced, replicas_equal=bool(torch.equal(gathered[0], gathered[1])),
                      finite=all(v == v and abs(v) < 1e9 for v in local + reduced), buckets=list(tr.bucket_log),
-                     step=tr.state.step)
+                     step=tr.state.step, calls=list(comm.calls), bucket_sizes=[hi - lo for _, lo, hi in tr.buckets])
     dist.destroy_process_group()
 
 
@@ -70,6 +87,16 @@ def test_two_rank_train_step_on_one_gpu(dev):
     for a, b, m in zip(r0['local'], r1['local'], r0['reduced']):
         assert abs(m - 0.5 * (a + b)) < 1e-5 * abs(m)
     assert r0['buckets'] == r1['buckets'] == EXPECTED_BUCKETS, r0['buckets']
+    # ranks that saw DIFFERENT batches enqueue the identical collective program (RCCL requires it): per step the all-gather of the
+    # embeddings, the reduce-scatter of their gradient, five gradient buckets in the documented order, then the metrics
+    assert r0['calls'] == r1['calls']
+    per_step = len(r0['calls']) // 3
+    step0 = r0['calls'][:per_step]
+    assert [c[0] for c in step0[:2]] == ['all_gather', 'reduce_scatter']
+    grads = [c for c in step0 if c[0] == 'all_reduce' and 'bfloat16' in c[2]]
+    by_key = dict(zip(['joint', 'audio', ('vision', 2), ('vision', 1), 'vision_end'], r0['bucket_sizes']))
+    assert [c[1] for c in grads] == [by_key[k] for k in EXPECTED_BUCKETS]
+    assert r0['calls'][:per_step] == r0['calls'][per_step:2 * per_step] == r0['calls'][2 * per_step:]
 
 
 def _grad_worker(rank, world, port, ret):

@@ -321,8 +321,8 @@ def test_full_size_forward_parity(dev, case):
 @pytest.mark.parametrize('case', ['base', 'large', 'base_resadapt', 'large_resadapt_shallow', 'base_resadapt24'])
 def test_full_size_backward_parity(dev, case):
     """Every parameter gradient of the FULL-width model (one record) for an injected upstream gradient dE against autograd
-    of the oracle on the host cores: same tolerance as the tiny-configuration test (|d| <= 8e-2 |g| + 1.5e-2 max|g|, cos >=
-    0.995 on every leaf that carries gradient).  base / large: the 256-row GEMM tiles, grouped weight gradients (256 x 256
+    of the oracle on the host cores: |d| <= 3e-2 |g| + 6e-3 max|g| and cos >= 0.9995 on every leaf that carries gradient = 3 x
+    what is measured (worst relative error on a significant leaf 0.6-1.2e-2, lowest cosine 0.99992; round 2 allowed 8e-2 / 0.995).  base / large: the 256-row GEMM tiles, grouped weight gradients (256 x 256
     tiles for large, nh = 16) and sequences of 241 / 640; *_resadapt: the flash backward at S = 577 / 1312."""
     import os
     from merlot_reserve_amd.config import Dims
@@ -372,7 +372,7 @@ def test_full_size_backward_parity(dev, case):
             worst = max(worst, (err / gn, name))
             wcos = min(wcos, cos)
         wabs = max(wabs, err / gmax)
-        if err > 8e-2 * gn + 1.5e-2 * gmax or (gn > 5e-2 * gmax and cos < 0.995):
+        if err > 3e-2 * gn + 6e-3 * gmax or (gn > 5e-2 * gmax and cos < 0.9995):      # 3 x the errors measured on MI355X (printed below)
             bad.append((name, err, gn, cos))
     print(f'{case} backward parity: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]}), lowest cosine {wcos:.6f}, '
           f'worst |d| / max|g| over all leaves {wabs:.3e}')

@@ -7,8 +7,9 @@
   layers' weight gradients per launch).
 * large and large-resadapt (B = 2): Trainer.capture + replays equal eager steps bit for bit.
 
-Tolerances = 3 x the errors measured on MI355X (printed by the test): forward rel-L2 <= 1.5e-2 (measured 4-5e-3), loss 2e-3
-relative (measured < 3e-4), gradients |d| <= 2.5e-2 |g| + 5e-3 max|g| and cosine >= 0.999 (measured worst 6-8e-3, cos > 0.9999).
+Tolerances = 2-3 x the errors measured on MI355X (printed by the test): forward rel-L2 <= 2e-2 (measured 9.5e-3 with the jittered
+LayerNorm parameters of this test), loss 2e-3 relative (measured 3e-6), gradients |d| <= 2.5e-2 |g| + 5e-3 max|g| and cosine >= 0.999
+(measured: worst 9.5e-3 on a significant leaf, |d| <= 8.8e-3 max|g| on every leaf, lowest cosine 0.99996).
 """
 import os
 
@@ -70,7 +71,7 @@ def test_base_b4_trainer_step_against_oracle(dev):
     for k, k2, _ in SECTIONS:
         e = relerr(outs[k][k2], preds[k][k2])
         worst = max(worst, e)
-        assert e <= 1.5e-2, f'B = 4 forward {k}/{k2}: rel err {e:.3e}'
+        assert e <= 2e-2, f'B = 4 forward {k}/{k2}: rel err {e:.3e}'
     assert abs(li['loss'] - float(loss)) <= 2e-3 * abs(float(loss)), (li['loss'], float(loss))
     print(f'base B=4 forward: worst rel-L2 {worst:.3e}; loss {li["loss"]:.5f} vs oracle {float(loss):.5f}')
 

@@ -201,3 +201,53 @@ def test_vcr_full_size_forward_backward(dev, model_name):
             bad.append((name, err, gn, cos))
     print(f'VCR {model_name}-size parity: logits rel err {e:.2e}, {len(leaves)} gradient leaves checked')
     assert not bad, bad[:10]
+
+
+def test_captured_step_with_the_rccl_communicator(dev):
+    """The multi-GPU VCR step -- four gradient buckets (nan_to_num -> all-reduce(mean) -> optimizer on the range) overlapped with the
+    vision tower's backward, finetune/optimization.py:106-191 -- captured with its collectives into ONE hipGraph through the library's
+    RCCL communicator (one rank: RCCL refuses two ranks on one device).  Same parameters as the plain single-rank step, bit for bit
+    (a one-rank mean is the identity), same bucket order eager and captured."""
+    from merlot_reserve_amd.dist import NativeComm
+    F, cfg, model_a, batch, params = setup(dev, seed=6)
+    _F, _c, model_b, _b, _p = setup(dev, seed=6)
+    cfg['model']['vit_num_layers'] = 3
+    comm = NativeComm()
+    model_b.comm = comm
+    b2 = F.make_vcr_batch(cfg, 2, seed=12, device=dev)
+    sa, _ = F.construct_finetuning_train_state(cfg['optimizer'], model_a, params)
+    sb, _ = F.construct_finetuning_train_state(cfg['optimizer'], model_b, params)
+    F.finetune_train_step(sa, batch)
+    step = F.VCRGraphStep(sb, batch)                      # eager step with the communicator, then the capture
+    eager_order = list(model_b.engine.bucket_log)
+    for b in (b2, batch, b2):
+        F.finetune_train_step(sa, b)
+        step(b)
+    torch.cuda.synchronize()
+    assert sa.step == sb.step == 4
+    assert len(eager_order) == len(model_b.engine.gradient_buckets()[0]) >= 3 and eager_order[0] == 'joint' and eager_order[-1] == 'vision_end'
+    assert model_a.engine.bucket_log == eager_order
+    pa, pb = model_a.params_store, model_b.params_store
+    assert torch.equal(pa.master, pb.master) and torch.equal(pa.nu, pb.nu) and torch.equal(pa.mu, pb.mu)
+    assert model_a.engine.loss_info() == model_b.engine.loss_info()
+    comm.close()
+
+
+def test_scan_minibatch_sums_per_example_gradients(dev):
+    """finetune_train_step(scan_minibatch=True), finetune/optimization.py:125-146: the examples one at a time, their bf16 gradients
+    SUMMED (B x the full-batch mean gradient), the metrics averaged."""
+    F, cfg, model, batch, params = setup(dev, seed=7)
+    state, _ = F.construct_finetuning_train_state(cfg['optimizer'], model, params)
+    eng, p = model._ensure(batch), model.params_store
+    model._load({'params': params})
+    eng.forward(batch)
+    eng.loss_and_grad_logits()
+    eng.backward()
+    torch.cuda.synchronize()
+    full, full_info = p.grad.float().clone(), eng.loss_info()
+    state, info = F.finetune_train_step(state, batch, scan_minibatch=True)
+    torch.cuda.synchronize()
+    summed = p.grad.float()
+    B = batch['image'].shape[0]
+    assert state.step == 1 and abs(info['loss'] - full_info['loss']) < 2e-3 * abs(full_info['loss']) and info['is_right'] == full_info['is_right']
+    assert relerr(summed, B * full) < 3e-2
