@@ -48,6 +48,13 @@ constexpr bool EPI_SYNC = false;
 #else
 constexpr bool EPI_SYNC = true;
 #endif
+// cache policy bits of the epilogue stores (raw_buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1): experiment knobs, default 0
+#ifndef MR_G3_AUX_C
+#define MR_G3_AUX_C 0
+#endif
+#ifndef MR_G3_AUX_C2
+#define MR_G3_AUX_C2 0
+#endif
 #ifdef MR_G3_PH4
 constexpr bool PH4 = true;
 #else
@@ -407,14 +414,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
             }
             // Stores widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 of adjacent 16-column blocks; one v_permlane16_swap per
             // dword leaves every lane with 8 contiguous columns (lane rows g = 0/2 own block 2jp, columns 0-7 / 8-15; g = 1/3 block 2jp+1)
-            auto store_pair = [&](const __amdgpu_buffer_rsrc_t& r, unsigned rowoff, bool mok, int jp, bf16x4 va, bf16x4 vb) {
+            auto store_pair = [&](const __amdgpu_buffer_rsrc_t& r, unsigned rowoff, bool mok, int jp, bf16x4 va, bf16x4 vb, auto aux_c) {
+                constexpr int AUX = decltype(aux_c)::value;
                 u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
                 const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
                 const unsigned off = (mok && col < eN) ? rowoff + (unsigned)col * 2u : OOB;
 #ifndef MR_G3_NOSTORE
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, off, 0, AUX);
 #else
                 asm volatile("" ::"v"(s0), "v"(s1), "v"(off));
 #endif
@@ -469,8 +477,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
                 }
 #pragma unroll
                 for (int jp = 0; jp < NJ / 2; ++jp) {
-                    if constexpr (MODE == 2) store_pair(rc2, rowoff, mok, jp, od[2 * jp], od[2 * jp + 1]);
-                    store_pair(rc, rowoff, mok, jp, oc[2 * jp], oc[2 * jp + 1]);
+                    if constexpr (MODE == 2) store_pair(rc2, rowoff, mok, jp, od[2 * jp], od[2 * jp + 1], std::integral_constant<int, MR_G3_AUX_C2>{});
+                    store_pair(rc, rowoff, mok, jp, oc[2 * jp], oc[2 * jp + 1], std::integral_constant<int, MR_G3_AUX_C>{});
                 }
                 if (NJ & 1) {                                          // BN = 192: the odd block keeps 8-byte stores
                     const int col = wcol0 + (NJ - 1) * 16 + g * 4;
@@ -698,7 +706,9 @@ bool mr_gemm3_eligible(const mr_gemm_args* a) {
     // enough tiles to fill the chip (short-K problems with few tiles go to the split-K path of the one-barrier kernel)
     const int64_t tm = (a->M + 255) / 256;
     if (tm * ((a->N + 191) / 192) > 64 * 256) return false;     // <= 64 items per workgroup (the kernel keeps them one per lane)
-    if (!forced && tm * ((a->N + 255) / 256) < 128) return false;
+    static int min_tiles = -1;
+    if (min_tiles < 0) { const char* e = getenv("MR_G3_MIN_TILES"); min_tiles = e ? atoi(e) : 128; }
+    if (!forced && tm * ((a->N + 255) / 256) < min_tiles) return false;
     return true;
 }
 

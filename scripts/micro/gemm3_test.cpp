@@ -325,6 +325,15 @@ int main(int argc, char** argv) {
         }
         mr_set_option("gemm3", 1);
     }
+    if (!strcmp(what, "quick")) {
+        const Case shapes[] = {{15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 3072, 768, 4, "fc1 dgrad aux+colsum"}, {15424, 3072, 768, 5, "fc1 plain"},
+                               {15424, 768, 3072, 3, "fc2 fwd residual"}, {15424, 2304, 768, 1, "qkv fwd bias+rot"}, {15424, 768, 768, 3, "proj fwd residual"}};
+        for (const Case& c : shapes) {
+            double t[4];
+            time_variants(c, c.mode == 4, reps * 10.0, t);
+            printf("quick %-24s g3/256 %7.1f us   g3/192 %7.1f us\n", c.name, t[1], t[2]);
+        }
+    }
     if (!strcmp(what, "stamps")) {       // needs the MR_G3_STAMPS build of the library
         const Case shapes[] = {{15424, 3072, 768, 5, "fc1 plain"}, {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 768, 3072, 3, "fc2 fwd residual"}, {8192, 8192, 8192, 5, "8192^3"}};
         const int widths[] = {256, 192};
