@@ -55,6 +55,10 @@ constexpr bool EPI_SYNC = true;
 #ifndef MR_G3_AUX_C2
 #define MR_G3_AUX_C2 0
 #endif
+#ifndef MR_G3_NA0
+#define MR_G3_NA0 4
+#endif
+constexpr int NA0 = MR_G3_NA0;        // A pieces (of a wave's four per k-tile) issued in phase 0
 #ifdef MR_G3_PH4
 constexpr bool PH4 = true;
 #else
@@ -119,23 +123,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     bool va = true, vb = true, issued = false;
     unsigned abase = (unsigned)item_m0(0) * lda2, bbase = (unsigned)item_n0(0) * ldb2;
     // the issue slots of a k-tile: A rows 0-127, A rows 128-255 (+ advance), B rows 0-127, B rows 128.. (+ advance)
-#define G3_ISSUE_A_LO()                                                                                                 \
+#define G3_ISSUE_A_PIECE(ar_, off_)                                                                                     \
     do {                                                                                                                \
-        issued = va;                                                                                                    \
-        if (va) {                                                                                                       \
-            char* st_ = smem + ista * STAGE_A + wave * 2048;                                                            \
-            const unsigned sa = (unsigned)ika * 128u;                                                                   \
-            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, abase + ar0, sa, 0, 0);                                               \
-            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, abase + ar1, sa, 0, 0);                                        \
-        }                                                                                                               \
+        if (va) MR_DMA(ra, MR_LDS_PTR(void, smem + ista * STAGE_A + (off_) + wave * 2048), 16, abase + (ar_), (unsigned)ika * 128u, 0, 0); \
     } while (0)
-#define G3_ISSUE_A_HI()                                                                                                 \
+#define G3_ADVANCE_A()                                                                                                  \
     do {                                                                                                                \
         if (va) {                                                                                                       \
-            char* st_ = smem + ista * STAGE_A + 16384 + wave * 2048;                                                    \
-            const unsigned sa = (unsigned)ika * 128u;                                                                   \
-            MR_DMA(ra, MR_LDS_PTR(void, st_), 16, abase + ar2, sa, 0, 0);                                               \
-            MR_DMA(ra, MR_LDS_PTR(void, st_ + 1024), 16, abase + ar3, sa, 0, 0);                                        \
             ista = (ista == NSTAGE_A - 1) ? 0 : ista + 1;                                                               \
             if (++ika == nkt) {                                                                                         \
                 ika = 0;                                                                                                \
@@ -144,6 +138,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
                 abase = (unsigned)m_ * lda2;                                                                            \
             }                                                                                                           \
         }                                                                                                               \
+    } while (0)
+    // the wave's four A pieces of a k-tile (rows 0-127: two, rows 128-255: two); the first NA0 are issued in phase 0, the rest lead
+    // phase 1's B pieces, so that the two phases' issue work (LDS reads + DMA) is balanced: 16 + NA0 against 8 + (8 - NA0) instructions
+#define G3_ISSUE_A_LO()                                                                                                 \
+    do {                                                                                                                \
+        issued = va;                                                                                                    \
+        G3_ISSUE_A_PIECE(ar0, 0);                                                                                       \
+        G3_ISSUE_A_PIECE(ar1, 1024);                                                                                    \
+    } while (0)
+#define G3_ISSUE_A_HI()                                                                                                 \
+    do {                                                                                                                \
+        G3_ISSUE_A_PIECE(ar2, 16384);                                                                                   \
+        G3_ISSUE_A_PIECE(ar3, 16384 + 1024);                                                                            \
+        G3_ADVANCE_A();                                                                                                 \
     } while (0)
 #define G3_ISSUE_B_LO()                                                                                                 \
     do {                                                                                                                \
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
                 read_a(0);
                 __builtin_amdgcn_sched_barrier(0);
                 G3_ISSUE_A_LO();
-                G3_ISSUE_A_HI();
+                if constexpr (NA0 >= 3) G3_ISSUE_A_PIECE(ar2, 16384);
+                if constexpr (NA0 >= 4) { G3_ISSUE_A_PIECE(ar3, 16384 + 1024); G3_ADVANCE_A(); }
                 G3_LGKM(8);
                 G3_BARRIER();
                 G3_LGKM(0);
@@ -296,6 +305,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
                 // ---------------- phase 1: A1 x B.  The A reads are retired ahead of the barrier (the next phase 0 restages A) ----------------
                 read_a(1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NA0 < 3) G3_ISSUE_A_PIECE(ar2, 16384);
+                if constexpr (NA0 < 4) { G3_ISSUE_A_PIECE(ar3, 16384 + 1024); G3_ADVANCE_A(); }
                 G3_ISSUE_B_LO();
                 G3_ISSUE_B_HI();
                 G3_LGKM(0);
