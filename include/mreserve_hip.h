@@ -49,6 +49,9 @@ const char* mr_last_error(void);
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
  *   "gemm3"         1 = default: NT problems with enough tiles run on the ping-pong kernel (gemm3.hip) | 0 = off | 256 / 192 = on
  *                   for EVERY NT problem it can take, with that tile width (tests, A/B)
+ *   "gemm3_phases"  0 = choose per problem (default) | 1 | 2 : barrier phases per k-tile of the ping-pong kernel (tests, A/B)
+ *   "gemm4"         -1 = default (on) | 0 | 1 : the one-wave-per-SIMD kernel (gemm4.hip) for the bias / residual / plain problems
+ *                   "gemm3" admits
  * Returns MR_EINVAL for an unknown name. */
 int mr_set_option(const char* name, int value);
 

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'libmreserve_hip.so')
 # (pretrain/optimization.py:36-51), the oracle evaluates (1 - b) * g + b * m without fused multiply-adds.
 EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'layernorm.hip': ['-fno-slp-vectorize'], 'rowops.hip': ['-fno-slp-vectorize'],
                'adam.hip': ['-fno-slp-vectorize', '-ffp-contract=off']}
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
 
 
 def _needs_build():
@@ -45,7 +45,8 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
+    # -z defs: an undefined kernel stub (a template the host pass silently failed to emit) fails the build instead of the first launch
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
     if verbose:
         print(f'built {LIB}', file=sys.stderr)

@@ -10,7 +10,13 @@
 // partner issues LDS reads and DMA: the matrix pipe never waits for fragment reads of its own wave, which is what bounds
 // the one-barrier-per-k-tile kernel of gemm256.hip (k-loop decomposition).
 //
-// Per k-tile and wave TWO phases: phase 0 reads B (8 | 6 ds_read_b128) + A0 (8) and multiplies A0 x B (32 | 24 MFMAs),
+// Schedules (template parameter PH, chosen per problem by mr_gemm3_launch):
+// PH = 1, the default: ONE phase per k-tile and wave.  Memory section: B (8 | 6 ds_read_b128) + A0 (8) + 8 | 6 DMA pieces; MFMA
+// section: A0 x B row block by row block, each block's A1 fragments requested into the registers its last A0 MFMA has just read
+// (fragment registers stay at 64), then A1 x B: 64 | 48 MFMAs between two barriers.  The groups split the operands: group 0 issues
+// every B piece (k-tile t+1, waited for at the END of its MFMA section: both groups read it after the closing barrier), group 1
+// every A piece (k-tile t+2, counted wait in its next memory section).
+// PH = 2: per k-tile and wave TWO phases: phase 0 reads B (8 | 6 ds_read_b128) + A0 (8) and multiplies A0 x B (32 | 24 MFMAs),
 // phase 1 reads A1 (8) and multiplies A1 x B; A0 / A1 = the wave's two 64-row halves.  (-DMR_G3_PH4: four phases of 16 | 8
 // MFMAs, quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0): twice the barriers per MFMA.)
 // Operand rings, filled by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, zero fill beyond the extents):
@@ -67,7 +73,11 @@ constexpr bool PH4 = false;
 
 // MODE (the epilogue, fixed per launch: one problem per launch):
 //   0: bias | 1: bias + "rotary" scales | 2: bias + GELU, gelu' copy to c2 | 3: + residual | 4: x aux (+ column sums)
-template <int BN, int MODE>
+// PH = phases per k-tile.  2: [B + A0 reads | 4 A pieces] [32 MFMAs] / [A1 reads | 4 B pieces] [32 MFMAs], both groups issue both operands.
+// 1: ONE phase of 64 | 48 MFMAs -- half the barriers per MFMA: the memory section reads B + A0 and issues 8 pieces, the A1 fragments
+// replace the A0 fragments in place INSIDE the MFMA section (two ds_read_b128 behind each row block's last A0 MFMA, 24+ MFMAs ahead
+// of their use), and the groups split the operands: group 0 issues every B piece (one k-tile ahead), group 1 every A piece (two ahead).
+template <int BN, int MODE, int PH>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     using GEO = Geo3<BN>;
     constexpr int WCOLS = GEO::WCOLS, NJ = GEO::NJ, JB1 = GEO::JB1;
@@ -118,6 +128,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     const unsigned br0 = rel(wave * 2, ldb2), br1 = rel(wave * 2 + 1, ldb2);
     const unsigned br2 = rel(NBP_HI == 2 ? 16 + wave * 2 : 16 + wave, ldb2), br3 = rel(16 + wave * 2 + 1, ldb2);
 
+    // PH == 1: the wave's 8 (6: B of a 192-wide tile) pieces of ITS operand -- group 0: B, group 1: A
+    constexpr int PB1 = (BN == 256) ? 8 : 6;
+    unsigned po[8];
+    if constexpr (PH == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) po[j] = (wr == 0) ? rel((wave & 3) * PB1 + (j < PB1 ? j : 0), ldb2) : rel((wave & 3) * 8 + j, lda2);
+    }
     // ---- issue cursors (one per operand), two k-tiles ahead of the compute cursor, across item boundaries ----
     int qa = 0, ika = 0, ista = 0, qb = 0, ikb = 0, istb = 0;
     bool va = true, vb = true, issued = false;
@@ -194,10 +211,42 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
 
+    // PH == 1: all 8 A pieces of the A cursor's k-tile (group 1) / all PB1 B pieces of the B cursor's k-tile (group 0)
+#define G3_ISSUE_A8()                                                                                                   \
+    do {                                                                                                                \
+        issued = va;                                                                                                    \
+        if (va) {                                                                                                       \
+            char* st_ = smem + ista * STAGE_A + (wave & 3) * 8192;                                                      \
+            const unsigned sa = (unsigned)ika * 128u;                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) MR_DMA(ra, MR_LDS_PTR(void, st_ + j_ * 1024), 16, abase + po[j_], sa, 0, 0); \
+        }                                                                                                               \
+        G3_ADVANCE_A();                                                                                                 \
+    } while (0)
+#define G3_ISSUE_B8()                                                                                                   \
+    do {                                                                                                                \
+        issued = vb;                                                                                                    \
+        if (vb) {                                                                                                       \
+            char* sb_ = smem + OFF_B + istb * STAGE_B + (wave & 3) * (PB1 * 1024);                                      \
+            const unsigned sb = (unsigned)ikb * 128u;                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < PB1; ++j_) MR_DMA(rb, MR_LDS_PTR(void, sb_ + j_ * 1024), 16, bbase + po[j_], sb, 0, 0); \
+            istb = (istb == NSTAGE_B - 1) ? 0 : istb + 1;                                                               \
+            if (++ikb == nkt) {                                                                                         \
+                ikb = 0;                                                                                                \
+                vb = item_m0(++qb) >= 0;                                                                                \
+                bbase = (unsigned)item_n0(qb) * ldb2;                                                                   \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+    if constexpr (PH == 1) {
+        // prologue: group 1 issues A of k-tiles 0 and 1 (k-tile 0 landed when only the second one's pieces are in flight), group 0 B of k-tile 0
+        if (wr == 1) { G3_ISSUE_A8(); G3_ISSUE_A8(); if (issued) wait_vmcnt<8>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else { G3_ISSUE_B8(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    } else {
     // prologue: k-tiles 0 and 1 of the sequence; k-tile 0 has landed when all but the second one's pieces have
     G3_ISSUE_A_LO(); G3_ISSUE_A_HI(); G3_ISSUE_B_LO(); G3_ISSUE_B_HI();
     G3_ISSUE_A_LO(); G3_ISSUE_A_HI(); G3_ISSUE_B_LO(); G3_ISSUE_B_HI();
     G3_RING_WAIT();
+    }
     G3_BARRIER();
     if (wr == 1) G3_BARRIER();          // group 1 runs one barrier behind group 0 from here on
 
@@ -288,7 +337,51 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
                 if (FIRST && issued && have_stores) wait_vmcnt<WAITN + NST>();
                 else G3_RING_WAIT();
             };
-            if constexpr (!PH4) {
+            if constexpr (PH == 1) {
+                // ---------------- memory section: B + A0 fragments, this group's 8 pieces ----------------
+                read_b(0, NJ);
+                __builtin_amdgcn_sched_barrier(0);      // B before A: the counted wait below relies on the issue order
+                read_a(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (wr == 0) {
+                    G3_ISSUE_B8();                       // k-tile t+1 into the stage k-tile t-1 was read from (its reads were retired ahead of a barrier)
+                    G3_LGKM(8);
+                } else {
+                    G3_ISSUE_A8();                       // k-tile t+2
+                    G3_LGKM(8);
+                    // A of k-tile t+1 (issued one k-tile ago) has landed behind the coming barrier: group 0 reads it right after it
+                    if (FIRST && issued && have_stores) wait_vmcnt<8 + NST>();
+                    else if (issued) wait_vmcnt<8>();
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                G3_BARRIER();
+                G3_LGKM(0);
+                // ---------------- MFMA section: A0 x B row block by row block, each block's A1 fragments requested into the registers
+                // its last A0 MFMA has just read; then A1 x B ----------------
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) a[i][kk] = frag<false, 256, 64>(As, wr * 128 + 64 + i * 16, kk, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[4 + i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // B of k-tile t+1 has landed behind the closing barrier
+                G3_BARRIER();
+            } else if constexpr (!PH4) {
                 // ---------------- phase 0: A0 x B.  The B reads are retired AHEAD of the barrier (phase 1 restages B) ----------------
                 read_b(0, NJ);
                 __builtin_amdgcn_sched_barrier(0);      // B before A: the counted wait below relies on the issue order
@@ -357,166 +450,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
         // its epilogue for group 0's, which restores the one-barrier offset); without, they run one after the other.
         if (EPI_SYNC && wr == 0) G3_BARRIER();
         {
-            const mr_gemm_args& pc = ga.p[0];
-            const int eM = (int)pc.M, eN = (int)pc.N;
-            const int e_ldc = (int)pc.ldc;
-            const __bf16* const pre_src = static_cast<const __bf16*>(MODE == 3 ? pc.residual : pc.aux);
-            const int64_t pre_ld = MODE == 3 ? pc.ldr : pc.ldaux;
-            const float* const e_rot = pc.rot_tab;
-            const int e_rot_rows = (int)pc.rot_rows, e_rot_cols = (int)pc.rot_cols;
-            const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
-            const void* const dummy = pc.A;
-            float* const e_cs = static_cast<float*>(pc.colsum);
-            const int64_t e_ldcs = pc.ldcs;
-            auto out_row = [&](int gm) -> int { return e_grp > 0 ? (gm / e_grp) * e_gstride + e_goff + gm % e_grp : gm; };
             const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
-            // output descriptors: every store is issued by every lane; rows >= M / columns >= N get an out-of-range offset
-            const unsigned c_bytes = (unsigned)(((int64_t)out_row(eM - 1) * e_ldc + eN) * 2);
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pc.C, 0, (int)c_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(MODE == 2 ? pc.c2 : pc.C, 0, (int)c_bytes, 0x00020000);
-
-            if (item_m0(qc + 1) >= 0) fetch_bias(item_n0(qc + 1));
-            constexpr bool HAS_X = MODE == 3 || MODE == 4;
-            constexpr int LXD = 4;                                   // row blocks of the residual / aux tile in flight
-            constexpr int NXV = NJ / 2 + (NJ & 1);
-            u32x4 lx[HAS_X ? LXD : 1][HAS_X ? NXV : 1];
-            auto lx_fetch = [&](int i, u32x4 (&dst)[HAS_X ? NXV : 1]) {
-                if constexpr (HAS_X) {
-                    const int gm = wrow0 + i * 16 + li;
-                    const __bf16* rowp = pre_src + (int64_t)out_row(gm) * pre_ld;
-#pragma unroll
-                    for (int jp = 0; jp < NJ / 2; ++jp) {       // 16 bytes per lane in the layout of the widened stores
-                        const int gn = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
-                        dst[jp] = *reinterpret_cast<const u32x4*>((gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy);
-                    }
-                    if (NJ & 1) {
-                        const int gn = wcol0 + (NJ - 1) * 16 + g * 4;
-                        const u32x2 v = *reinterpret_cast<const u32x2*>((gm < eM && gn < eN) ? (const void*)(rowp + gn) : dummy);
-                        dst[NJ / 2] = u32x4{v[0], v[1], 0u, 0u};
-                    }
-                }
-            };
-            if constexpr (HAS_X) {
-#pragma unroll
-                for (int i = 0; i < LXD; ++i) lx_fetch(i, lx[i]);
-            }
-            constexpr bool ROT = MODE == 1;
-            f32x4 rotv[ROT ? 2 : 1][ROT ? NJ : 1];
-            auto rot_fetch = [&](int i, f32x4 (&dst)[ROT ? NJ : 1]) {
-                if constexpr (ROT) {
-                    const int gm = wrow0 + i * 16 + li;
-                    const int rr = (gm >= eM) ? 0 : (e_rot_rows >= eM) ? gm : gm % e_rot_rows;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int gn0 = wcol0 + j * 16 + g * 4;      // the lane's 4 columns lie inside one head's first or second 32 dims
-                        const bool on = (gn0 & 63) < 32 && gn0 < e_rot_cols;
-                        const f32x4 tv = *reinterpret_cast<const f32x4*>(on ? (const void*)(e_rot + (int64_t)rr * 32 + (gn0 & 63)) : (const void*)e_rot);
-                        dst[j] = on ? tv : f32x4{1.f, 1.f, 1.f, 1.f};
-                    }
-                }
-            };
-            if constexpr (ROT) rot_fetch(0, rotv[0]);
-            constexpr bool CS = MODE == 4;
-            const bool f_cs = CS && e_cs != nullptr;
-            f32x4 cs[CS ? NJ : 1];
-            if constexpr (CS) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            // Stores widened to 16 B: lanes l and l+16 hold columns 4g..4g+3 of adjacent 16-column blocks; one v_permlane16_swap per
-            // dword leaves every lane with 8 contiguous columns (lane rows g = 0/2 own block 2jp, columns 0-7 / 8-15; g = 1/3 block 2jp+1)
-            auto store_pair = [&](const __amdgpu_buffer_rsrc_t& r, unsigned rowoff, bool mok, int jp, bf16x4 va, bf16x4 vb, auto aux_c) {
-                constexpr int AUX = decltype(aux_c)::value;
-                u32x2 ua = __builtin_bit_cast(u32x2, va), ub = __builtin_bit_cast(u32x2, vb);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                const int col = wcol0 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
-                const unsigned off = (mok && col < eN) ? rowoff + (unsigned)col * 2u : OOB;
-#ifndef MR_G3_NOSTORE
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, off, 0, AUX);
-#else
-                asm volatile("" ::"v"(s0), "v"(s1), "v"(off));
-#endif
-            };
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gm = wrow0 + i * 16 + li;
-                const bool mok = gm < eM;
-                const unsigned rowoff = (unsigned)out_row(gm) * (unsigned)e_ldc * 2u;
-                bf16x4 oc[NJ], od[NJ], xs[NJ];
-                if constexpr (ROT) { if (i < 7) rot_fetch(i + 1, rotv[(i + 1) & 1]); }
-                if constexpr (HAS_X) {       // undo the 16-byte load layout
-#pragma unroll
-                    for (int jp = 0; jp < NJ / 2; ++jp) {
-                        const u32x4 v4 = lx[i % LXD][jp];
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(v4[0], v4[2], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(v4[1], v4[3], false, false);
-                        xs[2 * jp] = __builtin_bit_cast(bf16x4, u32x2{s0[0], s1[0]});
-                        xs[2 * jp + 1] = __builtin_bit_cast(bf16x4, u32x2{s0[1], s1[1]});
-                    }
-                    if (NJ & 1) xs[NJ - 1] = __builtin_bit_cast(bf16x4, u32x2{lx[i % LXD][NJ / 2][0], lx[i % LXD][NJ / 2][1]});
-                    if (i + LXD < 8) lx_fetch(i + LXD, lx[i % LXD]);
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x4 v = acc[i][j];
-                    if constexpr (ROT) v *= rotv[i & 1][j];
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                    od[j] = o;
-                    if constexpr (MODE == 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float sg = sigmoid1702(v[r]);
-                            o[r] = (__bf16)(v[r] * sg);
-                            od[j][r] = (__bf16)(sg + 1.702f * v[r] * sg * (1.0f - sg));
-                        }
-                    }
-                    if constexpr (HAS_X) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            o[r] = (MODE == 3) ? (__bf16)((float)o[r] + (float)xs[j][r]) : (__bf16)((float)o[r] * (float)xs[j][r]);
-                    }
-                    oc[j] = o;
-                    if constexpr (CS) {
-                        if (f_cs && mok) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cs[j][r] += (float)o[r];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int jp = 0; jp < NJ / 2; ++jp) {
-                    if constexpr (MODE == 2) store_pair(rc2, rowoff, mok, jp, od[2 * jp], od[2 * jp + 1], std::integral_constant<int, MR_G3_AUX_C2>{});
-                    store_pair(rc, rowoff, mok, jp, oc[2 * jp], oc[2 * jp + 1], std::integral_constant<int, MR_G3_AUX_C>{});
-                }
-                if (NJ & 1) {                                          // BN = 192: the odd block keeps 8-byte stores
-                    const int col = wcol0 + (NJ - 1) * 16 + g * 4;
-                    const unsigned off = (mok && col < eN) ? rowoff + (unsigned)col * 2u : OOB;
-#ifndef MR_G3_NOSTORE
-                    if constexpr (MODE == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, od[NJ - 1]), rc2, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oc[NJ - 1]), rc, off, 0, 0);
-#else
-                    asm volatile("" ::"v"(od[NJ - 1]), "v"(oc[NJ - 1]), "v"(off));
-#endif
-                }
-                if constexpr (CS) {
-                    // column sums of the stored tile per 64-row band (mr_gemm_args.colsum: partial row 4 * (m / 256) + (m % 256) / 64):
-                    // 4 row blocks summed in registers, the 16 rows of a block across the DPP row
-                    if ((i & 3) == 3 && f_cs) {
-                        float* const prow = e_cs + (int64_t)((cm0 / 256) * 4 + wr * 2 + (i >> 2)) * e_ldcs;
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) cs[j][r] = row16_sum(cs[j][r]);
-                            const int col = wcol0 + j * 16 + g * 4;
-                            if (li == 0 && col < eN) *reinterpret_cast<f32x4*>(prow + col) = cs[j];
-                            cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    }
-                }
-            }
+#define MR_EPI_ROW_FENCE() do {} while (0)
+#include "gemm3_epilogue.inc"
+#undef MR_EPI_ROW_FENCE
 #ifndef MR_G3_NOSTORE
             have_stores = true;
 #endif
@@ -691,6 +628,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
 
 constexpr int64_t NUM_CU3 = 256;    // MI355X
 extern int g_mr_opt_group_streamk, g_mr_opt_group_headtail, g_mr_opt_group_tile_n;
+extern int g_mr_opt_gemm4;           // mr_set_option("gemm4"): -1 = default (MR_GEMM4, or on) | 0 | 1 : the one-wave-per-SIMD kernel for gemm3's bias / residual / plain problems
+bool mr_gemm4_takes(const mr_gemm_args* a);
+int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int64_t gsz, hipStream_t s);
+extern int g_mr_opt_gemm3_ph;        // mr_set_option("gemm3_phases"): 0 = default (MR_G3_PH or 1) | 1 | 2
 extern int g_mr_opt_gemm3;           // mr_set_option("gemm3"): 1 = on (default), 0 = off, 256 / 192 = on with that tile width forced
 
 // The ping-pong kernel takes: NT operands (A [M,K], B [N,K], K % 64 == 0), bf16 output, at least one full round of 256-row tiles'
@@ -760,16 +701,34 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     ga.tile_start[0] = 0;
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
     ga.p[0] = *a;
+    {   // the one-wave-per-SIMD kernel (gemm4.hip) shares this tile plan
+        static int g4_env = -1;
+        if (g4_env < 0) { const char* e = getenv("MR_GEMM4"); g4_env = e ? atoi(e) : 1; }
+        const int g4 = g_mr_opt_gemm4 >= 0 ? g_mr_opt_gemm4 : g4_env;
+        if (g4 && mr_gemm4_takes(a)) return mr_gemm4_launch(a, bn, ga, gsz, s);
+    }
     dim3 grid((unsigned)gsz), block(512);
     int mode = 0;
     if (a->c2) mode = 2;
     else if (a->rot_tab) mode = 1;
     else if (a->residual) mode = 3;
     else if (a->aux) mode = 4;
+    static int ph_env = -1;
+    if (ph_env < 0) { const char* e = getenv("MR_G3_PH"); ph_env = e ? atoi(e) : 0; }
+    // one phase per k-tile (half the barriers: 2-7 % faster at K <= 4096) except where it measured slower: the 256-wide aux / column-sum
+    // epilogue (its prefetch registers + the one-phase schedule's spill: 94 vs 86 us on the fc1 dgrad) and very long k-loops, where B
+    // requested one phase ahead by ONE group lands later than the two-phase schedule's (8192^3: 745 vs 729 us)
+    const int ph_auto = ((mode == 4 && bn == 256) || a->K >= 8192) ? 2 : 1;
+    const int ph = g_mr_opt_gemm3_ph ? g_mr_opt_gemm3_ph : ph_env ? ph_env : ph_auto;
 #define G3_LAUNCH(MODE)                                                                               \
     do {                                                                                              \
-        if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE>), grid, block, 0, s, ga);      \
-        else hipLaunchKernelGGL((g3::gemm3_kernel<192, MODE>), grid, block, 0, s, ga);                \
+        if (ph == 1) {                                                                                \
+            if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE, 1>), grid, block, 0, s, ga);   \
+            else hipLaunchKernelGGL((g3::gemm3_kernel<192, MODE, 1>), grid, block, 0, s, ga);             \
+        } else {                                                                                      \
+            if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE, 2>), grid, block, 0, s, ga);   \
+            else hipLaunchKernelGGL((g3::gemm3_kernel<192, MODE, 2>), grid, block, 0, s, ga);             \
+        }                                                                                             \
     } while (0)
     switch (mode) {
         case 0: G3_LAUNCH(0); break;

@@ -82,6 +82,8 @@ static bf16_t *dA[3], *dB, *dC[3], *dC2[3], *dX, *dBias, *dRefC, *dRefC2;
 static float *dRot, *dCs, *dWs;
 static int64_t capA, capB, capC;
 
+static bool g_cmp_ph = false;    // time_variants: [1]/[2] = one-phase, [0]/[3] = two-phase ping-pong (default: [1]/[2] = gemm4, [0]/[3] = gemm3)
+static bool g_cmp_old = false;   // time_variants: compare with the one-barrier kernel (NT, NN) instead of the 2-phase ping-pong schedule
 static bool g_nn = false;        // time the [K, N] (flax forward) operand layout instead: the one-barrier kernel's NN variants
 static void setup_args(mr_gemm_args* g, const Case& c, int set, bool colsum) {
     memset(g, 0, sizeof(*g));
@@ -101,15 +103,16 @@ static void setup_args(mr_gemm_args* g, const Case& c, int set, bool colsum) {
 
 // Sustained, interleaved timing: the variants take turns (one launch each, round robin) for ~`budget_ms` of GPU time after a
 // warm-up of the same length, so that they share the clock the chip settles at under load (a cold 3-ms burst runs ~15 % faster
-// than the same kernel inside a training step).  variants: 0 = one-barrier kernel NT, 1 = ping-pong 256, 2 = ping-pong 192,
-// 3 = one-barrier kernel NN (flax forward layout).
+// than the same kernel inside a training step).  variants: 1 = ping-pong 256, 2 = ping-pong 192 (one phase per k-tile), and
+// 0 / 3 = the two-phase schedule at 256 / 192 -- or, with G3_CMP_OLD=1, the one-barrier kernel NT / NN (flax forward layout).
 static void time_variants(const Case& c, bool colsum, double budget_ms, double out_us[4]) {
     mr_gemm_args g;
     hipEvent_t e0[4], e1[4];
     for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
     auto launch = [&](int v, int set) {
-        g_nn = v == 3;
-        mr_set_option("gemm3", v == 1 ? 256 : v == 2 ? 192 : 0);
+        if (g_cmp_old) { g_nn = v == 3; mr_set_option("gemm3", v == 1 ? 256 : v == 2 ? 192 : 0); }
+        else if (g_cmp_ph) { mr_set_option("gemm3", (v == 0 || v == 1) ? 256 : 192); mr_set_option("gemm3_phases", (v == 1 || v == 2) ? 1 : 2); }
+        else { mr_set_option("gemm3", (v == 0 || v == 1) ? 256 : 192); mr_set_option("gemm4", (v == 1 || v == 2) ? 1 : 0); }
         setup_args(&g, c, set, colsum);
         if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); }
     };
@@ -130,6 +133,8 @@ static void time_variants(const Case& c, bool colsum, double budget_ms, double o
     for (int v = 0; v < 4; ++v) out_us[v] = tot[v] * 1000.0 / n[v];
     g_nn = false;
     mr_set_option("gemm3", 1);
+    mr_set_option("gemm3_phases", 0);
+    mr_set_option("gemm4", -1);
 }
 
 static int check_case(const Case& c, const char* label) {
@@ -176,6 +181,8 @@ static int check_case(const Case& c, const char* label) {
 
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
+    g_cmp_old = getenv("G3_CMP_OLD") != nullptr;
+    g_cmp_ph = getenv("G3_CMP_PH") != nullptr;
     const int reps = argc > 2 ? atoi(argv[2]) : 12;
     capA = 15424LL * 4096; capB = 8192LL * 8192; capC = 15488LL * 4096;
     if (capA < 8192LL * 8192) capA = 8192LL * 8192;
@@ -200,11 +207,14 @@ int main(int argc, char** argv) {
             {1024, 256, 128, 3, "small"}, {1312, 3072, 64, 0, "one k-tile"}, {40000, 192, 128, 5, "two k-tiles, narrow"},
         };
         const int widths[] = {256, 192};
-        for (int w : widths) {
-            mr_set_option("gemm3", w);
-            char label[32]; snprintf(label, sizeof label, "g3/%d", w);
-            for (const Case& c : checks) fails += check_case(c, label);
-        }
+        for (int gen = 4; gen >= 3; --gen)
+            for (int w : widths) {
+                mr_set_option("gemm3", w);
+                mr_set_option("gemm4", gen == 4);
+                char label[32]; snprintf(label, sizeof label, "g%d/%d", gen, w);
+                for (const Case& c : checks) fails += check_case(c, label);
+            }
+        mr_set_option("gemm4", -1);
         mr_set_option("gemm3", 0);
         fails += check_case(checks[0], "old");       // the harness itself against the shipped kernel
         fails += check_case(checks[4], "old");
@@ -220,7 +230,8 @@ int main(int argc, char** argv) {
             {15424, 4096, 1024, 2, "large fc1 fwd"}, {15424, 4096, 1024, 5, "large fc1 plain"}, {15424, 1024, 4096, 3, "large fc2 fwd"}, {15424, 1024, 4096, 5, "large fc2 plain"},
             {15424, 3072, 1024, 1, "large qkv"}, {15424, 1024, 1024, 3, "large proj"}, {8192, 8192, 8192, 5, "8192^3"},
         };
-        printf("%-26s %18s | %9s %9s %9s %9s | TF/s: old NT, old NN -> best new   (sustained, interleaved)\n", "shape", "M x N x K", "old NT us", "old NN us", "g3/256 us", "g3/192 us");
+        printf("%-26s %18s | %9s %9s %9s %9s | TF/s: [0], [3] -> best new   (sustained, interleaved; [0]/[3] = %s)\n", "shape", "M x N x K", "[0] us", "[3] us", "g3/256 us", "g3/192 us",
+               g_cmp_old ? "one-barrier kernel NT / NN" : g_cmp_ph ? "two-phase ping-pong 256 / 192" : "ping-pong (gemm3) 256 / 192; g3/ columns = gemm4");
         for (const Case& c : shapes) {
             double t[4];
             time_variants(c, c.mode == 4, reps * 10.0, t);
@@ -331,7 +342,15 @@ int main(int argc, char** argv) {
         for (const Case& c : shapes) {
             double t[4];
             time_variants(c, c.mode == 4, reps * 10.0, t);
-            printf("quick %-24s g3/256 %7.1f us   g3/192 %7.1f us\n", c.name, t[1], t[2]);
+            printf("quick %-24s g3/256 %7.1f us   g3/192 %7.1f us   | [0] %7.1f us  [3] %7.1f us\n", c.name, t[1], t[2], t[0], t[3]);
+        }
+    }
+    if (!strcmp(what, "kloop")) {        // plain products only: the k-loop (and the plain epilogue) of the two generations
+        const Case shapes[] = {{8192, 8192, 8192, 5, "8192^3"}, {15424, 768, 3072, 5, "d ln2 plain"}, {15424, 3072, 768, 5, "fc1 plain"}};
+        for (const Case& c : shapes) {
+            double t[4];
+            time_variants(c, false, reps * 10.0, t);
+            printf("kloop %-16s g4/256 %7.1f us   g4/192 %7.1f us   | g3/256 %7.1f us  g3/192 %7.1f us\n", c.name, t[1], t[2], t[0], t[3]);
         }
     }
     if (!strcmp(what, "stamps")) {       // needs the MR_G3_STAMPS build of the library
