@@ -41,15 +41,14 @@ int mr_version(void);
 const char* mr_last_error(void);
 /* Tuning / diagnostic knobs (process-wide, not thread-safe against concurrent launches).  Known names:
  *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 192 | 256 : forces the output-tile width of the 256-row GEMM
- *                   | 4128 : 128-wide tiles computed by 4-wave workgroups, two per CU (experiment)
  *   "gemm_group_tile_n"  0 = choose (default) | 128 | 256 : tile width of mr_gemm_grouped's shared launch
- *   "gemm_group_streamk"  -1 = default (off) | 0 | 1 : stream-K schedule of mr_gemm_grouped (needs args[0].workspace)
- *   "gemm_group_headtail" -1 = default (off) | 0 | 1 : head / tail K split of mr_gemm_grouped when the tiles leave >= 1/5 of the CUs
- *                         idle and divide evenly over them (needs args[0].workspace for two fp32 slabs per tile)
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
  *   "gemm3"         1 = default: NT problems with enough tiles run on the ping-pong kernel (gemm3.hip) | 0 = off | 256 / 192 = on
  *                   for EVERY NT problem it can take, with that tile width (tests, A/B)
  *   "gemm3_phases"  0 = choose per problem (default) | 1 | 2 : barrier phases per k-tile of the ping-pong kernel (tests, A/B)
+ *   "gemm_cus"      0 / 256 = default: persistent GEMM grids fill all 256 CUs | 64 .. 248 (multiple of 8): the forward / dgrad kernels
+ *                   (gemm3.hip, gemm4.hip) launch that many workgroups, e.g. 240 = two CUs per XCD left to a resident RCCL kernel
+ *                   (the data-parallel trainer sets it while gradient buckets are in flight)
  *   "gemm4"         -1 = default (on) | 0 | 1 : the one-wave-per-SIMD kernel (gemm4.hip) for the bias / residual / plain problems
  *                   "gemm3" admits
  * Returns MR_EINVAL for an unknown name. */

@@ -12,11 +12,12 @@
 namespace g256 {
 
 
-template <int BN, bool TA, bool TB, int NW = 8>
-__global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) {
-    using GEO = Geo<BN, NW>;
+template <int BN, bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const G256Args ga) {
+    constexpr int NW = 8;
+    using GEO = Geo<BN>;
     constexpr int BKT = GEO::BKT, STAGE_A = GEO::STAGE_A;
-    constexpr int WCOLS = (NW == 8) ? BN / 2 : BN;       // wave tile = 64 x WCOLS: waves 4 x 2 (8 waves) or 4 x 1
+    constexpr int WCOLS = BN / 2;       // wave tile = 64 x WCOLS: waves 4 x 2
     constexpr int NJ = WCOLS / 16;                       // 16-col MFMA tiles per wave
     constexpr int BW = GEO::BW, NBP = GEO::NBP, STAGE_B = GEO::STAGE_B, OFF_B = GEO::OFF_B;
     constexpr int NSTAGE_A = GEO::NSTAGE_A, NSTAGE_B = GEO::NSTAGE_B, B_AHEAD = GEO::B_AHEAD;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: LDS-DMA bases stay scalar
-    const int wm = (NW == 8) ? wave >> 1 : wave, wn = (NW == 8) ? wave & 1 : 0;
+    const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, li = lane & 15;
 
     // PERSISTENT workgroups: block b handles work items b', b' + G, ... where b' is the XCD-aware permutation of b
@@ -38,22 +39,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     const int splits = ga.splits;
-    SkRange skr = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ga.xmode == 3) {       // head / tail split: T = nwork head workgroups, the rest take P = py tails each; W = px
-        const bool head = bperm < ga.nwork;
-        skr.ht_n = head ? 1 : ga.py;
-        skr.ht_tile0 = head ? bperm : (bperm - ga.nwork) * ga.py;
-        skr.ht_k0 = head ? 0 : ga.px;
-        skr.ht_k1 = head ? ga.px : ga.kt_per_split;
-        skr.ht_part = head ? 0 : 1;
-    }
-    if (ga.xmode == 2) {       // units = (tile, k-tile) pairs; this workgroup's range [u0, u1) (G = 256; units < 2^31 checked on the host)
-        const int64_t U = (int64_t)ga.nwork * ga.kt_per_split;
-        skr.u0 = (int)((int64_t)bperm * U / G);
-        skr.u1 = (int)((int64_t)(bperm + 1) * U / G);
-        skr.tfirst = skr.u0 / ga.kt_per_split;
-    }
-#define GET_ITEM(w) make_item<BKT, (NW == 8 ? 8 : 9)>(ga, (w), BN, bperm, skr)
+#define GET_ITEM(w) make_item<BKT, 8>(ga, (w), BN, bperm)
 
     // ---- issue cursors (one per operand): run ahead of the compute cursor, across item boundaries ----
     int iwa = bperm, ika = 0, ista = 0, iwb = bperm, ikb = 0, istb = 0;
@@ -184,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
         const int e_rot_rows = (int)pc.rot_rows, e_rot_cols = (int)pc.rot_cols;
         const int e_grp = (int)pc.out_grp, e_gstride = (int)pc.out_grp_stride, e_goff = (int)pc.out_grp_off;
         const bool do_act = (pc.act == MR_ACT_GELU1702);
-        const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16) && ci.slot < 0;
+        const bool epi_bf16 = (splits == 1) && (pc.c_dtype == MR_DT_BF16);
         const bool pre_rot = epi_bf16 && pre_src == nullptr && e_rot != nullptr && BN >= 128;   // BN = 96 never gets a rot_tab (host)
         const void* const dummy = pc.A;
         float* const e_cs = static_cast<float*>(pc.colsum);
@@ -326,15 +312,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
         if (!epi_bf16) {
             // split-K partials and fp32 outputs (contrastive logits): rare, small; direct loads / scalar stores
             const mr_gemm_args& p = ga.p[ci.pi];
-            if (ci.slot >= 0) {  // stream-K partial: raw fp32 accumulators into the workgroup's slab, tile-local [256][BN]
-                float* Wp = static_cast<float*>(ga.p[0].workspace) + (int64_t)ci.slot * (BM * BN);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = wm * 64 + i * 16 + li;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(Wp + r * BN + wn * WCOLS + j * 16 + g * 4) = acc[i][j];
-                }
-            } else if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
+            if (splits > 1) {   // raw fp32 accumulators (N % 4 == 0 checked on the host)
                 float* Wp = static_cast<float*>(p.workspace) + (int64_t)ci.split * p.M * p.N;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -600,73 +578,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm256_kernel(const G256Args ga) 
     }
 }
 
-// Stream-K second pass: one workgroup per output tile; a tile that one workgroup computed whole was stored by it and is skipped.
 template <int BN>
-__global__ __launch_bounds__(256) void streamk_fixup_kernel(const G256Args ga, int G) {
-    const int tile = blockIdx.x;
-    const int64_t nkt = ga.kt_per_split, U = (int64_t)ga.nwork * nkt;
-    const int64_t tb = (int64_t)tile * nkt, te = tb + nkt;
-    auto u0 = [&](int64_t c) { return c * U / G; };
-    int c = (int)(tb * G / U);
-    while (c > 0 && u0(c) > tb) --c;
-    while (u0(c + 1) <= tb) ++c;                               // c = the workgroup whose range holds the tile's first k-tile
-    if (u0(c) <= tb && u0(c + 1) >= te) return;                 // whole tile in one range: already stored
-    const int pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
-    const mr_gemm_args& p = ga.p[pi];
-    const int lt = tile - ga.tile_start[pi], tn = ga.tiles_n[pi];
-    const int m0 = (lt / tn) * BM, n0 = (lt % tn) * BN;
-    __bf16* C = static_cast<__bf16*>(p.C);
-    for (int e = threadIdx.x; e < BM * BN / 4; e += 256) {
-        const int r = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int cc = c; cc < G && u0(cc) < te; ++cc) {         // contributors in workgroup order
-            const int q = tile - (int)(u0(cc) / nkt);
-            const float* slab = static_cast<const float*>(ga.p[0].workspace) + (int64_t)(2 * cc + (q == 0 ? 0 : 1)) * (BM * BN);
-            sum += *reinterpret_cast<const f32x4*>(slab + r * BN + c4);
-        }
-        const int64_t m = m0 + r, n = n0 + c4;
-        if (m < p.M && n < p.N) {
-            bf16x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (__bf16)sum[k];
-            *reinterpret_cast<bf16x4*>(C + m * p.ldc + n) = o;
-        }
-    }
-}
-
-// Head / tail second pass: C tile = head slab + tail slab (fixed order), 4 workgroups per tile (64 rows each).
-template <int BN>
-__global__ __launch_bounds__(256) void headtail_fixup_kernel(const G256Args ga) {
-    const int tile = blockIdx.x >> 2, part = blockIdx.x & 3;
-    const int pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
-    const mr_gemm_args& p = ga.p[pi];
-    const int lt = tile - ga.tile_start[pi], tn = ga.tiles_n[pi];
-    const int m0 = (lt / tn) * BM, n0 = (lt % tn) * BN;
-    __bf16* C = static_cast<__bf16*>(p.C);
-    const float* s0 = static_cast<const float*>(ga.p[0].workspace) + (int64_t)(2 * tile) * (BM * BN);
-    const float* s1 = s0 + BM * BN;
-    const int64_t M = p.M, N = p.N, ldc = p.ldc;
-    for (int e = threadIdx.x; e < 64 * BN / 4; e += 256) {
-        const int r = part * 64 + e / (BN / 4), c4 = (e % (BN / 4)) * 4;
-        const f32x4 sum = *reinterpret_cast<const f32x4*>(s0 + r * BN + c4) + *reinterpret_cast<const f32x4*>(s1 + r * BN + c4);
-        const int64_t m = m0 + r, n = n0 + c4;
-        if (m < M && n < N) {
-            bf16x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (__bf16)sum[k];
-            *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
-        }
-    }
-}
-
-template <int BN, int NW = 8>
 static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
-    dim3 block(NW * 64);
+    dim3 block(512);
     const bool ta = ga.p[0].transA, tb = ga.p[0].transB;
-    if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, false, NW>), grid, block, 0, s, ga);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, true, NW>), grid, block, 0, s, ga);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, true, false, NW>), grid, block, 0, s, ga);
-    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true, NW>), grid, block, 0, s, ga);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, false>), grid, block, 0, s, ga);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<BN, false, true>), grid, block, 0, s, ga);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm256_kernel<BN, true, false>), grid, block, 0, s, ga);
+    else hipLaunchKernelGGL((gemm256_kernel<BN, true, true>), grid, block, 0, s, ga);
 }
 
 }  // namespace g256
@@ -674,8 +593,6 @@ static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
 constexpr int64_t NUM_CU = 256;    // MI355X
 extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
 extern int g_mr_opt_group_tile_n;  // mr_set_option("gemm_group_tile_n")
-extern int g_mr_opt_group_streamk; // mr_set_option("gemm_group_streamk"): -1 = environment / default (off)
-extern int g_mr_opt_group_headtail; // mr_set_option("gemm_group_headtail"): -1 = environment / default (off)
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -715,16 +632,14 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
         const int64_t t192 = tm * ((a->N + 191) / 192), c192 = ((t192 + 255) / 256) * c192_cost;
         if (can192 && c192 < best) { bn = 192; best = c192; }
     }
-    int nw = 8;                 // waves per workgroup: 4 = the two-workgroups-per-CU kernel (256 x 128 tiles, BK = 32)
     {
         const int f = g_mr_opt_tile_n ? g_mr_opt_tile_n : force_bn;
         if (f == 96 || f == 128 || (f == 256 && can256) || (f == 192 && can192)) bn = f;
-        if (f == 4128 && !a->colsum) { bn = 128; nw = 4; }
     }
     if (a->rot_tab && bn == 96) bn = 128;
     if (a->colsum && bn == 256 && can192) bn = 192;     // the column-sum accumulators beside a 256-wide tile's 128 accumulators spill (measured: +22 us)
     const int64_t tn = (a->N + bn - 1) / bn;
-    const int64_t bk = g256::bk_of(nw), full_grid = (nw == 4) ? 2 * NUM_CU : NUM_CU;
+    const int64_t bk = g256::BK, full_grid = NUM_CU;
     const int64_t nk = (a->K + bk - 1) / bk;
     int64_t splits = 1;
     const bool plain = !a->rot_tab && !a->c2 && a->act == MR_ACT_NONE && !a->residual && !a->aux && a->out_grp == 0;
@@ -775,8 +690,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     ga.tile_start[0] = 0;
     for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
     ga.p[0] = *a;
-    if (nw == 4) g256::launch<128, 4>(ga, grid, s);
-    else if (bn == 256) g256::launch<256>(ga, grid, s);
+    if (bn == 256) g256::launch<256>(ga, grid, s);
     else if (bn == 192) g256::launch<192>(ga, grid, s);
     else if (bn == 128) g256::launch<128>(ga, grid, s);
     else g256::launch<96>(ga, grid, s);
@@ -806,50 +720,7 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         can256 = can256 && list[k].N % 256 == 0;
     }
     int bn = (can256 && ((t256 + NUM_CU - 1) / NUM_CU) * c256_cost < ((t128 + NUM_CU - 1) / NUM_CU) * 100) ? 256 : 128;
-    // Stream-K (see G256Args), OPT-IN (MR_G256_STREAMK=1 / mr_set_option("gemm_group_streamk", 1)): when the tiles leave > 8 % of
-    // the CU-rounds idle, the problems share one K and the caller's workspace holds two [256][BN] fp32 slabs per workgroup.
-    // Measured on the base model's weight gradients (round 2): 315 us against 165 us for the plain one-tile-per-CU schedule.
-    // With K = 15 424 every workgroup of the plain schedule walks K in lockstep with the other tiles of its row / column, so
-    // an operand strip is fetched once per XCD; stream-K puts neighbouring workgroups at DIFFERENT k offsets of the same tile,
-    // nothing is shared, and the launch fetches 1.7 GB instead of 0.53 GB -- HBM-bound.  Kept for shapes with short K.
-    static int sk_env = -1;
-    if (sk_env < 0) { const char* e = getenv("MR_G256_STREAMK"); sk_env = e ? atoi(e) : 0; }
-    if (g_mr_opt_group_streamk >= 0) sk_env = g_mr_opt_group_streamk;
-    bool same_k = true;
-    for (int k = 1; k < count; ++k) same_k = same_k && list[k].K == list[0].K;
-    bool streamk = false;
-    if (sk_env && same_k && list[0].workspace != nullptr) {
-        const int sbn = can256 ? 256 : 128;
-        const int64_t st = can256 ? t256 : t128, nk = (list[0].K + g256::BK - 1) / g256::BK;
-        const double eff = (double)st / (double)(((st + NUM_CU - 1) / NUM_CU) * NUM_CU);
-        const int64_t need = 2 * NUM_CU * (int64_t)g256::BM * sbn * (int64_t)sizeof(float);
-        if ((eff < 0.92 || sbn != bn) && st * nk >= 8 * NUM_CU && list[0].workspace_bytes >= need) { streamk = true; bn = sbn; }
-    }
-    if (g_mr_opt_group_tile_n == 128 || (g_mr_opt_group_tile_n == 256 && can256)) {
-        if (bn != g_mr_opt_group_tile_n) streamk = false;       // a forced width (tests, A/B): the plain schedule
-        bn = g_mr_opt_group_tile_n;
-    }
-    // Head / tail split (see G256Args): a single partial round that leaves >= 1/5 of the CUs idle, tiles an exact multiple of the idle CUs
-    // OPT-IN (MR_G256_HEADTAIL=1 / mr_set_option("gemm_group_headtail", 1)).  Measured on the large model (round 2): the launch goes
-    // from 362 to 343 us with all 256 CUs busy instead of 192 -- not the 25 % the idle CUs promise, because these K = 15 424 GEMMs are
-    // bound by operand delivery (L2 fill / HBM), not by CU count -- the fix-up pass makes the short audio-tower launch 9 % slower,
-    // and the replayed step does not move (88.5 ms either way).
-    static int ht_env0 = -1;
-    if (ht_env0 < 0) { const char* e = getenv("MR_G256_HEADTAIL"); ht_env0 = e ? atoi(e) : 0; }
-    const int ht_env = g_mr_opt_group_headtail >= 0 ? g_mr_opt_group_headtail : ht_env0;
-    bool headtail = false;
-    int ht_w = 0, ht_p = 0;
-    {
-        const int64_t st = (bn == 256) ? t256 : t128, nk = (list[0].K + g256::BK - 1) / g256::BK, idle = NUM_CU - st;
-        bool out_ok = true;
-        for (int k = 0; k < count; ++k) out_ok = out_ok && list[k].c_dtype == MR_DT_BF16 && !list[k].bias && list[k].N % 4 == 0 && list[k].ldc % 4 == 0;
-        if (ht_env && !streamk && same_k && out_ok && g_mr_opt_group_tile_n == 0 && st < NUM_CU && idle * 5 >= NUM_CU && st % idle == 0 && st / idle <= 8 &&
-            list[0].workspace != nullptr && list[0].workspace_bytes >= 2 * st * (int64_t)g256::BM * bn * (int64_t)sizeof(float)) {
-            ht_p = (int)(st / idle);
-            ht_w = (int)((nk * ht_p + ht_p) / (ht_p + 1));           // heads W, tails P (nk - W): within one k-tile of each other
-            headtail = nk >= 16 * (ht_p + 1) && ht_w < nk;
-        }
-    }
+    if (g_mr_opt_group_tile_n == 128 || (g_mr_opt_group_tile_n == 256 && can256)) bn = g_mr_opt_group_tile_n;       // a forced width (tests, A/B)
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     int64_t tiles = 0;
@@ -866,30 +737,6 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
         if (nk > nk_max) nk_max = nk;
     }
     ga.count = count; ga.nwork = (int)tiles; ga.splits = 1; ga.kt_per_split = (int)nk_max;
-    if (streamk) {
-        ga.xmode = 2;
-        dim3 grid((unsigned)NUM_CU);
-        if (bn == 256) {
-            g256::launch<256>(ga, grid, s);
-            hipLaunchKernelGGL(g256::streamk_fixup_kernel<256>, dim3((unsigned)tiles), dim3(256), 0, s, ga, (int)NUM_CU);
-        } else {
-            g256::launch<128>(ga, grid, s);
-            hipLaunchKernelGGL(g256::streamk_fixup_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, s, ga, (int)NUM_CU);
-        }
-        return true;
-    }
-    if (headtail) {
-        ga.xmode = 3; ga.px = ht_w; ga.py = ht_p;
-        dim3 grid((unsigned)NUM_CU);
-        if (bn == 256) {
-            g256::launch<256>(ga, grid, s);
-            hipLaunchKernelGGL(g256::headtail_fixup_kernel<256>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, ga);
-        } else {
-            g256::launch<128>(ga, grid, s);
-            hipLaunchKernelGGL(g256::headtail_fixup_kernel<128>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, ga);
-        }
-        return true;
-    }
     dim3 grid((unsigned)(tiles < NUM_CU ? tiles : NUM_CU));
     if (bn == 256) g256::launch<256>(ga, grid, s);
     else g256::launch<128>(ga, grid, s);

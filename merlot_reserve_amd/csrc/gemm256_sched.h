@@ -46,13 +46,6 @@
 namespace g256 {
 
 constexpr int BM = 256, BK = 64;
-// NW = waves per workgroup.  8 (the kernels above: one 512-thread workgroup per CU, BK = 64) or 4: 256 x 128 tiles, BK = 32,
-// 72 KiB of LDS, TWO workgroups per CU (still two waves per SIMD, 256 registers each).  The two workgroups of a CU are
-// independent: one's barrier waits, fragment-read latencies and -- above all -- its epilogue (loads, GELU, stores: 25-30 % of a
-// K = 768 tile) run under the other's MFMAs instead of leaving the matrix pipe idle.  Per wave and k-step the counts are those
-// of the 8-wave 128-wide kernel (4 A pieces + 2 B pieces, 32 MFMAs); the price is 1.5x the LDS-DMA bytes per FLOP of a
-// 256 x 256 tile.
-constexpr int bk_of(int NW) { return NW == 8 ? 64 : 32; }
 // B is staged 128 wide (BN = 128 | 96: 48-KiB stages, 3-stage ring, two k-tiles ahead) or 256 wide (BN = 256: 64-KiB
 // stages, 2-stage ring, one k-tile ahead).  The k-loop is bound by the LDS-DMA fill rate of a CU (~60-70 GB/s measured
 // with the MFMAs compiled out), so the 256 x 256 tile -- 2/3 of the bytes per FLOP -- is the fast one wherever the
@@ -60,11 +53,10 @@ constexpr int bk_of(int NW) { return NW == 8 ? 64 : 32; }
 // BN = 192 uses the 256-wide geometry with the B columns beyond 192 left to the buffer descriptor's zero fill (no L2
 // traffic): 244 tiles instead of 183 for M = 15424, N = 768 -- one full round of the 256 CUs -- at 3/4 of the MFMAs
 // and 7/8 of the bytes of a 256-wide tile.
-template <int BN, int NW = 8> struct Geo {
-    static_assert(NW == 8 || (NW == 4 && BN == 128), "4-wave workgroups: 256 x 128 tiles only");
-    static constexpr int BKT = bk_of(NW);
+template <int BN> struct Geo {
+    static constexpr int NW = 8, BKT = BK;                 // eight waves, one 512-thread workgroup per CU
     static constexpr int BW = (BN > 128) ? 256 : 128;
-    static constexpr int STAGE_A = BM * BKT * 2;           // 32 KiB (16 KiB with 4 waves)
+    static constexpr int STAGE_A = BM * BKT * 2;           // 32 KiB
     static constexpr int STAGE_B = BW * BKT * 2;
     // Two rings.  A (32 KiB per k-tile) always runs TWO k-tiles ahead of the MFMAs in 3 stages.  B runs two ahead in 3
     // stages when it is 128 wide (144 KiB in all) and ONE ahead in 2 stages when it is 256 wide (96 + 64 = 160 KiB, all of
@@ -83,7 +75,7 @@ template <int BN, int NW = 8> struct Geo {
     // also runs two ahead
     static constexpr int WAITN = 4 + (B_AHEAD == 2 ? NBP : 0);
 };
-static_assert(Geo<256>::LDS_BYTES == 160 * 1024 && Geo<128>::LDS_BYTES == 144 * 1024 && Geo<128, 4>::LDS_BYTES == 72 * 1024, "LDS budget");
+static_assert(Geo<256>::LDS_BYTES == 160 * 1024 && Geo<128>::LDS_BYTES == 144 * 1024, "LDS budget");
 constexpr unsigned OOB = 0x80000000u;      // >= any operand extent (< 2^31 B, checked on the host); + soffset cannot wrap
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -94,20 +86,10 @@ __device__ __forceinline__ int swz_ks(int k) { return 2 * ((k & 3) + 4 * ((k >> 
 // byte offset (into the operand's buffer, for k-tile 0) of the 16-byte chunk that lane `lane` of piece `p` fetches.
 // The k-tile advance is a wave-uniform scalar offset (128 B per k-tile for K-contiguous, 64 rows for K-strided), and
 // k-rows past K fall beyond the operand's extent, so validity does not depend on the k-tile.
-// K-contiguous tile with BK = 32 ([rows][32 k], 64-B rows, 16 rows per piece): chunk ^= (-(row >> 2)) & 3.  ds_read_b128 serves
-// a wave in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (16 lanes = 256 B per LDS cycle); with fragment lane
-// (i, g) reading row i, chunk g, this XOR gives every such group 16 distinct 16-byte slots of the 256-byte bank row.
-__device__ __forceinline__ int swz_k32(int row) { return (-(row >> 2)) & 3; }
 
 template <bool TR, int W, int BKT = 64>
 __device__ __forceinline__ unsigned piece_src(int p, int lane, int64_t ld, int64_t own0, int64_t own_n) {
-    if (!TR && BKT == 32) {
-        const int row = p * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz_k32(row);
-        const int64_t grow = own0 + row;
-        if (grow >= own_n) return OOB;
-        return (unsigned)((grow * ld + chunk * 8) * 2);
-    } else if (!TR) {
+    if (!TR) {
         const int row = p * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz_kc(row);
         const int64_t grow = own0 + row;
@@ -134,10 +116,7 @@ __device__ __forceinline__ void reg_fence(u32x2& v) { asm volatile("" : "+v"(v))
 template <bool TR, int W, int BKT = 64>
 __device__ __forceinline__ bf16x8 frag(const char* tile, int own0, int kk, int lane) {
     const int g = lane >> 4, i = lane & 15;
-    if (!TR && BKT == 32) {
-        const int row = own0 + i;
-        return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((g ^ swz_k32(row)) << 4));
-    } else if (!TR) {
+    if (!TR) {
         const int row = own0 + i;
         return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((kk * 4 + g) ^ swz_kc(row)) << 4));
     } else {
@@ -175,7 +154,6 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // One unit of work: an output tile (and, under split-K, one K range of it).
 struct Item {
     int pi, m0, n0, kt0, nkt, split;
-    int slot;          // stream-K: >= 0 = a PARTIAL k-range of the tile: raw fp32 accumulators go to slab `slot` of the workspace
     bool valid;
 };
 
@@ -190,32 +168,14 @@ struct G256Args {
     // slice of B stays L2-resident while its A strips stream through.  (With the plain row-major order every XCD swept
     // all of B once per round of 256 tiles: rocprofv3 FETCH_SIZE showed 6x the operand bytes leaving L2 per launch.)
     int xmode, px, py, tm, tn;
-    // Stream-K (grouped weight gradients: 216 tiles of 241 k-tiles on 256 CUs, or 192 on 256 for the large model, used 84 % /
-    // 75 % of the chip for one round): the tiles' k-tiles form ONE sequence of `nwork * sk_nkt` units cut into gridDim.x equal
-    // ranges, one per workgroup.  A workgroup's range covers the tail of one tile, whole tiles, and the head of another; a
-    // k-range that is not a whole tile leaves its raw fp32 accumulators in slab 2 * wg + (first item ? 0 : 1) of sk_ws
-    // ([256][BN] each), and streamk_fixup_kernel sums a split tile's slabs in workgroup order (fixed order: reproducible).
-    // (xmode == 2 selects it; the k-tiles per tile are kt_per_split, the slabs live in p[0].workspace: no extra fields -- at
-    // 1024 bytes instead of 1000 the by-value kernel argument was copied to scratch and every variant spilled)
-    // Head / tail split (xmode == 3; the large model's grouped weight gradients: T = 192 tiles of 241 k-tiles on 256 CUs, i.e. one
-    // round at 75 % of the chip): the first T workgroups compute k-tiles [0, W) of "their" tile, the other G - T workgroups the
-    // tails [W, nkt) of P = T / (G - T) tiles each (W = px, P = py; 181 and 3 x 60 k-tiles instead of 241).  Unlike stream-K
-    // every workgroup of a kind walks the SAME k range at the same time, so operand strips stay shared in L2.  Each tile leaves
-    // two raw fp32 slabs (2 tile, 2 tile + 1) in p[0].workspace, summed by headtail_fixup_kernel.
     int tiles_n[MAXG], tile_start[MAXG + 1];
     mr_gemm_args p[MAXG];
 };
 
 constexpr int XPANEL = 8;
-// stream-K constants of one workgroup (computed once, at kernel entry: the divisions stay out of the k-loop)
-struct SkRange {
-    int u0, u1, tfirst;
-    int ht_n, ht_tile0, ht_k0, ht_k1, ht_part;      // head / tail split (xmode == 3): this workgroup's ht_n items, all over k-tiles [ht_k0, ht_k1)
-};
 template <int BKT, int GSH>     // GSH = log2(workgroups of a full grid): 8, or 9 for the two-per-CU kernel
-__device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int bperm, const SkRange& sk) {
+__device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int bperm) {
     Item it;
-    it.slot = -1;
     if (ga.xmode == 1) {
         constexpr int PX = 1 << (GSH - 3);                                 // workgroups per XCD
         const int r = w >> GSH, bp = w & ((1 << GSH) - 1), x = bp / PX, sl = bp % PX;     // w = bperm + r * 256, bperm = xcd * 32 + slot
@@ -236,49 +196,42 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
         it.nkt = (int)((ga.p[0].K + BKT - 1) / BKT);
         return it;
     }
-    // plain / split-K / stream-K share ONE decode of (tile -> problem, m0, n0): a second copy of these dynamically indexed reads
-    // of the by-value argument made the compiler spill the whole 1000-byte struct to scratch
-    int tile, k0 = 0, k1 = 0;
-    const bool sk_mode = ga.xmode == 2, ht_mode = sk.ht_n > 0;
-    if (ht_mode) {                                              // (constants from the kernel's entry: nothing of `ga` is read here)
-        const int q = (w - bperm) >> 8;                          // 256 workgroups
-        it.valid = q < sk.ht_n;
-        tile = sk.ht_tile0 + q;
-        k0 = sk.ht_k0;
-        k1 = sk.ht_k1;
-        it.split = 0;
-        it.slot = 2 * tile + sk.ht_part;
-        if (!it.valid) tile = 0;
-    } else if (sk_mode) {
-        const int q = (w - bperm) >> 8;                          // the workgroup's q-th item (stream-K grids have 256 workgroups)
-        const int nkt = ga.kt_per_split;
-        tile = sk.tfirst + q;
-        const int tb = tile * nkt;
-        it.valid = tb < sk.u1;
-        k0 = (q == 0) ? sk.u0 - tb : 0;
-        k1 = (sk.u1 - tb < nkt) ? sk.u1 - tb : nkt;
-        it.split = 0;
-        if (k0 != 0 || k1 != nkt) it.slot = 2 * bperm + (q == 0 ? 0 : 1);
-        if (!it.valid) tile = 0;
-    } else {
-        it.valid = w < ga.nwork;
-        tile = (ga.splits == 1) ? w : w / ga.splits;
-        it.split = w - tile * ga.splits;
-    }
+    it.valid = w < ga.nwork;
+    const int tile = (ga.splits == 1) ? w : w / ga.splits;
+    it.split = w - tile * ga.splits;
     it.pi = (tile >= ga.tile_start[1]) + (tile >= ga.tile_start[2]) + (tile >= ga.tile_start[3]);
     const int lt = tile - ga.tile_start[it.pi], tn = ga.tiles_n[it.pi];
     it.m0 = (lt / tn) * BM;
     it.n0 = (lt % tn) * bn;
-    if (sk_mode || ht_mode) {
-        it.kt0 = k0;
-        it.nkt = k1 - k0;
-    } else {
-        const int nk_all = (int)((ga.p[it.pi].K + BKT - 1) / BKT);
-        it.kt0 = it.split * ga.kt_per_split;
-        const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
-        it.nkt = kt1 - it.kt0;
-    }
+    const int nk_all = (int)((ga.p[it.pi].K + BKT - 1) / BKT);
+    it.kt0 = it.split * ga.kt_per_split;
+    const int kt1 = (it.kt0 + ga.kt_per_split < nk_all) ? it.kt0 + ga.kt_per_split : nk_all;
+    it.nkt = kt1 - it.kt0;
     return it;
+}
+
+// The persistent kernels of gemm3.hip / gemm4.hip decode their items once per workgroup (lane q = the workgroup's q-th item) for ANY
+// grid size G (a multiple of 8 when the XCD partition is on: G / 8 workgroups per XCD): 256 = the whole chip, 240 = 30 per XCD, which
+// leaves two CUs of every XCD to a resident collective kernel (mr_set_option "gemm_cus").  Single problem, no split-K.
+__device__ __forceinline__ void item_pp(const G256Args& ga, int bperm, int q, int G, int bn, int& m0, int& n0) {
+    if (ga.xmode == 1) {
+        const int px_ = G >> 3;                                             // workgroups per XCD
+        const int x = bperm / px_, sl = bperm - x * px_;
+        const int xi = x / ga.py, xj = x - xi * ga.py;
+        const int m_lo = xi * ga.tm / ga.px, hm = (xi + 1) * ga.tm / ga.px - m_lo;
+        const int n_lo = xj * ga.tn / ga.py, hn = (xj + 1) * ga.tn / ga.py - n_lo;
+        const int qq = q * px_ + sl;
+        const int gw = hn < XPANEL ? hn : XPANEL;
+        const int panel = qq / (hm * gw), rem = qq - panel * hm * gw;
+        const int left = hn - panel * gw, pw = left < gw ? left : gw;          // the last panel may be narrower
+        const int m = rem / (pw > 0 ? pw : 1), n = panel * gw + rem - m * pw;
+        m0 = qq < hm * hn ? (m_lo + m) * BM : -1;
+        n0 = (n_lo + n) * bn;
+    } else {
+        const int w = bperm + q * G, tn = ga.tiles_n[0];
+        m0 = w < ga.nwork ? (w / tn) * BM : -1;
+        n0 = (w % tn) * bn;
+    }
 }
 
 }  // namespace g256

@@ -100,16 +100,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
-    const SkRange skr = {0, 0, 0, 0, 0, 0, 0, 0};
     // The workgroup's items (output tiles), decoded ONCE: lane q holds item q (m0 < 0 = none), fetched with v_readlane.  Decoding
     // an item at every cursor switch -- integer divisions and kernel-argument loads inside a phase that all eight waves wait
     // for -- cost ~4 000 cycles per tile (in-kernel stamps).  <= 64 items per workgroup (host check).
     int m0v, n0v;
-    {
-        const Item it = make_item<64, 8>(ga, bperm + lane * G, BN, bperm, skr);
-        m0v = it.valid ? it.m0 : -1;
-        n0v = it.n0;
-    }
+    item_pp(ga, bperm, lane, G, BN, m0v, n0v);
     auto item_m0 = [&](int q) -> int { return q < 64 ? __builtin_amdgcn_readlane(m0v, q) : -1; };
     auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
     if (item_m0(0) < 0) return;
@@ -627,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
 }  // namespace g3
 
 constexpr int64_t NUM_CU3 = 256;    // MI355X
-extern int g_mr_opt_group_streamk, g_mr_opt_group_headtail, g_mr_opt_group_tile_n;
+extern int g_mr_opt_group_tile_n;
 extern int g_mr_opt_gemm4;           // mr_set_option("gemm4"): -1 = default (MR_GEMM4, or on) | 0 | 1 : the one-wave-per-SIMD kernel for gemm3's bias / residual / plain problems
 bool mr_gemm4_takes(const mr_gemm_args* a);
 int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int64_t gsz, hipStream_t s);
@@ -637,6 +632,11 @@ extern int g_mr_opt_gemm3;           // mr_set_option("gemm3"): 1 = on (default)
 // The ping-pong kernel takes: NT operands (A [M,K], B [N,K], K % 64 == 0), bf16 output, at least one full round of 256-row tiles'
 // worth of work, and one of the epilogue combinations the step uses -- bias; bias + "rotary"; bias + GELU with the gelu' copy;
 // residual; aux (with or without column sums).
+extern int g_mr_opt_gemm_cus;        // mr_set_option("gemm_cus"): 0 / 256 = all CUs | 64 .. 248: persistent grids of the NT kernels use this many workgroups
+// persistent workgroups = CUs a launch may fill (mr_set_option "gemm_cus": 256, or fewer -- a multiple of 8 -- while a collective
+// kernel holds CUs: a 256-workgroup grid would then run its last workgroups as a second round behind the others)
+static int64_t g3_ncu() { return (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < NUM_CU3) ? (g_mr_opt_gemm_cus & ~7) : NUM_CU3; }
+
 bool mr_gemm3_eligible(const mr_gemm_args* a) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MR_GEMM3"); env = e ? atoi(e) : 1; }
@@ -657,7 +657,7 @@ bool mr_gemm3_eligible(const mr_gemm_args* a) {
     if (a->bias && (a->residual || a->aux)) return false;      // the bias rides in the accumulators of the bias modes only
     // enough tiles to fill the chip (short-K problems with few tiles go to the split-K path of the one-barrier kernel)
     const int64_t tm = (a->M + 255) / 256;
-    if (tm * ((a->N + 191) / 192) > 64 * 256) return false;     // <= 64 items per workgroup (the kernel keeps them one per lane)
+    if (tm * ((a->N + 191) / 192) > 64 * g3_ncu()) return false;     // <= 64 items per workgroup (the kernel keeps them one per lane)
     static int min_tiles = -1;
     if (min_tiles < 0) { const char* e = getenv("MR_G3_MIN_TILES"); min_tiles = e ? atoi(e) : 128; }
     if (!forced && tm * ((a->N + 255) / 256) < min_tiles) return false;
@@ -668,15 +668,16 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     const int64_t tm = (a->M + 255) / 256;
     // tile width: fewest CU-rounds, a 192-wide tile costing 3/4 of a 256-wide one
     const int64_t t256 = tm * ((a->N + 255) / 256), t192 = tm * ((a->N + 191) / 192);
-    const int64_t c256 = ((t256 + NUM_CU3 - 1) / NUM_CU3) * 100, c192 = ((t192 + NUM_CU3 - 1) / NUM_CU3) * 78;
+    const int64_t ncu = g3_ncu();
+    const int64_t c256 = ((t256 + ncu - 1) / ncu) * 100, c192 = ((t192 + ncu - 1) / ncu) * 78;
     int bn = (c192 < c256) ? 192 : 256;
     if (g_mr_opt_gemm3 == 256 || g_mr_opt_gemm3 == 192) bn = g_mr_opt_gemm3;
     const int64_t tn = (a->N + bn - 1) / bn, nwork = tm * tn;
-    const int64_t gsz = nwork < NUM_CU3 ? nwork : NUM_CU3;
+    const int64_t gsz = nwork < ncu ? nwork : ncu;
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
     ga.count = 1; ga.nwork = (int)nwork; ga.splits = 1; ga.kt_per_split = (int)(a->K / 64);
-    if (gsz == NUM_CU3 && nwork >= 2 * NUM_CU3) {
+    if (gsz == ncu && nwork >= 2 * ncu) {
         // XCD partition of the tile grid (see G256Args.xmode): fewest rounds first, then least traffic out of L2
         const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
         double best = 1e300;
@@ -687,7 +688,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
             for (int xi = 0; xi < px; ++xi)
                 for (int xj = 0; xj < py; ++xj) {
                     const int64_t hm = (xi + 1) * tm / px - xi * tm / px, hn = (xj + 1) * tn / py - xj * tn / py;
-                    const int64_t r = (hm * hn + NUM_CU3 / 8 - 1) / (NUM_CU3 / 8);
+                    const int64_t r = (hm * hn + ncu / 8 - 1) / (ncu / 8);
                     if (r > rounds) rounds = r;
                 }
             const bool b_fits = b_bytes / py < 2.5e6;
@@ -747,7 +748,7 @@ bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MR_GEMM3_TN"); env = e ? atoi(e) : 1; }
     if (!env || !g_mr_opt_gemm3 || count < 1 || count > g3::TN_MAXG) return false;
-    if (g_mr_opt_group_streamk > 0 || g_mr_opt_group_headtail > 0 || g_mr_opt_group_tile_n != 0) return false;   // an explicitly requested schedule of the one-barrier kernel
+    if (g_mr_opt_group_tile_n != 0) return false;   // an explicitly requested tile width of the one-barrier kernel
     g3::TNArgs ta;
     memset(&ta, 0, sizeof(ta));
     int64_t tiles = 0;

@@ -2,22 +2,31 @@
 // grid, operand rings and epilogue as the ping-pong kernel (gemm3.hip); what changes is who multiplies:
 //
 // ONE wave per SIMD.  256 x {256,192} x 64 tiles, FOUR waves as 2 (M) x 2 (N): a wave owns 128 x {128,96} of the tile = 8 x {8,6}
-// accumulators of v_mfma_f32_16x16x32_bf16 (256 | 192 registers -- the wave has the SIMD's whole 512-entry file), i.e. per k-tile it
-// reads (128 + 128) rows of fragments for 128 MFMAs where an eight-wave 128 x 64 block reads (128 + 64) for 64: the LDS bytes per FLOP
-// that bound the eight-wave k-loops drop by a third (192 -> 128 KiB of ds_read_b128 per k-tile and CU).
-// With nobody else on the SIMD to fill its gaps, the wave's own instruction stream is software-pipelined: a k-tile is two halves of
-// 64 | 48 MFMAs (k = 0..31, 32..63 of the tile),
-//     half 0:  MFMAs of k-half 0        beside  the 16 | 14 ds_read_b128 of k-half 1's fragments
-//     s_waitcnt vmcnt (own pieces of k-tile t+1 landed) . lgkmcnt(0) . s_barrier
-//     half 1:  MFMAs of k-half 1        beside  the LDS-DMA issue of B(t+2), A(t+3) and the reads of k-tile t+1's k-half 0
-// placed between the MFMAs with __builtin_amdgcn_sched_group_barrier (every DMA and LDS read is independent of the half's MFMAs).
+// accumulators of v_mfma_f32_16x16x32_bf16 (256 | 192 registers, in AGPRs -- the wave has the SIMD's whole 512-entry file), i.e. per
+// k-tile it reads (128 + 128) rows of fragments for 128 MFMAs where an eight-wave 128 x 64 block reads (128 + 64) for 64: the LDS
+// bytes per FLOP that bound the eight-wave k-loops drop by a third (192 -> 128 KiB of ds_read_b128 per
+// k-tile and CU).  This is the shape of the vendor library's kernels for these problems (MT256x256x64 / MT256x192x64, 4 waves).
+// With nobody else on the SIMD to fill its gaps, the wave's own instruction stream is software-pipelined.  A k-tile is two halves
+// of 64 | 48 MFMAs (k = 0..31, 32..63 of the tile):
+//     half 0:  MFMAs of k-half 0   beside  the 16 | 14 ds_read_b128 of k-half 1's fragments  and the 8 LDS-DMA requests of A(t+2)
+//     s_waitcnt vmcnt(8) (own pieces of k-tile t+1 landed: all but the newest 8) . lgkmcnt(0) . s_barrier
+//     half 1:  MFMAs of k-half 1   beside  the reads of k-tile t+1's k-half 0                and the 8 | 6 requests of B(t+2)
+// Every read and request is independent of the half's MFMAs and sits behind a PAIR of MFMAs: at most two other instructions
+// between two MFMAs, in SOURCE order pinned by scheduling barriers (the compiler's own placement, also under sched_group_barrier,
+// bunches the requests with their M0 writes and the scalar bookkeeping: 846 vs 703 us on 8192^3).
 // ONE barrier per k-tile (128 | 96 MFMAs): behind it every wave's pieces of k-tile t+1 are visible, and every read of k-tile t's
-// stage has been retired (the wait that precedes it), so the stage is refilled right away -- safe by construction.
-// Operand rings as in gemm3: A 3 stages x 32 KiB (requested three k-tiles ahead, landed two k-tiles later), B 2 stages x {32,24} KiB
-// (two ahead, one k-tile to land); every wave issues 8 A + {8,6} B pieces per k-tile, unconditionally -- a cursor that has run out
-// of tiles requests out-of-range rows (zero fill into a stage nobody reads), which keeps the k-loop free of branches and the
-// counted vmcnt exact.  The issue cursors run across output tiles, and so do the fragment reads: the next tile's first fragments
-// are in registers before the epilogue starts.
+// stages has been retired (the wait in front of it) -- B(t+2) then refills k-tile t's B stage, A(t+2) the stage k-tile t-1 was
+// read from: safe by construction.  Rings as in gemm3: A 3 stages x 32 KiB, B 2 stages x {32,24} KiB; every wave issues 8 A +
+// {8,6} B pieces per k-tile UNCONDITIONALLY -- a cursor that has run out of tiles requests from an empty descriptor (zero fill
+// into a stage nobody reads) -- which keeps the k-loop free of branches and the counted vmcnt exact.  One issue cursor serves both
+// operands (always two k-tiles ahead); it moves at the k-tile's end, where an item switch rebuilds the two descriptors (base = the
+// item's first row) in a scalar branch outside the MFMA stream, so a request inside it costs its M0 write and nothing else.
+// The cursor runs across output tiles, and so do the fragment reads: the next tile's first fragments are in registers before the
+// epilogue starts.  Instantiated for the bias / residual / plain epilogues; rotary scales, GELU + gelu' and aux + column sums need
+// more registers than the 256 VGPRs beside the accumulators leave (spill reloads inside the k-loop) and stay with gemm3.
+// Measured (sustained, interleaved with gemm3): 15424 x 768 x 3072 59.4 vs 63.7 us, x 2304 46.2 vs 50.1, 15424 x 2304 x 768
+// plain 57.0 vs 61.6, 8192^3 706 vs 738 (the vendor library: 683); K = 768, N = 3072 ties (72.5 vs 72.2): there the epilogue,
+// which no second wave hides here either, is a third of the tile.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -64,14 +73,9 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const G256Args ga) {
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
-    const SkRange skr = {0, 0, 0, 0, 0, 0, 0, 0};
     // the workgroup's items (output tiles), decoded once: lane q holds item q (m0 < 0 = none); <= 64 items per workgroup (host check)
     int m0v, n0v;
-    {
-        const Item it = make_item<64, 8>(ga, bperm + lane * G, BN, bperm, skr);
-        m0v = it.valid ? it.m0 : -1;
-        n0v = it.n0;
-    }
+    item_pp(ga, bperm, lane, G, BN, m0v, n0v);
     // (the readlane is unconditional: a convergent operation under a condition would put a branch into the k-loop's issue slot)
     auto item_m0 = [&](int q) -> int { const int r = __builtin_amdgcn_readlane(m0v, q & 63); return q < 64 ? r : -1; };
     auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };

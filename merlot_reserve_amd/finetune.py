@@ -350,8 +350,9 @@ def _backward_reduce_update(state):
             state.apply_range(lo, hi)
     eng.backward_stage_joint()
     finish('joint')
-    eng.backward_stage_vision(layer_done=lambda l: finish(('vision', l)) if l in cuts else None)
-    finish('vision_end')
+    with ops.gemm_cus(comm.world if comm is not None else 1):      # a bucket's all-reduce runs beside the vision tower's GEMMs
+        eng.backward_stage_vision(layer_done=lambda l: finish(('vision', l)) if l in cuts else None)
+        finish('vision_end')
     main.wait_stream(cs)
 
 

@@ -2,6 +2,7 @@
 current HIP stream.  Every op launches asynchronously on torch's current stream; nothing allocates unless an output
 tensor is not passed in.  All 2-D operands must have unit stride in the last dim; the row stride is the leading dim."""
 import ctypes as C
+import os
 
 import torch
 
@@ -48,6 +49,32 @@ def _timed(family):
         wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
         return wrapper
     return deco
+
+
+def set_option(name, value):
+    """mr_set_option: process-wide tuning knob of the library (include/mreserve_hip.h lists them)."""
+    check(_lib.load().mr_set_option(name.encode(), int(value)), 'mr_set_option')
+
+
+class gemm_cus:
+    """with ops.gemm_cus(world): the persistent forward / dgrad GEMM grids launched inside use MR_COMM_GEMM_CUS workgroups (default 240 =
+    30 per XCD) when world > 1, i.e. while a gradient bucket's RCCL kernel may hold CUs next to them: a 256-workgroup grid then runs its
+    last workgroups as a second round (scripts/bench_contention.py: 16 CUs held -> 111 vs 79 us for the fc1 shape).  Launch parameters
+    are fixed at capture time, so inside a captured step this shapes the graph's kernels, not the replay."""
+
+    def __init__(self, world):
+        n = int(os.environ.get('MR_COMM_GEMM_CUS', '240'))
+        self.n = n if world > 1 and 64 <= n < 256 else 0
+
+    def __enter__(self):
+        if self.n:
+            set_option('gemm_cus', self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if self.n:
+            set_option('gemm_cus', 0)
+        return False
 
 
 def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, rot_cols=0, c2=None, act=ACT_NONE,

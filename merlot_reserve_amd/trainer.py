@@ -217,20 +217,22 @@ class Trainer:
         self.bucket_log = []
         eng.backward_stage_joint()
         self._finish_bucket('joint', main, update)
-        eng.side_stream.wait_stream(main)
-        eng._on_side(eng.backward_stage_audio)
-        audio_stream = main if os.environ.get('MR_NO_SIDE_STREAM') == '1' else eng.side_stream     # (A/B switch: issued in line)
-        pending = ['audio']                     # enqueued behind the first vision bucket: audio rarely ends before it
+        # from here to the end of backward a bucket's all-reduce is in flight beside the GEMMs: leave its kernel two CUs per XCD
+        with ops.gemm_cus(self.world if self.use_comm else 1):
+            eng.side_stream.wait_stream(main)
+            eng._on_side(eng.backward_stage_audio)
+            audio_stream = main if os.environ.get('MR_NO_SIDE_STREAM') == '1' else eng.side_stream     # (A/B switch: issued in line)
+            pending = ['audio']                     # enqueued behind the first vision bucket: audio rarely ends before it
 
-        def layer_done(l):
-            if l in self.vision_cuts:
-                self._finish_bucket(('vision', l), main, update)
-                if pending:
-                    self._finish_bucket(pending.pop(), audio_stream, update)
-        eng.backward_stage_vision(layer_done=layer_done)
-        if pending:
-            self._finish_bucket(pending.pop(), audio_stream, update)
-        self._finish_bucket('vision_end', main, update)
+            def layer_done(l):
+                if l in self.vision_cuts:
+                    self._finish_bucket(('vision', l), main, update)
+                    if pending:
+                        self._finish_bucket(pending.pop(), audio_stream, update)
+            eng.backward_stage_vision(layer_done=layer_done)
+            if pending:
+                self._finish_bucket(pending.pop(), audio_stream, update)
+            self._finish_bucket('vision_end', main, update)
         main.wait_stream(eng.side_stream)
         main.wait_stream(self.comm_stream)
 

@@ -18,7 +18,7 @@ def run(name, m, n, k, tb, variants):
         sets.append((a, b, c, c2, x))
     bias = torch.randn(n, device=dev).to(torch.bfloat16)
     tab = torch.rand(241, 32, device=dev)
-    for vname, kw, bn in [(v, k_, b_) for v, k_ in variants for b_ in (0, 192, 256, 4128)]:
+    for vname, kw, bn in [(v, k_, b_) for v, k_ in variants for b_ in (0, 192, 256)]:
         _lib.load().mr_set_option(b'gemm_tile_n', bn)
         vname = f'{vname} bn={bn}'
         def call(a, b, c, c2, x):

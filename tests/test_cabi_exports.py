@@ -40,3 +40,29 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(root, f)).read()
                 assert 'oracle' not in re.sub(r'#.*', '', src).replace('"""', ''), f'{f} mentions the oracle'
+
+
+def test_options_are_named_and_unknown_names_rejected(monkeypatch):
+    """mr_set_option: every knob the header documents is accepted, an unknown name is MR_EINVAL; ops.gemm_cus (the 240-workgroup plan of
+    the data-parallel backward) sets and restores the knob only for world > 1."""
+    from merlot_reserve_amd import _lib, ops
+    lib = _lib.load()
+    text = open(os.path.join(ROOT, 'include', 'mreserve_hip.h')).read()
+    names = re.findall(r'^ \*   "([a-z0-9_]+)"', text, flags=re.M)
+    assert {'gemm3', 'gemm3_phases', 'gemm4', 'gemm_cus', 'gemm_tile_n'} <= set(names)
+    defaults = {'gemm3': 1, 'gemm4': -1}
+    for n in names:
+        assert lib.mr_set_option(n.encode(), defaults.get(n, 0)) == 0, n
+    assert lib.mr_set_option(b'no_such_knob', 1) == -1 and b'no_such_knob' in lib.mr_last_error()
+    calls = []
+    monkeypatch.setattr(ops, 'set_option', lambda name, value: calls.append((name, value)))
+    with ops.gemm_cus(1):
+        pass
+    assert calls == []
+    with ops.gemm_cus(8):
+        assert calls == [('gemm_cus', 240)]
+    assert calls == [('gemm_cus', 240), ('gemm_cus', 0)]
+    monkeypatch.setenv('MR_COMM_GEMM_CUS', '0')
+    with ops.gemm_cus(8):
+        pass
+    assert len(calls) == 2

@@ -154,3 +154,33 @@ def test_tn_grouped_weight_gradients(dev, Mtok, H):
         lib.mr_set_option(b'gemm3', 1)
     for x, dy, o in zip(xs, dys, outs):
         assert_close(o, x.float().T @ dy.float(), 3e-3, f'wgrad {tuple(o.shape)}')
+
+
+@pytest.mark.parametrize('cus', [240, 64])
+def test_fewer_persistent_workgroups_same_result(dev, cus):
+    """mr_set_option('gemm_cus', n): the persistent grids use n workgroups (n / 8 per XCD) -- what the data-parallel trainer asks for while a
+    gradient bucket's RCCL kernel holds CUs.  Same tiles, same k order: bit-identical outputs, with and without the XCD partition."""
+    from merlot_reserve_amd import _lib, ops
+    lib = _lib.load()
+    cases = [(15424, 3072, 768, True), (9000, 768, 1024, False), (3000, 1000, 256, False)]       # (M, N, K, bias): >= 2 rounds | 1-2 rounds | few tiles
+    try:
+        for M, N, K, with_bias in cases:
+            a, w = rnd((M, K), dev, seed=1), rnd((N, K), dev, scale=0.1, seed=2)
+            bias = rnd((N,), dev, seed=3) if with_bias else None
+            outs = []
+            for g4 in (0, 1):
+                for n in (0, cus):
+                    lib.mr_set_option(b'gemm3', 256 if M < 4000 else 1)          # the small case: forced onto the kernel
+                    lib.mr_set_option(b'gemm4', g4)
+                    lib.mr_set_option(b'gemm_cus', n)
+                    o = torch.full((M, N), float('nan'), dtype=BF16, device=dev)
+                    ops.gemm(a, w, o, transB=True, bias=bias)
+                    outs.append(o)
+            ref = a.float() @ w.float().T + (bias.float() if with_bias else 0)
+            assert_close(outs[0], ref, 3e-3, f'{M}x{N}x{K}')
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), f'{M}x{N}x{K}: outputs differ with gemm_cus = {cus}'
+    finally:
+        lib.mr_set_option(b'gemm3', 1)
+        lib.mr_set_option(b'gemm4', -1)
+        lib.mr_set_option(b'gemm_cus', 0)

@@ -570,7 +570,7 @@ GEMM256_CASES = [
 ]
 
 
-@pytest.fixture(params=[0, 96, 128, 192, 256, 4128])      # 4128 = 128-wide tiles, 4-wave workgroups, two per CU
+@pytest.fixture(params=[0, 96, 128, 192, 256])
 def tile_n(request):
     """Forces the output-tile width of the 256-row GEMM (0 = the library's own choice) for the duration of a test."""
     from merlot_reserve_amd import _lib
@@ -678,60 +678,3 @@ def test_gemm_grouped(dev, group_tile):
     for x, o in zip(small, so):
         assert_close(o, x.float().T @ dd.float(), 3e-3, 'grouped fallback')
     _lib.load().mr_set_option(b'gemm_group_tile_n', 0)
-
-
-@pytest.mark.parametrize('Mtok', [4616, 5000])
-def test_gemm_grouped_head_tail(dev, Mtok):
-    """The large model's four weight gradients (H = 1024: 192 tiles of 256 x 256 for 256 CUs) with a workspace: the grouped launch
-    splits every tile's K range between a head workgroup and a tail workgroup (64 of the 256 take three tails each), two fp32 slabs per
-    tile + the fix-up pass.  Same results as four separate GEMMs, reproducible bit for bit, stale slabs never read; K = 5000 is not
-    a multiple of the 64-deep k-tile."""
-    from merlot_reserve_amd import _lib, ops
-    H = 1024
-    ws = torch.zeros(32 * 1024 * 1024, device=dev)
-    _lib.check(_lib.load().mr_set_option(b'gemm_group_headtail', 1), 'mr_set_option')        # opt-in (off by default: DESIGN.md)
-    xs = [rnd((Mtok, 4 * H), dev, seed=1), rnd((Mtok, H), dev, seed=2), rnd((Mtok, H), dev, seed=3), rnd((Mtok, H), dev, seed=4)]
-    ds = [rnd((Mtok, H), dev, seed=5), rnd((Mtok, 4 * H), dev, seed=6), rnd((Mtok, H), dev, seed=7), rnd((Mtok, 3 * H), dev, seed=8)]
-    runs = []
-    for rep in range(2):
-        outs = [torch.full((x.shape[1], d.shape[1]), float('nan'), dtype=BF16, device=dev) for x, d in zip(xs, ds)]
-        ws.fill_(float('nan'))
-        ops.gemm_grouped([ops.gemm_args(x, d, o, transA=True, ws=ws) for x, d, o in zip(xs, ds, outs)])
-        runs.append(outs)
-    for x, d, o, o2 in zip(xs, ds, runs[0], runs[1]):
-        assert_close(o, x.float().T @ d.float(), 3e-3, f'head/tail grouped {tuple(o.shape)}')
-        assert torch.equal(o, o2)
-    assert not torch.isnan(ws[:2 * 192 * 256 * 256]).any(), 'both slabs of every tile are written by the head / tail schedule'
-    _lib.load().mr_set_option(b'gemm_group_headtail', -1)
-    outs = [torch.zeros((x.shape[1], d.shape[1]), dtype=BF16, device=dev) for x, d in zip(xs, ds)]
-    ops.gemm_grouped([ops.gemm_args(x, d, o, transA=True) for x, d, o in zip(xs, ds, outs)])     # no workspace: the plain schedule
-    for o, o2 in zip(outs, runs[0]):
-        assert relerr(o, o2) < 2e-3
-
-
-@pytest.mark.parametrize('Mtok,H', [(3856, 512), (15424, 768), (2500, 384)])
-def test_gemm_grouped_streamk(dev, Mtok, H):
-    """The grouped weight-gradient launch with a workspace: when the tiles leave CUs idle it runs stream-K (every workgroup an
-    equal range of (tile, k-tile) units, partial tiles through fp32 slabs + the fix-up pass) -- same results as four separate
-    GEMMs, bit for bit from run to run (fixed summation order), and the same as the plain schedule up to fp32 sum order."""
-    from merlot_reserve_amd import _lib, ops
-    ws = torch.zeros(32 * 1024 * 1024, device=dev)
-    _lib.check(_lib.load().mr_set_option(b'gemm_group_streamk', 1), 'mr_set_option')        # opt-in (off by default: DESIGN.md)
-    xs = [rnd((Mtok, 4 * H), dev, seed=1), rnd((Mtok, H), dev, seed=2), rnd((Mtok, H), dev, seed=3), rnd((Mtok, H), dev, seed=4)]
-    ds = [rnd((Mtok, H), dev, seed=5), rnd((Mtok, 4 * H), dev, seed=6), rnd((Mtok, H), dev, seed=7), rnd((Mtok, 3 * H), dev, seed=8)]
-    runs = []
-    for rep in range(2):
-        outs = [torch.full((x.shape[1], d.shape[1]), float('nan'), dtype=BF16, device=dev) for x, d in zip(xs, ds)]
-        ws.fill_(float('nan'))                                   # stale slabs must never be read
-        ops.gemm_grouped([ops.gemm_args(x, d, o, transA=True, ws=ws) for x, d, o in zip(xs, ds, outs)])
-        runs.append(outs)
-    for x, d, o, o2 in zip(xs, ds, runs[0], runs[1]):
-        assert_close(o, x.float().T @ d.float(), 3e-3, f'stream-K grouped {tuple(o.shape)}')
-        assert torch.equal(o, o2)
-    _lib.check(_lib.load().mr_set_option(b'gemm_group_tile_n', 128), 'mr_set_option')      # forced width: the plain schedule
-    outs = [torch.zeros((x.shape[1], d.shape[1]), dtype=BF16, device=dev) for x, d in zip(xs, ds)]
-    ops.gemm_grouped([ops.gemm_args(x, d, o, transA=True, ws=ws) for x, d, o in zip(xs, ds, outs)])
-    _lib.load().mr_set_option(b'gemm_group_tile_n', 0)
-    _lib.load().mr_set_option(b'gemm_group_streamk', -1)
-    for o, o2 in zip(outs, runs[0]):
-        assert relerr(o, o2) < 2e-3
