@@ -475,11 +475,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
 // "TN" variant for the weight gradients:  C[M,N] = A^T . B with A stored [K, M] and B stored [K, N] (activations x upstream
 // gradients, the contraction index = tokens is the ROW index of both).  Same two-group ping-pong k-loop; the operand tiles are
 // [64 k][256] images read with ds_read_b64_tr_b16 (two per MFMA operand).  One 256 x 256 output tile per workgroup, no
-// persistence (K = tokens is long: 93-241 k-tiles, the prologue and the plain bf16 epilogue are < 2 % of a tile), up to 8
+// persistence (K = tokens is long: 93-241 k-tiles, the prologue and the plain bf16 epilogue are < 2 % of a tile), up to 16
 // problems per launch: the weight gradients of TWO transformer layers fill the chip without split-K (216 tiles for the base
-// model) where one layer's four are 108.
+// model) where one layer's four are 108; FOUR layers of the large model are 768 tiles = three full rounds where one layer's 192
+// leave a quarter of the CUs idle.
 struct TNProb { const void* A; const void* B; void* C; int M, N, lda, ldb, ldc, pad; };
-constexpr int TN_MAXG = 8;
+constexpr int TN_MAXG = 16;
 struct TNArgs { int count, K; int tile_start[TN_MAXG + 1]; int tiles_n[TN_MAXG]; TNProb p[TN_MAXG]; };
 
 __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
@@ -769,7 +770,7 @@ bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     ta.K = (int)list[0].K;
     // worth it when the tiles fill most of the chip (one tile per workgroup, one workgroup per CU) and K is long
     const bool forced = g_mr_opt_gemm3 == 256;
-    if (!forced && (tiles < 160 || tiles > 2 * NUM_CU3 || list[0].K < 2048)) return false;
+    if (!forced && (tiles < 160 || tiles > 4 * NUM_CU3 || list[0].K < 2048)) return false;
     hipLaunchKernelGGL(g3::gemm3_tn_kernel, dim3((unsigned)tiles), dim3(512), 0, s, ta);
     return true;
 }

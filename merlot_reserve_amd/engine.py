@@ -54,12 +54,13 @@ class TowerEngine:
         class Scratch:
             pass
         sc = Scratch()
-        sc.T_a, sc.T_d1, sc.T_d2 = z(Ms, H), z(Ms, H), z(Ms, H)
-        sc.T_q, sc.T_h = z(Ms, 3 * H), z(Ms, 4 * H)
-        # second set: the weight gradients of TWO layers share one launch (encoder_backward), so a layer's upstream gradients
-        # stay alive while the next layer's are produced
-        sc.T_d3, sc.T_d4 = z(Ms, H), z(Ms, H)
-        sc.T_q2, sc.T_h2 = z(Ms, 3 * H), z(Ms, 4 * H)
+        sc.T_a = z(Ms, H)
+        # the weight gradients of up to WG layers share one launch (encoder_backward / _wgrad_group), so a layer's upstream gradients
+        # (d qkv, d pre-activation, and the two [M, H] gradients of its residual stream) stay alive while the next layers' are produced:
+        # WG sets of T_q / T_h, 2 WG [M, H] buffers (the caller's D joins their rotation)
+        WG = self._wgrad_group(Ms, H)
+        sc.T_qs, sc.T_hs = [z(Ms, 3 * H) for _ in range(WG)], [z(Ms, 4 * H) for _ in range(WG)]
+        sc.T_ds = [z(Ms, H) for _ in range(2 * WG)]
         sc.delta = f(Ms * nh)
         sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
         sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
@@ -217,15 +218,21 @@ class TowerEngine:
         ops.layernorm_fwd(st.X[st.L], W[f'{prefix}/final_ln/scale'], W[f'{prefix}/final_ln/bias'], st.xf, st.stats[k, 0], st.stats[k, 1])
 
     def _wgrad_group(self, M, H):
-        """Layers whose weight gradients share one grouped launch: 2 when two layers' 256 x 256 output tiles fill the chip better
-        than one layer's (base model: 108 -> 216 of 256 CUs; large: 192 of 256 either way -> 1).  The one-tile-per-workgroup
-        TN kernel (csrc/gemm3.hip) needs K = M tokens long enough to amortise a tile's prologue."""
+        """Layers whose weight gradients share one grouped launch of the one-tile-per-workgroup TN kernel (csrc/gemm3.hip): the count
+        (<= 4) whose 256 x 256 output tiles fill the 256 CUs' rounds best, the smallest on a tie -- base model: 108 tiles per layer ->
+        2 layers = 216 (one round at 84 %; 3 or 4 layers are no better); large: 192 per layer -> 4 layers = 768 = three full rounds
+        (one layer per launch left a quarter of the chip idle: 24 rounds per tower instead of 18).  K = M tokens must be long
+        enough to amortise a tile's prologue."""
         if os.environ.get('MR_WGRAD_PAIR') == '0' or M < 2048:
             return 1
         t = lambda m, n: ((m + 255) // 256) * ((n + 255) // 256)
         tiles = t(4 * H, H) + t(H, 4 * H) + t(H, H) + t(H, 3 * H)
         eff = lambda n: n / (((n + 255) // 256) * 256)
-        return 2 if eff(2 * tiles) > eff(tiles) + 0.05 else 1
+        best = 1
+        for g in range(2, int(os.environ.get('MR_WGRAD_MAX', '4')) + 1):
+            if eff(g * tiles) > eff(best * tiles) + 0.05:
+                best = g
+        return best
 
     def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None):
         """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (D or one of the scratch
@@ -236,12 +243,12 @@ class TowerEngine:
         trainer reduces gradient buckets from there while backward continues)."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
         T_a = self.cur.T_a[:M]
-        T_qs, T_hs = (self.cur.T_q[:M], self.cur.T_q2[:M]), (self.cur.T_h[:M], self.cur.T_h2[:M])
-        # [M, H] gradient buffers: a layer reads Dcur, writes Dmid and Dnext; Dcur / Dmid (and T_q / T_h) stay untouched until
-        # the layer's weight gradients have been issued
-        free = [self.cur.T_d1[:M], self.cur.T_d2[:M], self.cur.T_d3[:M], self.cur.T_d4[:M]]
+        # [M, H] gradient buffers: a layer reads Dcur, writes Dmid and Dnext; Dcur / Dmid (and the layer's T_q / T_h) stay untouched
+        # until the group's weight gradients have been issued
+        group = min(self._wgrad_group(M, H), len(self.cur.T_qs))
+        T_qs, T_hs = [t[:M] for t in self.cur.T_qs], [t[:M] for t in self.cur.T_hs]
+        free = [t[:M] for t in self.cur.T_ds[:2 * group]]
         Dcur = D
-        group = self._wgrad_group(M, H)
         pending, held, done_layers = [], [], []
         k = 2 * st.L + 1
         self._t_ln_bwd(tr, Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
@@ -252,7 +259,7 @@ class TowerEngine:
         jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
-            T_q, T_h = T_qs[l & 1], T_hs[l & 1]
+            T_q, T_h = T_qs[len(done_layers)], T_hs[len(done_layers)]
             Dmid, Dnext = free.pop(), free.pop()
             fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']],
                                             jobs if os.environ.get('MR_NO_GEMM_COLSUM') != '1' else None, transB=True,

@@ -137,17 +137,18 @@ def test_schedules_agree_bit_for_bit(dev):
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize('Mtok,H', [(15424, 768), (5000, 1024)])
-def test_tn_grouped_weight_gradients(dev, Mtok, H):
-    """The eight weight gradients of two transformer layers in ONE launch of the TN ping-pong kernel (dW = X^T . dY)."""
+@pytest.mark.parametrize('Mtok,H,layers', [(15424, 768, 2), (5000, 1024, 2), (4616, 1024, 4)])
+def test_tn_grouped_weight_gradients(dev, Mtok, H, layers):
+    """The weight gradients of two (base: 216 tiles) or four (large: 768 tiles = three rounds of the 256 CUs) transformer layers in
+    ONE launch of the TN ping-pong kernel (dW = X^T . dY)."""
     from merlot_reserve_amd import _lib, ops
     lib = _lib.load()
-    shapes = [(4 * H, H), (H, 4 * H), (H, H), (H, 3 * H)] * 2
+    shapes = [(4 * H, H), (H, 4 * H), (H, H), (H, 3 * H)] * layers
     xs = [rnd((Mtok, m), dev, seed=20 + i) for i, (m, n) in enumerate(shapes)]
     dys = [rnd((Mtok, n), dev, scale=0.05, seed=40 + i) for i, (m, n) in enumerate(shapes)]
     outs = [torch.full((m, n), float('nan'), dtype=BF16, device=dev) for m, n in shapes]
     ws = torch.zeros(16 << 20, device=dev)
-    lib.mr_set_option(b'gemm3', 256)
+    lib.mr_set_option(b'gemm3', 256)          # (forced: the grouped launch must take all of them, whatever the tile count)
     try:
         ops.gemm_grouped([ops.gemm_args(x, dy, o, transA=True, ws=ws) for x, dy, o in zip(xs, dys, outs)])
     finally:
