@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const G256Args ga) {
 #define MR_EPI_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #include "gemm3_epilogue.inc"
 #undef MR_EPI_ROW_FENCE
+#ifndef MR_G3_NOSTORE
             have_stores = true;
+#endif
         }
         ++qc;
         cm0 = item_m0(qc);
