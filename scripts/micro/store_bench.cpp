@@ -37,25 +37,27 @@ __global__ __launch_bounds__(512) void k(unsigned short* C, int M, int N, int ti
 }
 
 int main(int argc, char** argv) {
-    const int M = 15424, N = argc > 1 ? atoi(argv[1]) : 3072, delay = argc > 2 ? atoi(argv[2]) : 0;
+    const int M = argc > 5 ? atoi(argv[5]) : 15424, N = argc > 1 ? atoi(argv[1]) : 3072, delay = argc > 2 ? atoi(argv[2]) : 0, grid = argc > 3 ? atoi(argv[3]) : 256;
+    const int Mw = argc > 4 ? atoi(argv[4]) : M;          // rows actually written (fewer tiles for a small grid)
     unsigned short* C;
     hipMalloc(&C, (size_t)M * N * 2);
-    const int tm = (M + 255) / 256, tn = N / 128;
+    const int tm = (Mw + 255) / 256, tn = N / 128;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int pat = 0; pat < 3; ++pat) {
         float best = 1e9;
         for (int r = 0; r < 5; ++r) {
             hipEventRecord(e0);
-            if (pat == 0) k<0><<<256, 512>>>(C, M, N, tm, tn, delay);
-            if (pat == 1) k<1><<<256, 512>>>(C, M, N, tm, tn, delay);
-            if (pat == 2) k<2><<<256, 512>>>(C, M, N, tm, tn, delay);
+            if (pat == 0) k<0><<<grid, 512>>>(C, M, N, tm, tn, delay);
+            if (pat == 1) k<1><<<grid, 512>>>(C, M, N, tm, tn, delay);
+            if (pat == 2) k<2><<<grid, 512>>>(C, M, N, tm, tn, delay);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        printf("N=%d delay=%d pattern %d: %.1f us  %.2f TB/s\n", N, delay, pat, best * 1e3, (double)M * N * 2 / (best * 1e-3) / 1e12);
+        printf("N=%d delay=%d grid=%d rows=%d pattern %d: %.1f us  %.2f TB/s  (%.1f B/clk/CU at 2.1 GHz)\n", N, delay, grid, Mw, pat, best * 1e3, (double)Mw * N * 2 / (best * 1e-3) / 1e12,
+               (double)Mw * N * 2 / (best * 1e-3) / grid / 2.1e9);
     }
     return 0;
 }
