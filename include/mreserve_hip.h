@@ -121,7 +121,7 @@ int64_t mr_colsum_nparts(int64_t rows);
 int mr_colsum(const void* x, int64_t ldx, int64_t rows, int64_t N, void* out, void* partials, void* stream);
 
 /* ---- several deferred column reductions in ONE launch (the 2 LayerNorm + 2 bias gradients of a transformer layer):
- * out0[c] = bf16(sum_p partials[p, c]) for c < split, out1[c - split] for split <= c < ncols; fixed order. count <= 8. */
+ * out0[c] = bf16(sum_p partials[p, c]) for c < split, out1[c - split] for split <= c < ncols; fixed order. count <= 16. */
 typedef struct {
     const float* partials;
     int32_t nparts, ncols, split;

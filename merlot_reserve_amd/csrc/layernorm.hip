@@ -225,7 +225,7 @@ static void launch_reduce(const float* partials, int nparts, int ncols, int spli
 // Several independent reductions in ONE launch (the LayerNorm and bias gradients of a transformer layer): single level,
 // block = 32 columns of one job x 32 row groups (a row segment = one 128-byte line), fixed summation order.  (64 columns x 16 groups
 // left half of the CUs without a block and every thread with 4 dependent rounds of loads for the 244 partial rows of an fc1 bias: 11.7 us.)
-constexpr int MAX_JOBS = 8;
+constexpr int MAX_JOBS = 16;
 struct ReduceBatch {
     int count;
     int blk_start[MAX_JOBS + 1];

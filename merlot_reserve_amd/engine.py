@@ -61,19 +61,23 @@ class TowerEngine:
         WG = self._wgrad_group(Ms, H)
         sc.T_qs, sc.T_hs = [z(Ms, 3 * H) for _ in range(WG)], [z(Ms, 4 * H) for _ in range(WG)]
         sc.T_ds = [z(Ms, H) for _ in range(2 * WG)]
+        sc.WG = WG
         sc.delta = f(Ms * nh)
         sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
         sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
         sc.cs_ws = ops.colsum_workspace(4 * H, dev)
-        # a layer's four deferred reductions (2 LayerNorm, 2 bias) each keep their partial rows until the layer's
-        # single mr_reduce_partials launch
-        sc.ln_ws2 = ops.layernorm_bwd_workspace(H, dev)
-        sc.cs_ws2 = ops.colsum_workspace(4 * H, dev)
+        # A layer's four deferred reductions (2 LayerNorm, 2 bias) keep their partial rows until ONE mr_reduce_partials launch per
+        # weight-gradient GROUP of layers (engine._wgrad_group: 2 base, 4 large) -- the gradients are not needed before the group's
+        # layer_done: one set of partial-row workspaces per position in the group
+        sc.ln_wsA = [ops.layernorm_bwd_workspace(H, dev) for _ in range(WG)]
+        sc.ln_wsB = [ops.layernorm_bwd_workspace(H, dev) for _ in range(WG)]
+        sc.cs_wsA = [ops.colsum_workspace(4 * H, dev) for _ in range(WG)]
+        sc.cs_wsB = [ops.colsum_workspace(4 * H, dev) for _ in range(WG)]
         # per-(tile, wave) column-sum partials written by the d(pre-activation) GEMM's epilogue (the fc1 bias gradient)
-        sc.cs_fused = f(4 * ((Ms + 255) // 256) * 4 * H)
+        sc.cs_fused = [f(4 * ((Ms + 255) // 256) * 4 * H) for _ in range(WG)]
         # per-(sequence, block) column-sum partials written by the attention backward kernels (the qkv bias gradient): at most
         # one row per 16 positions (short sequences) of [3H]
-        sc.cs_attn = f(((Ms + 15) // 16 + 64) * 3 * H)
+        sc.cs_attn = [f(((Ms + 15) // 16 + 64) * 3 * H) for _ in range(WG)]
         # tower-level reductions (pre / final LayerNorm, pooling and projection biases) keep their partial rows in these until
         # the tower's ONE mr_reduce_partials launch (they used to be two latency-bound launches each)
         sc.tower_ln_ws = [ops.layernorm_bwd_workspace(H, dev) for _ in range(2)]
@@ -261,20 +265,21 @@ class TowerEngine:
             n = self._names(prefix, l)
             T_q, T_h = T_qs[len(done_layers)], T_hs[len(done_layers)]
             Dmid, Dnext = free.pop(), free.pop()
-            fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused, G[n['bb1']],
+            gi = len(done_layers)               # position in the weight-gradient group: its own partial-row workspaces
+            fused_bb1 = ops.gemm_colsum_job(Dcur, W[n['w2']], T_h, self.cur.cs_fused[gi], G[n['bb1']],
                                             jobs if os.environ.get('MR_NO_GEMM_COLSUM') != '1' else None, transB=True,
                                             aux=st.hpre[l], ws=self.cur.gemm_ws)            # d hpre (+ its column sums = d bias)
             self.gemm(T_h, W[n['w1']], T_a, transB=True)                                    # d ln2
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
-                              G[n['g2']], G[n['b2']], self.cur.ln_ws, dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
+                              G[n['g2']], G[n['b2']], self.cur.ln_wsA[gi], dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
             self.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
             fuse_q = jobs is not None and os.environ.get('MR_NO_ATTN_COLSUM') != '1'          # (A/B switch)
             ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh,
-                              colsum_ws=self.cur.cs_attn, bias_grad=G[n['bqkv']], jobs=jobs if fuse_q else None)   # (+ column sums of T_q = d bias)
+                              colsum_ws=self.cur.cs_attn[gi], bias_grad=G[n['bqkv']], jobs=jobs if fuse_q else None)   # (+ column sums of T_q = d bias)
             if not fused_bb1:
-                ops.colsum(T_h, G[n['bb1']], self.cur.cs_ws, jobs=jobs)
+                ops.colsum(T_h, G[n['bb1']], self.cur.cs_wsA[gi], jobs=jobs)
             if not fuse_q:
-                ops.colsum(T_q, G[n['bqkv']], self.cur.cs_ws2, jobs=jobs)
+                ops.colsum(T_q, G[n['bqkv']], self.cur.cs_wsB[gi], jobs=jobs)
             self.gemm(T_q, W[n['wqkv']], T_a, transB=True)                                  # d ln1
             pending += [self.gemm_args(st.hact[l], Dcur, G[n['w2']], transA=True),
                         self.gemm_args(st.ln2[l], T_h, G[n['w1']], transA=True),
@@ -283,10 +288,10 @@ class TowerEngine:
             held += [Dcur, Dmid]          # (the caller's D joins the rotation once its layer's weight gradients are issued)
             done_layers.append(l)
             ops.layernorm_bwd(T_a, st.X[l], W[n['g1']], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1], Dnext,
-                              G[n['g1']], G[n['b1']], self.cur.ln_ws2, dx_add=Dmid, jobs=jobs)   # Dnext = d X[l]
-            if jobs is not None:
-                ops.reduce_partials(jobs)          # the layer's 2 LayerNorm + 2 bias gradients: one launch
+                              G[n['g1']], G[n['b1']], self.cur.ln_wsB[gi], dx_add=Dmid, jobs=jobs)   # Dnext = d X[l]
             if len(done_layers) == group or l == 0:
+                if jobs is not None:
+                    ops.reduce_partials(jobs)      # the group's 2 LayerNorm + 2 bias gradients per layer: one launch (<= 16 jobs)
                 ops.gemm_grouped(pending)
                 free += held
                 if layer_done is not None:

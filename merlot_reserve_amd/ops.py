@@ -232,10 +232,10 @@ def colsum(x, out, partials, jobs=None):
 
 @_timed('layernorm+reductions')
 def reduce_partials(jobs):
-    """Runs the deferred column reductions (<= 8 per launch) and clears the list."""
+    """Runs the deferred column reductions (<= 16 per launch) and clears the list."""
     while jobs:
-        chunk = jobs[:8]
-        del jobs[:8]
+        chunk = jobs[:16]
+        del jobs[:16]
         arr = (_lib.ReduceJob * len(chunk))(*chunk)
         check(_lib.load().mr_reduce_partials(arr, len(chunk), _stream()), 'mr_reduce_partials')
 
