@@ -375,7 +375,7 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
 extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream) {
     MR_CHECK_ARG(list != nullptr && count >= 1, "mr_gemm_grouped: empty list");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (use_gemm256() && count <= 16 && mr_gemm3_tn_grouped(list, count, s)) {      // weight gradients: the TN ping-pong kernel
+    if (use_gemm256() && count <= 20 && mr_gemm3_tn_grouped(list, count, s)) {      // weight gradients: the TN ping-pong kernel
         MR_CHECK_LAUNCH("mr_gemm_grouped (ping-pong kernel)");
         return MR_OK;
     }

@@ -475,12 +475,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
 // "TN" variant for the weight gradients:  C[M,N] = A^T . B with A stored [K, M] and B stored [K, N] (activations x upstream
 // gradients, the contraction index = tokens is the ROW index of both).  Same two-group ping-pong k-loop; the operand tiles are
 // [64 k][256] images read with ds_read_b64_tr_b16 (two per MFMA operand).  One 256 x 256 output tile per workgroup, no
-// persistence (K = tokens is long: 93-241 k-tiles, the prologue and the plain bf16 epilogue are < 2 % of a tile), up to 16
+// persistence (K = tokens is long: 93-241 k-tiles, the prologue and the plain bf16 epilogue are < 2 % of a tile), up to 20
 // problems per launch: the weight gradients of TWO transformer layers fill the chip without split-K (216 tiles for the base
 // model) where one layer's four are 108; FOUR layers of the large model are 768 tiles = three full rounds where one layer's 192
 // leave a quarter of the CUs idle.
 struct TNProb { const void* A; const void* B; void* C; int M, N, lda, ldb, ldc, pad; };
-constexpr int TN_MAXG = 16;
+constexpr int TN_MAXG = 20;
 struct TNArgs { int count, K; int tile_start[TN_MAXG + 1]; int tiles_n[TN_MAXG]; TNProb p[TN_MAXG]; };
 
 __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {

@@ -238,13 +238,16 @@ class TowerEngine:
                 best = g
         return best
 
-    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None):
+    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None, extra_wgrads=None):
         """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (D or one of the scratch
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
         gradients of a layer -- of TWO layers when that fills the chip better (_wgrad_group) -- are deferred to ONE grouped
         GEMM launch (no split-K).
         layer_done(l): called once every parameter gradient of layers >= l is final on the issuing stream (the data-parallel
-        trainer reduces gradient buckets from there while backward continues)."""
+        trainer reduces gradient buckets from there while backward continues).
+        extra_wgrads: [(x, dy, out)] weight gradients of the tower's head over the SAME tokens (attention-pool key / value
+        projections, the joint head): they join the FIRST group's launch when its tiles still fit the same number of CU rounds
+        (base: 216 + 9 per extra of 256) -- alone each is a 9-tile split-K launch of ~65 us --, else they are launched here."""
         W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
         T_a = self.cur.T_a[:M]
         # [M, H] gradient buffers: a layer reads Dcur, writes Dmid and Dnext; Dcur / Dmid (and the layer's T_q / T_h) stay untouched
@@ -254,6 +257,16 @@ class TowerEngine:
         free = [t[:M] for t in self.cur.T_ds[:2 * group]]
         Dcur = D
         pending, held, done_layers = [], [], []
+        if extra_wgrads:
+            t256 = lambda m, n: ((m + 255) // 256) * ((n + 255) // 256)
+            tiles = group * (t256(4 * H, H) + t256(H, 4 * H) + t256(H, H) + t256(H, 3 * H))
+            extra = sum(t256(x.shape[1], dy.shape[1]) for x, dy, _ in extra_wgrads)
+            rounds = lambda n: (n + 255) // 256
+            if M >= 2048 and 4 * group + len(extra_wgrads) <= 20 and rounds(tiles + extra) == rounds(tiles) and os.environ.get('MR_NO_WGRAD_EXTRA') != '1':
+                pending += [self.gemm_args(x, dy, out, transA=True) for x, dy, out in extra_wgrads]
+            else:
+                for x, dy, out in extra_wgrads:
+                    self.gemm(x, dy, out, transA=True)
         k = 2 * st.L + 1
         self._t_ln_bwd(tr, Dcur, st.X[st.L], W[f'{prefix}/final_ln/scale'], st.stats[k, 0], st.stats[k, 1], Dcur,
                        G[f'{prefix}/final_ln/scale'], G[f'{prefix}/final_ln/bias'])
@@ -334,11 +347,11 @@ class TowerEngine:
         self.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
         self.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
         self._t_colsum(tr, d_k, G[f'{prefix_pool}/key/bias'])
-        self.gemm(st.xf, d_k, G[f'{prefix_pool}/key/kernel'], transA=True)
         self.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
         self._t_colsum(tr, d_v, G[f'{prefix_pool}/value/bias'])
-        self.gemm(st.xf, d_v, G[f'{prefix_pool}/value/kernel'], transA=True)
         self.gemm(d_v, W[f'{prefix_pool}/value/kernel'], D, transB=True, residual=D)
+        # the key / value weight gradients (K = all M tokens) ride in the encoder's first grouped weight-gradient launch
+        extra = [(st.xf, d_k, G[f'{prefix_pool}/key/kernel']), (st.xf, d_v, G[f'{prefix_pool}/value/kernel'])]
         ops.rows_mean_bwd(d_qin, pool_rows, D)
         # cls head
         cls_in = self._cls_view(st.xf, st.nseq, st.S)
@@ -346,7 +359,7 @@ class TowerEngine:
         self.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
         Dc = self._cls_view(D, st.nseq, st.S)
         self.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
-        D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done, tr=tr)
+        D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done, tr=tr, extra_wgrads=extra)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
 
@@ -641,10 +654,10 @@ class PretrainEngine(TowerEngine):
         ops.segment_sum([self.dXpool], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.d_hj)
         trj = self._begin_tower_reductions()
         self._t_colsum(trj, self.d_hj, G['head/bias'])
-        self.gemm(tj.xf, self.d_hj, G['head/kernel'], transA=True)
         Dj = self.Dj
         self.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
-        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj, tr=trj)
+        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj, tr=trj,
+                                   extra_wgrads=[(tj.xf, self.d_hj, G['head/kernel'])])
         self._flush_tower_reductions(trj)
         main.wait_stream(self.side_stream)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
