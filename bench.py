@@ -296,34 +296,47 @@ def main():
         n = len(ops.GEMM_PROFILE)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
-        # the same launches with the side stream disabled: each GEMM then has the GPU to itself (in the step two towers
-        # run concurrently, so a launch's duration above includes the CUs it yields to the other stream); this pass also
-        # times EVERY launch by kernel family
-        os.environ['MR_NO_SIDE_STREAM'] = '1'
-        ops.GEMM_PROFILE, ops.FAMILY_PROFILE = [], {}
-        run(nprof, graph=False)
-        torch.cuda.synchronize()
-        ms_x = sum(r[0].elapsed_time(r[1]) for r in ops.GEMM_PROFILE)
-        fl_x = sum(r[2] for r in ops.GEMM_PROFILE)
-        breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in ops.FAMILY_PROFILE.items()}
-        launches = {k: len(v) // nprof for k, v in ops.FAMILY_PROFILE.items()}
-        breakdown['gemm'], launches['gemm'] = round(ms_x / nprof, 3), len(ops.GEMM_PROFILE) // nprof
+        # the same launches with the side stream disabled: the two towers no longer share the GPU (in the step a launch's duration
+        # above includes the CUs it yields to the other tower's kernels); the gradient buckets' Adam / transposes still run on their
+        # own stream, as in the replayed step -- these durations are what rocprofv3's per-kernel averages of the replay show (profiles/)
+        def timed_pass(env):
+            for k in env:
+                os.environ[k] = '1'
+            ops.GEMM_PROFILE, ops.FAMILY_PROFILE = [], {}
+            run(nprof, graph=False)
+            torch.cuda.synchronize()
+            gp, fp = ops.GEMM_PROFILE, ops.FAMILY_PROFILE
+            ops.GEMM_PROFILE, ops.FAMILY_PROFILE = None, None
+            for k in env:
+                del os.environ[k]
+            return gp, fp
+        gp, _ = timed_pass(['MR_NO_SIDE_STREAM'])
+        ms_x = sum(r[0].elapsed_time(r[1]) for r in gp)
+        fl_x = sum(r[2] for r in gp)
+        # ... and with the buckets' kernels issued in line as well (MR_NO_COMM_STREAM): every launch of the step ALONE on the GPU.  A
+        # whole-CU GEMM launched beside a bucket's Adam kernel waits for CUs (the audio tower's first 20-us weight gradient reads 450 us
+        # in every step), which the pass above counts as GEMM time: this one is the kernels' own time, and the per-family breakdown
+        gp, fam = timed_pass(['MR_NO_SIDE_STREAM', 'MR_NO_COMM_STREAM'])
+        ms_xx = sum(r[0].elapsed_time(r[1]) for r in gp)
+        fl_xx = sum(r[2] for r in gp)
+        breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in fam.items()}
+        launches = {k: len(v) // nprof for k, v in fam.items()}
+        breakdown['gemm'], launches['gemm'] = round(ms_xx / nprof, 3), len(gp) // nprof
         if os.environ.get('MR_BENCH_GEMM_SHAPES'):      # diagnostic: per-shape totals of the exclusive pass -> text file
             agg = {}
-            for e0, e1, fl_, tag in ops.GEMM_PROFILE:
+            for e0, e1, fl_, tag in gp:
                 a = agg.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl_
             with open(os.environ['MR_BENCH_GEMM_SHAPES'], 'w') as f:
                 f.write('# (M, N, K, transA, transB, bias, rot, c2, act, residual, aux) | (grouped, n, K): launches/step ms/step avg_us TFLOP/s\n')
                 for tag, (n_, ms_, fl_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     f.write(f'{str(tag):70s} {n_ // nprof:4d} {ms_ / nprof:7.3f} {ms_ / n_ * 1e3:8.1f} {fl_ / ms_ / 1e9:7.1f}\n')
-        ops.GEMM_PROFILE, ops.FAMILY_PROFILE = None, None
-        del os.environ['MR_NO_SIDE_STREAM']
         breakdown = {'ms_per_step': breakdown, 'launches_per_step': launches, 'sum_ms': round(sum(breakdown.values()), 3),
-                     'note': 'exclusive HIP-event duration of every launch, by kernel family, in an eager pass with the side stream off; '
-                             'the graph-replayed step overlaps the towers on two streams and the optimizer / reductions on a third, '
-                             'so ms_per_step <= sum_ms'}
+                     'note': 'HIP-event duration of every launch alone on the GPU, by kernel family: an eager pass with the side stream and the '
+                             'gradient-bucket stream off; the graph-replayed step overlaps the towers on two streams and the optimizer / '
+                             'reductions on a third, so ms_per_step <= sum_ms'}
         ach_x = fl_x / (ms_x * 1e-3) / 1e12
+        ach_xx = fl_xx / (ms_xx * 1e-3) / 1e12
         traffic, traffic_src = None, None       # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
         for cand in ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
             pmc = os.path.join(ROOT, 'profiles', cand)
@@ -335,11 +348,12 @@ def main():
                 traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
                 traffic_src = cand
                 break
-        # `achieved` = the launches timed one at a time (side stream off): that is the kernel's own duration and what rocprofv3's
-        # per-kernel average of the graph-replayed step shows (profiles/); `achieved_concurrent` = the same launches timed while
-        # the other tower's kernels share the GPU on the second stream (durations then include the CUs yielded to them)
-        roof = {'bound': 'mfma', 'kernel': 'g3::gemm3_kernel<*> / gemm3_tn_kernel (ping-pong), g256::gemm256_kernel<*>, gemm_bf16_kernel for small shapes', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic,
+        # `achieved` = the launches with the side stream off: what rocprofv3's per-kernel averages of the graph-replayed step show
+        # (profiles/); `achieved_concurrent` = the same launches timed while the other tower's kernels share the GPU on the second
+        # stream (durations then include the CUs yielded to them); `achieved_alone` = with the gradient-bucket stream off too
+        roof = {'bound': 'mfma', 'kernel': 'g4::gemm4_kernel<*> (one wave per SIMD), g3::gemm3_kernel<*> / gemm3_tn_kernel (ping-pong), g256::gemm256_kernel<*>, gemm_bf16_kernel for small shapes', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12),
+                'achieved_alone': ach_xx, 'frac_alone': ach_xx / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic,
                 'traffic_unit': f'HBM-side bytes per GEMM launch (PMC, profiles/{traffic_src})', 'launches': n,
                 'avg_launch_us': ms_x * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
 

@@ -201,7 +201,9 @@ class Trainer:
         Buckets are enqueued in ONE program order on ONE stream, the same on every rank, as RCCL requires."""
         _, lo, hi = next(b for b in self.buckets if b[0] == key)
         self.bucket_log.append(key)
-        cs = self.comm_stream
+        # (MR_NO_COMM_STREAM=1, bench.py's exclusive timing pass: the bucket's kernels are issued in line -- beside a bucket's Adam kernel a
+        # whole-CU GEMM of either tower waits for CUs, and its HIP-event duration would include that wait)
+        cs = producer if os.environ.get('MR_NO_COMM_STREAM') == '1' else self.comm_stream
         cs.wait_stream(producer)
         with torch.cuda.stream(cs):
             g = self.params.grad[lo:hi]
