@@ -304,6 +304,9 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s);
 bool mr_gemm3_eligible(const mr_gemm_args* a);
 int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s);
 bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s);
+// gemm5.hip
+bool mr_gemm5_wanted(const mr_gemm_args* a);
+int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s);
 
 extern int g_mr_opt_v1_only;        // mr_set_option("gemm_v1_only")
 static int use_gemm256() {
@@ -335,6 +338,7 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
     MR_CHECK_ARG(!a->colsum || (use_gemm256() && mr_gemm_colsum_supported(a) && a->ldcs >= a->N && ((uintptr_t)a->colsum % 16) == 0 && a->ldcs % 4 == 0),
                  "mr_gemm: colsum is only produced by the 256-row kernel with the aux epilogue (ask mr_gemm_colsum_supported)");
+    if (use_gemm256() && mr_gemm5_wanted(a)) return mr_gemm5_launch(a, static_cast<hipStream_t>(stream));      // two workgroups per CU
     if (use_gemm256() && mr_gemm3_eligible(a)) {
         mr_gemm3_launch(a, static_cast<hipStream_t>(stream));
         MR_CHECK_LAUNCH("mr_gemm (ping-pong kernel)");

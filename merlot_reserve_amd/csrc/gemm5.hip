@@ -1,0 +1,377 @@
+// Fifth-generation bf16 MFMA GEMM for gfx950, "NT" operands:  C[M,N] = A[M,K] . B[N,K]^T, both K-contiguous.  Same interface, epilogue
+// text (gemm3_epilogue.inc) and tile-list decode as the ping-pong (gemm3.hip) and one-wave-per-SIMD (gemm4.hip) kernels; what
+// changes is who shares a CU:
+//
+// TWO independent workgroups per CU.  A workgroup is FOUR waves (one per SIMD) as 2 (M) x 2 (N) on a 256 x 128 tile: a wave owns
+// 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 -- the ping-pong kernel's wave tile -- and at most 256 registers, so
+// two workgroups are resident per CU and every SIMD hosts one wave of each.  They share nothing but the CU: each has its own
+// barrier, its own 72-KiB LDS ring and its own tile list, so one workgroup's epilogue -- 8 k cycles of GELU + gelu' on the vector
+// ALU, the bf16 conversions, the ~3.5 k-cycle drain of its stores (vmcnt retires in order) -- runs UNDER the other's k-loop instead
+// of idling the matrix pipe of the whole CU, which is what bounds the K = 768 problems in the one-workgroup-per-CU kernels (a tile's
+// fixed cost there is 6.6-9.2 us of a 23-26 us tile: DESIGN.md section 3).  Persistent workgroups with equal tile lists would run in
+// lockstep (both in their k-loops, then both in their epilogues), and the phase between two residents is neutrally stable, so it is
+// SET at the start: the workgroup in the second wave slot of its SIMDs sleeps for about one k-loop first (a speed knob only --
+// nothing depends on which workgroups share a CU).
+//
+// k-loop: BK = 32 steps (64-byte LDS rows), a 3-stage ring of (256 + 128) x 32 operand images = 24 KiB per stage, filled by LDS-DMA
+// three steps ahead: step t multiplies the fragments of stage t from registers (read during step t-1), reads the fragments of stage
+// t+1 from LDS and requests stage t+3 into the buffer stage t was read from; it ends with
+//     s_waitcnt vmcnt(6) (own pieces of stage t+2 landed: all but the 6 just requested) . lgkmcnt(0) (own reads of stage t+1 done) . s_barrier
+// behind which stage t+2 is visible to every wave and stage t+1's buffer is free for the requests of step t+1: safe by construction.
+// Per step and wave: 32 MFMAs, 12 ds_read_b128, 6 LDS-DMA requests (4 A + 2 B pieces of 1 KiB), each behind a pair of MFMAs in
+// source order pinned by scheduling barriers (as in gemm4.hip).  The requests are unconditional (a cursor without an item requests
+// from an empty descriptor: zero fill into a stage nobody reads), the cursor runs across output tiles, and so do the fragment reads.
+// 64-byte rows: a 16-row fragment block is one 1-KiB LDS-DMA piece (lane l -> row l >> 2, 16-byte slot l & 3); slot = chunk ^
+// ((0 - (row >> 2)) & 3) on the SOURCE address and on the ds_read_b128 address makes the reads conflict-free over the hardware's
+// four 16-lane groups (checked by enumeration: every group covers 16 distinct 16-byte columns of the 256-byte bank row).
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "gemm256_sched.h"
+
+namespace g5 {
+
+using namespace g256;
+
+#ifndef MR_G3_AUX_C
+#define MR_G3_AUX_C 0
+#endif
+#ifndef MR_G3_AUX_C2
+#define MR_G3_AUX_C2 0
+#endif
+
+constexpr int BN5 = 128;
+constexpr int STG_A = 256 * 64, STG_B = BN5 * 64, STG = STG_A + STG_B, NSTG = 3;
+constexpr int LDS5 = NSTG * STG;
+static_assert(LDS5 == 72 * 1024 && 2 * LDS5 <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ int swz5(int row) { return (0 - ((row >> 2) & 3)) & 3; }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const int stagger_mode, const int stagger_units) {
+    constexpr int NJ = 4, WCOLS = 64;
+    // store instructions a wave issues per tile (all unconditional, see gemm3_epilogue.inc): the first step behind an epilogue may
+    // leave them -- and its own 6 requests -- outstanding while it waits for the stage requested AHEAD of the epilogue
+    constexpr int NST = 8 * (NJ / 2) * (MODE == 2 ? 2 : 1);
+    constexpr int WAIT_FIRST = 6 + NST;
+    static_assert(WAIT_FIRST <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) char smem[LDS5];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
+    const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+    int m0v, n0v;
+    item_pp(ga, bperm, lane, G, BN5, m0v, n0v);
+    auto item_m0 = [&](int q) -> int { const int r = __builtin_amdgcn_readlane(m0v, q & 63); return q < 64 ? r : -1; };
+    auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
+    if (item_m0(0) < 0) return;
+    const mr_gemm_args& p0 = ga.p[0];
+    const int nks = (int)(p0.K >> 5);
+    const unsigned lda2 = (unsigned)p0.lda * 2u, ldb2 = (unsigned)p0.ldb * 2u;
+    const char* const Aptr = static_cast<const char*>(p0.A);
+    const char* const Bptr = static_cast<const char*>(p0.B);
+    const int a_extent = (int)(((p0.M - 1) * p0.lda + p0.K) * 2), b_extent = (int)(((p0.N - 1) * p0.ldb + p0.K) * 2);
+    auto rel = [&](int piece, unsigned ld2) -> unsigned {      // byte offset of this lane's chunk of 1-KiB piece `piece` in an item at row 0
+        const int row = piece * 16 + (lane >> 2);
+        return (unsigned)row * ld2 + (unsigned)(((lane & 3) ^ swz5(row)) * 16);
+    };
+    // one per-lane offset per operand: a wave's pieces are 16 rows apart, a wave-uniform stride that rides in the scalar offset
+    const unsigned pao = rel(wave * 4, lda2), pbo = rel(wave * 2, ldb2);
+    const unsigned pstep_a = 16u * lda2, pstep_b = 16u * ldb2;
+    // fragment reads: lane (g, li) of a 16-row block reads k-chunk g of row li
+    const int fo = li * 64 + ((g ^ swz5(li)) << 4);
+    const int fa = wr * 8192 + fo, fb = STG_A + wc * 4096 + fo;
+
+    // The phase between the two workgroups of a CU (see the header): the one whose waves sit in the odd wave slots waits ~ one k-loop.
+    if (stagger_mode != 0) {
+        bool late;
+        if (stagger_mode == 1) late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;          // HW_REG_HW_ID.WAVE_ID bit 0
+        else if (stagger_mode == 2) late = (int)blockIdx.x >= (G >> 1);
+        else late = ((blockIdx.x >> 3) & 1) != 0;
+        if (late)
+            for (int n = 0; n < stagger_units; ++n) __builtin_amdgcn_s_sleep(32);        // 2048 cycles each
+    }
+
+    // ---- ONE issue cursor for both operands, three steps ahead of the compute cursor, across item boundaries ----
+    int ik = 0, qi = 0, ist = 0;
+    __amdgpu_buffer_rsrc_t ra_c, rb_c;
+    auto set_item = [&](int q_) {
+        const int mi = item_m0(q_), ni = item_n0(q_);
+        const int aoff = (mi >= 0 ? mi : 0) * (int)lda2, boff = (mi >= 0 ? ni : 0) * (int)ldb2;
+        ra_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Aptr) + aoff, 0, mi >= 0 ? a_extent - aoff : 0, 0x00020000);
+        rb_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Bptr) + boff, 0, mi >= 0 ? b_extent - boff : 0, 0x00020000);
+    };
+    set_item(0);
+#define G5_ISSUE_ALL()                                                                                                  \
+    do {                                                                                                                \
+        char* st_ = smem + ist * STG;                                                                                   \
+        const unsigned so_ = (unsigned)ik * 64u;                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * 4096 + j_ * 1024), 16, pao, so_ + j_ * pstep_a, 0, 0); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * 2048 + j_ * 1024), 16, pbo, so_ + j_ * pstep_b, 0, 0); \
+    } while (0)
+#define G5_ADVANCE()                                                                                                    \
+    do {                                                                                                                \
+        ist = (ist == NSTG - 1) ? 0 : ist + 1;                                                                          \
+        if (++ik == nks) {                                                                                              \
+            ik = 0;                                                                                                     \
+            set_item(++qi);                                                                                             \
+        }                                                                                                               \
+    } while (0)
+#define G5_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef MR_G5_NOREAD        /* timing-only diagnostic builds (wrong results): scripts/build_g5_variants.sh */
+#define G5_RD(dst, ptr) asm volatile("" : "+v"(dst))
+#else
+#define G5_RD(dst, ptr) (dst) = *reinterpret_cast<const bf16x8*>(ptr)
+#endif
+#ifdef MR_G5_NOBAR
+#define G5_BARRIER() do {} while (0)
+#else
+#define G5_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+    int qc = 0, rs = 0;                 // rs: the stage the NEXT fragments are read from
+    int cm0 = item_m0(0), cn0 = item_n0(0);
+    bool have_stores = false;
+    constexpr bool BIAS = MODE <= 2;
+    f32x4 binit[NJ];
+    auto fetch_bias = [&](int n0_) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) binit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS) {
+            const __bf16* const bp = static_cast<const __bf16*>(p0.bias);
+            if (bp != nullptr) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int gn = n0_ + wc * WCOLS + j * 16 + g * 4;
+                    if (gn < (int)p0.N) {
+                        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bp + gn);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) binit[j][r] = (float)b4[r];
+                    }
+                }
+            }
+        }
+    };
+    fetch_bias(cn0);
+
+    // prologue: stages 0, 1, 2 requested; stage 0 has landed when only the last two are in flight
+    G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE();
+    wait_vmcnt<12>();
+    G5_SB();
+    __builtin_amdgcn_s_barrier();
+    G5_SB();
+    // Fragment registers: the B fragments and the last two A row blocks are double buffered (parity = step & 1: K % 64 == 0, so a
+    // tile's first step has parity 0); A row blocks 0-5 are replaced IN PLACE behind their own MFMAs (72 registers instead of 96:
+    // beside the 128 accumulators the rotary / GELU / column-sum epilogues spill with 96).  The in-place read of row block 5 is the
+    // step's last: it has the 8 MFMAs of row blocks 6 and 7 to land before the step's closing wait.
+    bf16x8 a[6], a67[2][2], b[NJ][2];
+    auto read_frags0 = [&](const char* st) {          // all 12 fragments of a stage into parity 0 (prologue, tile switch)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8*>(st + fb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + fa + i * 1024);
+        a67[0][0] = *reinterpret_cast<const bf16x8*>(st + fa + 6 * 1024);
+        a67[1][0] = *reinterpret_cast<const bf16x8*>(st + fa + 7 * 1024);
+    };
+    read_frags0(smem);
+    wait_vmcnt<6>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G5_SB();
+    __builtin_amdgcn_s_barrier();
+    G5_SB();
+    rs = 1;
+
+    while (cm0 >= 0) {
+        // accumulators TRANSPOSED (mfma(B-frag, A-frag)): the lane holds C[m = .. + li][n = .. + 4 g + r]; bias modes start from the bias
+        f32x4 acc[8][NJ];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = binit[j];
+
+        // one k-step: multiply the fragments of parity CUR, read the next step's into parity 1 - CUR, request three steps ahead
+        auto step = [&](auto cur_c, auto first_c, auto last_c) {
+            constexpr int CUR = decltype(cur_c)::value, NXT = 1 - CUR;
+            constexpr bool FIRST = decltype(first_c)::value;        // the tile's first step: the previous tile's stores may be in flight
+            constexpr bool LAST = decltype(last_c)::value;          // the tile's last step reads no fragments: the next tile's first ones are read behind the epilogue (registers)
+            const char* const rd = smem + rs * STG;
+            char* const st_ = smem + ist * STG;
+            const unsigned so_ = (unsigned)ik * 64u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bf16x8 ar = r < 6 ? a[r < 6 ? r : 0] : a67[r - 6 < 0 ? 0 : r - 6][CUR];
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][CUR], ar, acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][CUR], ar, acc[r][1], 0, 0, 0);
+                G5_SB();
+                if constexpr (!LAST) {               // the double-buffered fragments first: b0..b3, then row blocks 6, 7
+                    if (r < 4) G5_RD(b[r][NXT], rd + fb + r * 1024);
+                    else if (r < 6) G5_RD(a67[r - 4][NXT], rd + fa + (r + 2) * 1024);
+                }
+                if (r < 4) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * 4096 + r * 1024), 16, pao, so_ + r * pstep_a, 0, 0);
+                else if (r < 6) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * 2048 + (r - 4) * 1024), 16, pbo, so_ + (r - 4) * pstep_b, 0, 0);
+                G5_SB();
+                acc[r][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2][CUR], ar, acc[r][2], 0, 0, 0);
+                acc[r][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[3][CUR], ar, acc[r][3], 0, 0, 0);
+                G5_SB();
+                if constexpr (!LAST) {
+                    if (r < 6) G5_RD(a[r], rd + fa + r * 1024);       // in place: this row block's MFMAs are issued
+                }
+                G5_SB();
+            }
+            if (FIRST && have_stores) wait_vmcnt<WAIT_FIRST>();
+            else wait_vmcnt<6>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G5_SB();
+            G5_BARRIER();
+            G5_SB();
+            if constexpr (!LAST) rs = (rs == NSTG - 1) ? 0 : rs + 1;
+            G5_ADVANCE();
+        };
+        step(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
+        for (int t = 1; t + 2 < nks; t += 2) {
+            step(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+            step(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+        }
+        step(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});          // (K % 64 == 0: an even number of steps >= 4)
+
+        // ---------------- epilogue (bf16 output; registers + ordinary loads, no LDS) ----------------
+        {
+            const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
+#define MR_EPI_ROW_FENCE() do {} while (0)
+#include "gemm3_epilogue.inc"
+#undef MR_EPI_ROW_FENCE
+#ifndef MR_G3_NOSTORE
+            have_stores = true;
+#endif
+        }
+        ++qc;
+        cm0 = item_m0(qc);
+        cn0 = item_n0(qc);
+        // the next tile's first fragments (stage `rs`: landed and visible since the barrier of the last step but one); the barrier keeps
+        // the requests of the next step, which refill this stage's buffer, behind every wave's reads
+        if (cm0 >= 0) {
+            read_frags0(smem + rs * STG);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G5_SB();
+            __builtin_amdgcn_s_barrier();
+            G5_SB();
+            rs = (rs == NSTG - 1) ? 0 : rs + 1;
+        }
+    }
+    // the ring's last requests (zero fill) and the stores retire before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+}  // namespace g5
+
+extern int g_mr_opt_gemm_cus;        // mr_set_option("gemm_cus"), see gemm3.hip
+extern int g_mr_opt_gemm5;           // mr_set_option("gemm5"): -1 = default (MR_GEMM5, or the shapes measured faster) | 0 = off | 1 = every problem the kernel can take
+extern int g_mr_opt_gemm5_stagger;   // mr_set_option("gemm5_stagger"): -1 = default | 0 = none | 1 = by wave slot | 2 = upper half of the grid | 3 = by blockIdx bit 3
+
+// Same operand / epilogue contract as the ping-pong kernel (the caller has checked mr_gemm3_eligible's operand conditions).
+bool mr_gemm5_takes(const mr_gemm_args* a) {
+    if (a->transA || !a->transB || a->c_dtype != MR_DT_BF16 || a->K % 64 != 0 || a->K < 128) return false;
+    if (a->M * a->lda * 2 >= (1LL << 31) || a->N * a->ldb * 2 >= (1LL << 31)) return false;
+    {
+        const int64_t last = a->out_grp > 0 ? ((a->M - 1) / a->out_grp) * a->out_grp_stride + a->out_grp_off + (a->M - 1) % a->out_grp : a->M - 1;
+        if ((last * a->ldc + a->N) * 2 >= (1LL << 31)) return false;
+    }
+    const int n_extra = (a->rot_tab != nullptr) + (a->residual != nullptr) + (a->aux != nullptr) + (a->c2 != nullptr);
+    if (n_extra > 1) return false;
+    if ((a->c2 != nullptr) != (a->act == MR_ACT_GELU1702)) return false;
+    if (a->colsum && !a->aux) return false;
+    if (a->bias && (a->residual || a->aux)) return false;
+    const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
+    if (((a->M + 255) / 256) * ((a->N + 127) / 128) > 64 * 2 * ncu) return false;          // <= 64 items per workgroup
+    return true;
+}
+
+int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
+    const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
+    const int64_t slots = 2 * ncu;                      // two workgroups per CU
+    const int64_t tm = (a->M + 255) / 256, tn = (a->N + g5::BN5 - 1) / g5::BN5, nwork = tm * tn;
+    const int64_t gsz = nwork < slots ? nwork : slots;
+    g256::G256Args ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.count = 1; ga.nwork = (int)nwork; ga.splits = 1; ga.kt_per_split = (int)(a->K / 32);
+    if (gsz == slots && nwork >= 2 * slots) {
+        // XCD partition of the tile grid (see G256Args.xmode): fewest rounds first, then least traffic out of L2
+        const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
+        double best = 1e300;
+        for (int px = 1; px <= 8; px *= 2) {
+            const int py = 8 / px;
+            if (px > tm || py > tn) continue;
+            int64_t rounds = 0;
+            for (int xi = 0; xi < px; ++xi)
+                for (int xj = 0; xj < py; ++xj) {
+                    const int64_t hm = (xi + 1) * tm / px - xi * tm / px, hn = (xj + 1) * tn / py - xj * tn / py;
+                    const int64_t r = (hm * hn + slots / 8 - 1) / (slots / 8);
+                    if (r > rounds) rounds = r;
+                }
+            const bool b_fits = b_bytes / py < 2.5e6;
+            const double traffic = a_bytes * py + b_bytes * px * (b_fits ? 1.0 : (double)rounds);
+            const double cost = (double)rounds * 1e12 + traffic;
+            if (cost < best) { best = cost; ga.px = px; ga.py = py; }
+        }
+        if (best < 1e300) { ga.xmode = 1; ga.tm = (int)tm; ga.tn = (int)tn; }
+    }
+    ga.tiles_n[0] = (int)tn;
+    ga.tile_start[0] = 0;
+    for (int k = 1; k <= g256::MAXG; ++k) ga.tile_start[k] = 0x7fffffff;
+    ga.p[0] = *a;
+    int mode = 5;
+    if (a->c2) mode = 2;
+    else if (a->rot_tab) mode = 1;
+    else if (a->residual) mode = 3;
+    else if (a->aux) mode = 4;
+    else if (a->bias) mode = 0;
+    static int st_env = -2, su_env = -2;
+    if (st_env == -2) { const char* e = getenv("MR_G5_STAGGER"); st_env = e ? atoi(e) : -1; }
+    if (su_env == -2) { const char* e = getenv("MR_G5_STAGGER_PCT"); su_env = e ? atoi(e) : -1; }
+    int st_mode = g_mr_opt_gemm5_stagger >= 0 ? g_mr_opt_gemm5_stagger : st_env >= 0 ? st_env : 1;
+    if (gsz <= ncu) st_mode = 0;                          // one workgroup per CU: nobody to be out of phase with
+    // ~ one k-loop alone on the CU: K / 32 steps of 512 MFMA cycles, in units of 2048 cycles (percent knob for experiments)
+    const int pct = su_env >= 0 ? su_env : 100;
+    const int st_units = (int)((a->K / 32) * 600 * pct / 100 / 2048);
+    dim3 grid((unsigned)gsz), block(256);
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("MR_G5_DEBUG"); dbg = e ? atoi(e) : 0; }
+        if (dbg == 1) {
+            dbg = 2;
+            int nb = -1;
+            hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g5::gemm5_kernel<5>, 256, 0);
+            hipFuncAttributes fa_;
+            hipError_t e2_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void*>(g5::gemm5_kernel<5>));
+            fprintf(stderr, "[gemm5] occupancy query: %d blocks / CU (err %d); regs %d, static LDS %zu, scratch %zu (err %d); grid %ld, stagger mode %d units %d\n", nb, (int)e_,
+                    fa_.numRegs, fa_.sharedSizeBytes, fa_.localSizeBytes, (int)e2_, (long)gsz, st_mode, st_units);
+        }
+    }
+#define G5_LAUNCH(MODE) hipLaunchKernelGGL((g5::gemm5_kernel<MODE>), grid, block, 0, s, ga, st_mode, st_units)
+    switch (mode) {
+        case 0: G5_LAUNCH(0); break;
+        case 1: G5_LAUNCH(1); break;
+        case 2: G5_LAUNCH(2); break;
+        case 3: G5_LAUNCH(3); break;
+        case 4: G5_LAUNCH(4); break;
+        default: G5_LAUNCH(5); break;
+    }
+#undef G5_LAUNCH
+    MR_CHECK_LAUNCH("mr_gemm (gemm5)");
+    return MR_OK;
+}
+
+// Which problems go to this kernel: mr_set_option("gemm5") 1 = every one it can take (tests, A/B), 0 = none, -1 = the policy below.
+bool mr_gemm5_wanted(const mr_gemm_args* a) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("MR_GEMM5"); env = e ? atoi(e) : -1; }
+    const int v = g_mr_opt_gemm5 >= 0 ? g_mr_opt_gemm5 : env;
+    if (v == 0 || a->colsum != nullptr && !a->aux) return false;
+    if (!mr_gemm5_takes(a)) return false;
+    if (v == 1) return true;
+    return false;
+}

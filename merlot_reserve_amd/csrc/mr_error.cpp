@@ -26,6 +26,8 @@ int g_mr_opt_gemm3 = 1;
 int g_mr_opt_gemm3_ph = 0;
 int g_mr_opt_gemm4 = -1;
 int g_mr_opt_gemm_cus = 0;
+int g_mr_opt_gemm5 = -1;
+int g_mr_opt_gemm5_stagger = -1;
 extern "C" int mr_set_option(const char* name, int value) {
     if (name && !strcmp(name, "gemm_tile_n")) { g_mr_opt_tile_n = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_v1_only")) { g_mr_opt_v1_only = value; return MR_OK; }
@@ -34,6 +36,8 @@ extern "C" int mr_set_option(const char* name, int value) {
     if (name && !strcmp(name, "gemm3_phases")) { g_mr_opt_gemm3_ph = value; return MR_OK; }
     if (name && !strcmp(name, "gemm4")) { g_mr_opt_gemm4 = value; return MR_OK; }
     if (name && !strcmp(name, "gemm_cus")) { g_mr_opt_gemm_cus = value; return MR_OK; }
+    if (name && !strcmp(name, "gemm5")) { g_mr_opt_gemm5 = value; return MR_OK; }
+    if (name && !strcmp(name, "gemm5_stagger")) { g_mr_opt_gemm5_stagger = value; return MR_OK; }
     mr_set_error("mr_set_option: unknown option '%s'", name ? name : "(null)");
     return MR_EINVAL;
 }

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <string>
 #include "../../include/mreserve_hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -137,6 +138,37 @@ static void time_variants(const Case& c, bool colsum, double budget_ms, double o
     mr_set_option("gemm4", -1);
 }
 
+
+// gemm5 (two workgroups per CU): [0] = the shipped default path, [1..3] = gemm5 with stagger mode 0 / 1 / 2
+static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[4]) {
+    mr_gemm_args g;
+    hipEvent_t e0[4], e1[4];
+    for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
+    auto launch = [&](int v, int set) {
+        mr_set_option("gemm5", v == 0 ? 0 : 1);
+        if (v) mr_set_option("gemm5_stagger", v - 1);
+        setup_args(&g, c, set, colsum);
+        if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); }
+    };
+    double tot[4] = {0, 0, 0, 0}; int n[4] = {0, 0, 0, 0};
+    for (int phase = 0; phase < 2; ++phase) {
+        double spent = 0; int it = 0;
+        while (spent < budget_ms) {
+            for (int v = 0; v < 4; ++v) {
+                CK(hipEventRecord(e0[v], nullptr));
+                for (int r = 0; r < 4; ++r) launch(v, (it + r) % 3);
+                CK(hipEventRecord(e1[v], nullptr));
+            }
+            CK(hipEventSynchronize(e1[3]));
+            for (int v = 0; v < 4; ++v) { float ms; CK(hipEventElapsedTime(&ms, e0[v], e1[v])); spent += ms; if (phase) { tot[v] += ms; n[v] += 4; } }
+            ++it;
+        }
+    }
+    for (int v = 0; v < 4; ++v) out_us[v] = tot[v] * 1000.0 / n[v];
+    mr_set_option("gemm5", -1);
+    mr_set_option("gemm5_stagger", -1);
+}
+
 static int check_case(const Case& c, const char* label) {
     const int64_t rows_out = c.mode == 6 ? (c.M / 240 + 1) * 241 : c.M;
     if (rows_out * c.N > capC) { printf("  (skip check: output too large)\n"); return 0; }
@@ -240,6 +272,49 @@ int main(int argc, char** argv) {
                    fl / t[0] * 1e-6, fl / t[3] * 1e-6, fl / tb * 1e-6);
         }
         mr_set_option("gemm3", 1);
+    }
+
+    if (!strcmp(what, "g5check") || !strcmp(what, "g5")) {
+        const Case checks[] = {
+            {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 3072, 768, 4, "fc1 dgrad aux+colsum"}, {15424, 768, 3072, 3, "fc2 fwd residual"},
+            {15424, 768, 3072, 5, "d ln2 plain"}, {15424, 2304, 768, 1, "qkv fwd bias+rot"}, {15424, 768, 2304, 0, "bias"},
+            {15360, 768, 768, 6, "patch embed row map"}, {5952, 3072, 768, 2, "audio fc1"}, {5952, 768, 768, 3, "audio proj"},
+            {3072, 2304, 768, 1, "span qkv"}, {4616, 4096, 1024, 4, "ragged M aux"}, {2000, 1000, 192, 0, "ragged M N"},
+            {1024, 256, 128, 3, "small"}, {1312, 3072, 128, 0, "four steps"}, {40000, 192, 128, 5, "four steps, narrow"}, {300, 192, 256, 1, "tiny ragged rot"},
+        };
+        mr_set_option("gemm5", 1);
+        for (int st = 0; st < 3; ++st) {
+            mr_set_option("gemm5_stagger", st);
+            char label[32]; snprintf(label, sizeof label, "g5/st%d", st);
+            for (const Case& c : checks) fails += check_case(c, label);
+        }
+        mr_set_option("gemm5", -1);
+        mr_set_option("gemm5_stagger", -1);
+    }
+    if (!strcmp(what, "g5time") || !strcmp(what, "g5")) {
+        const Case shapes[] = {
+            {15424, 3072, 768, 2, "fc1 fwd gelu+c2"}, {15424, 3072, 768, 4, "fc1 dgrad aux+colsum"}, {15424, 3072, 768, 5, "fc1 plain"},
+            {15424, 2304, 768, 1, "qkv fwd bias+rot"}, {15424, 768, 3072, 3, "fc2 fwd residual"}, {15424, 768, 3072, 5, "d ln2 plain"},
+            {15424, 768, 2304, 5, "d ln1 plain"}, {15424, 768, 768, 3, "proj fwd residual"}, {15424, 768, 768, 5, "d att plain"},
+            {5952, 3072, 768, 2, "audio fc1 fwd"}, {5952, 3072, 768, 4, "audio fc1 dgrad"}, {5952, 768, 3072, 3, "audio fc2 fwd"}, {5952, 2304, 768, 1, "audio qkv"}, {5952, 768, 768, 3, "audio proj"},
+            {3072, 3072, 768, 2, "span fc1 fwd"}, {3072, 768, 3072, 3, "span fc2 fwd"}, {3072, 2304, 768, 1, "span qkv"}, {3072, 768, 768, 3, "span proj"},
+            {2308, 4096, 1024, 2, "vcr vit fc1"}, {2308, 1024, 4096, 3, "vcr vit fc2"}, {2308, 3072, 1024, 1, "vcr vit qkv"},
+            {15424, 4096, 1024, 2, "large fc1 fwd"}, {15424, 4096, 1024, 4, "large fc1 dgrad"}, {15424, 1024, 4096, 3, "large fc2 fwd"},
+            {15424, 3072, 1024, 1, "large qkv"}, {15424, 1024, 1024, 3, "large proj"}, {8192, 8192, 8192, 5, "8192^3"},
+        };
+        printf("%-26s %18s | %9s %9s %9s %9s | TF/s default -> best g5   (sustained, interleaved; [0] default path, g5 stagger 0 / 1 (wave slot) / 2 (grid half))\n", "shape", "M x N x K", "default", "g5/st0", "g5/st1", "g5/st2");
+        const char* sel = getenv("G5_SHAPES");          // e.g. "0,2,26": only these rows of the table
+        int idx = -1;
+        for (const Case& c : shapes) {
+            ++idx;
+            if (sel) { char key[16]; snprintf(key, sizeof key, ",%d,", idx); std::string ss = std::string(",") + sel + ","; if (ss.find(key) == std::string::npos) continue; }
+            double t[4];
+            time_g5(c, c.mode == 4, reps * 10.0, t);
+            const double fl = 2.0 * c.M * c.N * c.K;
+            double tb = t[1]; if (t[2] < tb) tb = t[2]; if (t[3] < tb) tb = t[3];
+            printf("%-26s %6ldx%5ldx%5ld | %9.1f %9.1f %9.1f %9.1f | %7.0f -> %7.0f\n", c.name, (long)c.M, (long)c.N, (long)c.K, t[0], t[1], t[2], t[3], fl / t[0] * 1e-6, fl / tb * 1e-6);
+            fflush(stdout);
+        }
     }
     if (!strcmp(what, "tn") || !strcmp(what, "all")) {
         // weight gradients of a layer (x 2 layers): A = activations [K = tokens, in], B = upstream gradients [K, out]
