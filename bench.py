@@ -38,18 +38,43 @@ def algorithmic_flops_per_record(config, train=True):
     return fwd * (3 if train else 1)
 
 
+def _host_cpu():
+    """(model name, physical cores available to this process, logical CPUs available) from /proc/cpuinfo and the affinity mask."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    model, cores, cur = 'unknown', set(), {}
+    try:
+        for line in open('/proc/cpuinfo'):
+            if ':' in line:
+                k, v = [t.strip() for t in line.split(':', 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get('processor', -1)) in avail:
+                    cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                    model = cur.get('model name', model)
+                cur = {}
+        if cur and int(cur.get('processor', -1)) in avail:
+            cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+            model = cur.get('model name', model)
+    except OSError:
+        pass
+    return model, (len(cores) or len(avail)), len(avail)
+
+
 def cpu_baseline(config, threads=None):
     """The oracle (torch CPU restatement of the reference's step, fp32) timed on a BOUNDED sample of the bench workload:
     forward + backward of ONE record (2 video-segment groups) of the full-depth base model (or, for larger models,
     every tower at 1/`depth_div` of its depth, scaled back by the ratio of algorithmic FLOPs), the same
-    widths, sequence lengths and batch structure; reported in the metric's unit."""
+    widths, sequence lengths and batch structure; reported in the metric's unit.  Protocol of BASELINE.md section 3: one thread per
+    PHYSICAL core available to the process, 1 warm-up + the median of 3 runs, CPU model and core counts in the record."""
     import copy
+    import statistics
     import torch
     from oracle import ref_torch as R
     from merlot_reserve_amd.params import ParamStore
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from tests.util import oracle_batch, oracle_draws
-    threads = threads or min(os.cpu_count() or 1, 32)          # more threads than that only add fork/join overhead
+    model, phys, logical = _host_cpu()
+    threads = threads or phys
     torch.set_num_threads(threads)
     small = copy.deepcopy(config)
     m = small['model']
@@ -63,13 +88,21 @@ def cpu_baseline(config, threads=None):
     splits, z = make_draws(small, 1, seed=1234)
     osp, oz = oracle_draws(splits, z)
     ob = oracle_batch(batch)
-    t0 = time.time()
-    R.loss_and_grads(params, small, ob, osp, oz)
-    dt = time.time() - t0
+    times = []
+    for i in range(4):                       # run 0 = warm-up (allocator, thread pool, first-touch of the activations)
+        t0 = time.time()
+        R.loss_and_grads(params, small, ob, osp, oz)
+        times.append(time.time() - t0)
+        if i == 0 and times[0] > 40.0:       # a host far slower than planned: keep the bounded-sample promise, say so
+            break
+    timed = times[1:] if len(times) > 1 else times
+    dt = statistics.median(timed)
     return {'value': 2.0 / (dt * scale), 'unit': 'video-segments/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle (fp32 torch-CPU port) forward+backward of 1 record (2 video-segment groups x 8 frames), towers '
-                      f'at 1/{depth_div} depth ({m["vit_num_layers"]}/{m["audio_num_layers"]}/{m["joint_num_layers"]}/{m["span_num_layers"]} '
-                      f'layers): {dt:.1f} s measured, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
+            'cpu_model': model, 'physical_cores_available': phys, 'logical_cpus_available': logical,
+            'runs_s': [round(t, 2) for t in times], 'protocol': '1 warm-up + median of 3' if len(times) == 4 else 'single run (warm-up took > 40 s)',
+            'sample': f'oracle (fp32 torch-CPU port of the reference step; JAX is not installable here) forward+backward of 1 record '
+                      f'(2 video-segment groups x 8 frames), towers at 1/{depth_div} depth ({m["vit_num_layers"]}/{m["audio_num_layers"]}/'
+                      f'{m["joint_num_layers"]}/{m["span_num_layers"]} layers): median {dt:.1f} s, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
 def secondary_configs(dev, replays=6, warm=3):
@@ -316,15 +349,24 @@ def main():
         # ... and with the buckets' kernels issued in line as well (MR_NO_COMM_STREAM): every launch of the step ALONE on the GPU.  A
         # whole-CU GEMM launched beside a bucket's Adam kernel waits for CUs (the audio tower's first 20-us weight gradient reads 450 us
         # in every step), which the pass above counts as GEMM time: this one is the kernels' own time, and the per-family breakdown
+        ops.set_option('gemm_trace', 1)          # every launch records the kernel it is routed to (mr_last_gemm_kernel)
         gp, fam = timed_pass(['MR_NO_SIDE_STREAM', 'MR_NO_COMM_STREAM'])
+        ops.set_option('gemm_trace', 0)
         ms_xx = sum(r[0].elapsed_time(r[1]) for r in gp)
         fl_xx = sum(r[2] for r in gp)
+        kernels = {}                            # per kernel (template instance): launches / step, GFLOP and us per launch, fraction of the bf16 MFMA peak
+        for e0, e1, fl_, _tag, kname in gp:
+            k_ = kernels.setdefault(kname or 'unknown', [0, 0.0, 0.0])
+            k_[0] += 1; k_[1] += fl_; k_[2] += e0.elapsed_time(e1)
+        kernels = {k_: {'launches_per_step': v[0] // nprof, 'gflop_per_launch': round(v[1] / v[0] / 1e9, 2), 'avg_us': round(v[2] / v[0] * 1e3, 2),
+                        'ms_per_step': round(v[2] / nprof, 3), 'frac': round(v[1] / (v[2] * 1e-3) / MFMA_BF16_PEAK, 4)}
+                   for k_, v in sorted(kernels.items(), key=lambda kv: -kv[1][2])}
         breakdown = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / nprof, 3) for k, v in fam.items()}
         launches = {k: len(v) // nprof for k, v in fam.items()}
         breakdown['gemm'], launches['gemm'] = round(ms_xx / nprof, 3), len(gp) // nprof
         if os.environ.get('MR_BENCH_GEMM_SHAPES'):      # diagnostic: per-shape totals of the exclusive pass -> text file
             agg = {}
-            for e0, e1, fl_, tag in gp:
+            for e0, e1, fl_, tag, _kn in gp:
                 a = agg.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl_
             with open(os.environ['MR_BENCH_GEMM_SHAPES'], 'w') as f:
@@ -338,7 +380,8 @@ def main():
         ach_x = fl_x / (ms_x * 1e-3) / 1e12
         ach_xx = fl_xx / (ms_xx * 1e-3) / 1e12
         traffic, traffic_src = None, None       # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
-        for cand in ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
+        traffic_commit = None
+        for cand in ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
             pmc = os.path.join(ROOT, 'profiles', cand)
             if not os.path.exists(pmc):
                 continue
@@ -347,15 +390,20 @@ def main():
                 g = [v for k, v in p['kernels'].items() if 'gemm' in k]
                 traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
                 traffic_src = cand
+                traffic_commit = p.get('commit', 'not recorded (collected before round 4)')
                 break
         # `achieved` = the launches with the side stream off: what rocprofv3's per-kernel averages of the graph-replayed step show
         # (profiles/); `achieved_concurrent` = the same launches timed while the other tower's kernels share the GPU on the second
         # stream (durations then include the CUs yielded to them); `achieved_alone` = with the gradient-bucket stream off too
-        roof = {'bound': 'mfma', 'kernel': 'g4::gemm4_kernel<*> (one wave per SIMD), g3::gemm3_kernel<*> / gemm3_tn_kernel (ping-pong), g256::gemm256_kernel<*>, gemm_bf16_kernel for small shapes', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+        top = next(iter(kernels)) if kernels else None
+        roof = {'bound': 'mfma', 'kernel': f'bf16 MFMA GEMM family (largest: {top}); per-kernel figures in `kernels`', 'achieved': ach_x, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': ach_x / (MFMA_BF16_PEAK / 1e12), 'achieved_concurrent': ach, 'frac_concurrent': ach / (MFMA_BF16_PEAK / 1e12),
                 'achieved_alone': ach_xx, 'frac_alone': ach_xx / (MFMA_BF16_PEAK / 1e12), 'traffic': traffic,
-                'traffic_unit': f'HBM-side bytes per GEMM launch (PMC, profiles/{traffic_src})', 'launches': n,
-                'avg_launch_us': ms_x * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9}
+                'traffic_unit': f'HBM-side bytes per GEMM launch (PMC, profiles/{traffic_src})', 'traffic_commit': traffic_commit, 'launches': n,
+                'avg_launch_us': ms_x * 1e3 / n, 'avg_launch_gflop': fl / n / 1e9,
+                'kernels': kernels,
+                'kernels_note': 'every GEMM launch of the step ALONE on the GPU (eager pass, side and gradient-bucket streams off), HIP events on the launching stream; '
+                                'frac = Sigma 2MNK / Sigma time / 2.5 PFLOP/s per kernel template instance'}
 
     if rank == 0:
         vseg = 2 * B * world * args.steps

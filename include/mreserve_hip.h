@@ -39,7 +39,18 @@ extern "C" {
 
 int mr_version(void);
 const char* mr_last_error(void);
-/* Tuning / diagnostic knobs (process-wide, not thread-safe against concurrent launches).  Known names:
+/* ---- Handles (mr_create / mr_destroy).  The reference has no FFI; what a handle replaces is the process-global state an
+ *      XLA client keeps for a jitted step (pretrain/train.py:98-120: one jax device, one compiled step).  A handle owns what the library
+ *      would otherwise keep per process: the tuning OPTION SET below and, optionally, a split-K workspace on its device.
+ *        mr_create(device, ws_bytes, &h)   options = the process defaults at this moment; ws_bytes > 0: hipMalloc'ed here (the one
+ *                                          allocation the library makes), used by mr_gemm when mr_gemm_args.workspace is NULL
+ *        mr_make_current(h)                the CALLING THREAD launches under h's options from now on (NULL: the process defaults);
+ *                                          per thread, so two trainers on two threads cannot disturb each other
+ *        mr_handle_set_option / mr_handle_get_option(h, name, ...)    h = NULL addresses the process defaults
+ *        mr_destroy(h)                     after the caller has synchronised the streams that used it
+ *      mr_set_option / mr_get_option are the round-1..3 entry points, kept as shims: they address the calling thread's current handle,
+ *      or the process defaults when it has none.
+ * Option names:
  *   "gemm_tile_n"   0 = choose per problem (default) | 96 | 128 | 192 | 256 : forces the output-tile width of the 256-row GEMM
  *   "gemm_group_tile_n"  0 = choose (default) | 128 | 256 : tile width of mr_gemm_grouped's shared launch
  *   "gemm_v1_only"  1 = route every GEMM to the small-tile kernel
@@ -47,12 +58,27 @@ const char* mr_last_error(void);
  *                   for EVERY NT problem it can take, with that tile width (tests, A/B)
  *   "gemm3_phases"  0 = choose per problem (default) | 1 | 2 : barrier phases per k-tile of the ping-pong kernel (tests, A/B)
  *   "gemm_cus"      0 / 256 = default: persistent GEMM grids fill all 256 CUs | 64 .. 248 (multiple of 8): the forward / dgrad kernels
- *                   (gemm3.hip, gemm4.hip) launch that many workgroups, e.g. 240 = two CUs per XCD left to a resident RCCL kernel
- *                   (the data-parallel trainer sets it while gradient buckets are in flight)
+ *                   (gemm3.hip, gemm4.hip, gemm5.hip) launch that many workgroups (x 2 for gemm5), e.g. 240 = two CUs per XCD left to a
+ *                   resident RCCL kernel (the data-parallel trainer sets it while gradient buckets are in flight)
  *   "gemm4"         -1 = default (on) | 0 | 1 : the one-wave-per-SIMD kernel (gemm4.hip) for the bias / residual / plain problems
  *                   "gemm3" admits
- * Returns MR_EINVAL for an unknown name. */
+ *   "gemm5"         -1 = default (off: measured slower) | 0 | 1 = every NT problem it can take runs on the
+ *                   two-workgroups-per-CU kernel (gemm5.hip; tests, A/B);  "gemm5_stagger"  -1 = default | 0 | 1 | 2 | 3 : its start phase
+ *   "gemm_trace"    1 = every GEMM launch records the kernel it was routed to (mr_last_gemm_kernel; bench.py's per-kernel table)
+ * Environment variables (MR_GEMM3, MR_G3_PH, ...: experiment scripts) are read only by a library built with -DMR_DEBUG_ENV
+ * (MR_DEBUG_ENV=1 python -m merlot_reserve_amd.build); the product build ignores the environment.
+ * Unknown names return MR_EINVAL. */
+typedef struct mr_handle_s* mr_handle;
+int mr_create(int32_t device, int64_t ws_bytes, mr_handle* out);
+int mr_destroy(mr_handle h);
+int mr_make_current(mr_handle h);
+mr_handle mr_get_current(void);
+int mr_handle_set_option(mr_handle h, const char* name, int32_t value);
+int mr_handle_get_option(mr_handle h, const char* name, int32_t* value);
 int mr_set_option(const char* name, int value);
+int mr_get_option(const char* name, int32_t* value);
+/* the kernel (template instance) the calling thread's last mr_gemm / mr_gemm_grouped launch went to; "" unless "gemm_trace" is on */
+const char* mr_last_gemm_kernel(void);
 
 /* ---- GEMM with fused epilogue (flax Dense / DenseGeneral: M:228-236, 252-255, 371, 402, 453, 631;
  *      and their dgrad / wgrad) --------------------------------------------------------------
@@ -96,9 +122,13 @@ typedef struct {
 int mr_gemm(const mr_gemm_args* args, void* stream);
 int64_t mr_gemm_colsum_rows(int64_t M);
 int32_t mr_gemm_colsum_supported(const mr_gemm_args* args);
-/* count independent GEMMs (same transA/transB, epilogue limited to bias).  When they qualify (<= 4 problems, large M,
- * N % 128 == 0) they run as ONE persistent launch sharing the 256 CUs -- the four weight gradients of a transformer
- * layer -- with no split-K; otherwise this is count calls of mr_gemm.  Results are identical either way. */
+/* count independent GEMMs in one call.  Weight gradients (every problem transA = 1 / transB = 0, one K, bf16, no epilogue, <= 20
+ * problems, enough 256 x 256 tiles to fill most of the chip) run as ONE launch of the TN ping-pong kernel -- the weight gradients of
+ * two (base) or four (large) transformer layers; <= 4 problems with identical layouts, bias-only epilogues and N % 128 == 0 as one
+ * launch of the one-barrier kernel; anything else as `count` calls of mr_gemm.  Every problem is validated like mr_gemm's (non-null,
+ * 16-byte aligned operands, M / N / K > 0) BEFORE any kernel is launched.  Which kernel a problem lands on is a function of its shape
+ * and of the options; kernels that take the bias as the accumulators' initial value (gemm3 / gemm4 / gemm5) and those that add it in
+ * the epilogue (gemm256, gemm.hip) round in a different order, so the same problem may differ by one bf16 ulp between routes. */
 int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream);
 
 /* ---- LayerNorm (flax nn.LayerNorm eps=1e-5, fp32 stats, var = E[x^2]-E[x]^2: M:272,277,360,366) ---- */

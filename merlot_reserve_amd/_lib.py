@@ -34,6 +34,14 @@ class ReduceJob(C.Structure):
 PROTOTYPES = {
     'mr_version': (i32, []),
     'mr_set_option': (i32, [C.c_char_p, i32]),
+    'mr_get_option': (i32, [C.c_char_p, C.POINTER(i32)]),
+    'mr_create': (i32, [i32, i64, C.POINTER(vp)]),
+    'mr_destroy': (i32, [vp]),
+    'mr_make_current': (i32, [vp]),
+    'mr_get_current': (vp, []),
+    'mr_handle_set_option': (i32, [vp, C.c_char_p, i32]),
+    'mr_handle_get_option': (i32, [vp, C.c_char_p, C.POINTER(i32)]),
+    'mr_last_gemm_kernel': (C.c_char_p, []),
     'mr_last_error': (C.c_char_p, []),
     'mr_gemm': (i32, [C.POINTER(GemmArgs), vp]),
     'mr_gemm_grouped': (i32, [C.POINTER(GemmArgs), i32, vp]),

@@ -33,12 +33,15 @@ def build(force=False, verbose=True):
     if not force and not _needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    # MR_DEBUG_ENV=1: a DEBUG build whose kernels' dispatch reads the experiment scripts' environment knobs (MR_GEMM3, MR_G3_PH, ...:
+    # csrc/mr_options.h mr_env_int); the product build ignores the environment
+    debug = ['-DMR_DEBUG_ENV'] if os.environ.get('MR_DEBUG_ENV') == '1' else []
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.o')
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + debug + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

@@ -63,6 +63,18 @@ class Dims:
     def __init__(self, config, B):
         d, m = config['data'], config['model']
         self.B = B
+        # Flags of the reference's pretrainer that change the program.  Built: no_vision (pretrain/pretrain_model.py:61-63: the pooled
+        # vision sequence is multiplied by 0 on its way into the joint tower).  Not built -- a config that sets them would train a
+        # different model, so it is refused instead of ignored: do_rotary = False (:146-148 drops the joint coordinates, which sends
+        # TransformerEncoder to its learned `pe`, mreserve/modeling.py:335-341), more than one audio2text / text2audio sequence per
+        # segment group (:99-110, :124-135 tile the inputs), heads of another width than 64 (mreserve/modeling.py:598).
+        if not m.get('do_rotary', True):
+            raise NotImplementedError("model.do_rotary = False (learned position embeddings, mreserve/modeling.py:335-341) is not implemented")
+        if d.get('num_audio2text_seqs', 1) != 1 or d.get('num_text2audio_seqs', 1) != 1:
+            raise NotImplementedError('data.num_audio2text_seqs / num_text2audio_seqs other than 1 (pretrain/pretrain_model.py:99, 124) are not implemented')
+        if m.get('size_per_head', 64) != 64:
+            raise NotImplementedError('model.size_per_head other than 64 is not implemented (the attention kernels are written for 64)')
+        self.no_vision = bool(m.get('no_vision', False))
         self.H = m['hidden_size']
         self.nh = self.H // 64
         self.gh, self.gw = m['output_grid']
@@ -75,7 +87,7 @@ class Dims:
         self.nspg = self.nseg // self.ngroups
         self.nas = d['num_audio_subsegments']
         self.nspans = self.nseg * self.nas
-        self.ntrg = int(self.nspans * d['mask_rate']) * d['num_text2audio_seqs']
+        self.ntrg = int(self.nspans * d['mask_rate']) * d.get('num_text2audio_seqs', 1)
         self.lang = d['lang_seq_len']
         self.seq_len = d['seq_len']
         self.vis_len = self.nspg * self.hw4

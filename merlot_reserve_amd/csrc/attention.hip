@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "mr_common.h"
+#include "mr_options.h"
 
 // diagnostic builds (scripts/build_diag.sh): -DMR_ATTN_OCC=n / -DMR_ATTN_OCC_DQ=n set the waves per SIMD the register allocator targets
 // (the forward kernel fits three by itself since its K / V tiles are LDS-DMA staged: 162-168 registers)
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
 // MR_ATTN_QB_S (diagnostic): sequences longer than this use two query / key blocks per workgroup (default 64)
 static int64_t attn_qb_threshold() {
     static int64_t v = -1;
-    if (v < 0) { const char* e = getenv("MR_ATTN_QB_S"); v = e ? atoll(e) : 64; }
+    if (v < 0) v = mr_env_int("MR_ATTN_QB_S", 64);
     return v;
 }
 

@@ -14,6 +14,7 @@
 // through LDS so that residual / gelu' operands are read and C is written as 16-byte row segments.
 #include <stdlib.h>
 #include "mr_common.h"
+#include "mr_options.h"
 
 namespace {
 
@@ -308,10 +309,9 @@ bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s);
 bool mr_gemm5_wanted(const mr_gemm_args* a);
 int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s);
 
-extern int g_mr_opt_v1_only;        // mr_set_option("gemm_v1_only")
 static int use_gemm256() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MR_GEMM_V1_ONLY"); v = (e && e[0] == '1') ? 0 : 1; }
+    if (v < 0) v = mr_env_int("MR_GEMM_V1_ONLY", 0) ? 0 : 1;
     return v && !g_mr_opt_v1_only;
 }
 
@@ -338,6 +338,13 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(!a->rot_tab || a->rot_rows > 0, "mr_gemm: rot_rows must be > 0");
     MR_CHECK_ARG(!a->colsum || (use_gemm256() && mr_gemm_colsum_supported(a) && a->ldcs >= a->N && ((uintptr_t)a->colsum % 16) == 0 && a->ldcs % 4 == 0),
                  "mr_gemm: colsum is only produced by the 256-row kernel with the aux epilogue (ask mr_gemm_colsum_supported)");
+    mr_gemm_args with_ws;                    // the current handle's split-K workspace when the caller brings none
+    if (a->workspace == nullptr && mr_current_handle() != nullptr && mr_current_handle()->ws != nullptr) {
+        with_ws = *a;
+        with_ws.workspace = mr_current_handle()->ws;
+        with_ws.workspace_bytes = mr_current_handle()->ws_bytes;
+        a = &with_ws;
+    }
     if (use_gemm256() && mr_gemm5_wanted(a)) return mr_gemm5_launch(a, static_cast<hipStream_t>(stream));      // two workgroups per CU
     if (use_gemm256() && mr_gemm3_eligible(a)) {
         mr_gemm3_launch(a, static_cast<hipStream_t>(stream));
@@ -372,12 +379,22 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
     else if (a->transA && !a->transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, *a, (int)tn, (int)kt_per_split);
     if (splits > 1) launch_splitk_reduce(a, splits, s);
+    mr_note_route("gemm_bf16_kernel<%d,%d>%s", (int)a->transA, (int)a->transB, splits > 1 ? " + splitk_reduce" : "");
     MR_CHECK_LAUNCH("mr_gemm");
     return MR_OK;
 }
 
 extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* stream) {
     MR_CHECK_ARG(list != nullptr && count >= 1, "mr_gemm_grouped: empty list");
+    for (int k = 0; k < count; ++k) {          // the same operand checks mr_gemm makes, BEFORE any kernel sees the list (16-byte LDS-DMA loads / b128 stores)
+        const mr_gemm_args* a = &list[k];
+        MR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "mr_gemm_grouped: problem %d is empty (M=%ld N=%ld K=%ld)", k, (long)a->M, (long)a->N, (long)a->K);
+        MR_CHECK_ARG(a->A && a->B && a->C, "mr_gemm_grouped: problem %d has a null operand", k);
+        MR_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "mr_gemm_grouped: problem %d: lda / ldb must be multiples of 8", k);
+        MR_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
+                     "mr_gemm_grouped: problem %d: operands must be 16-byte aligned", k);
+        MR_CHECK_ARG(a->c_dtype != MR_DT_BF16 || (a->N % 8 == 0 && a->ldc % 8 == 0), "mr_gemm_grouped: problem %d: bf16 output needs N, ldc multiples of 8", k);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_gemm256() && count <= 20 && mr_gemm3_tn_grouped(list, count, s)) {      // weight gradients: the TN ping-pong kernel
         MR_CHECK_LAUNCH("mr_gemm_grouped (ping-pong kernel)");

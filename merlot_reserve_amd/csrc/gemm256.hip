@@ -8,6 +8,7 @@
 // Out-of-range rows / columns are fetched with an out-of-range buffer offset, which the hardware zero-fills.
 // Same contract and epilogue as gemm.hip (mr_gemm dispatches here for large problems).
 #include "gemm256_sched.h"
+#include "mr_options.h"
 
 namespace g256 {
 
@@ -591,8 +592,6 @@ static void launch(const G256Args& ga, dim3 grid, hipStream_t s) {
 }  // namespace g256
 
 constexpr int64_t NUM_CU = 256;    // MI355X
-extern int g_mr_opt_tile_n;        // mr_set_option("gemm_tile_n")
-extern int g_mr_opt_group_tile_n;  // mr_set_option("gemm_group_tile_n")
 
 // Returns true when the problem suits the 256-row kernel (then *splits / tiling are filled in by mr_gemm256_launch).
 bool mr_gemm256_eligible(const mr_gemm_args* a) {
@@ -616,10 +615,10 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     // tile width: the one that wastes the fewest CU-rounds (256 workgroups per round, one per CU)
     int bn = 128;
     static int force_bn = -1, grid_mode = -1, c256_cost = -1, c192_cost = -1;
-    if (force_bn < 0) { const char* e = getenv("MR_G256_BN"); force_bn = e ? atoi(e) : 0; }
-    if (grid_mode < 0) { const char* e = getenv("MR_G256_GRID"); grid_mode = e ? atoi(e) : 0; }
-    if (c256_cost < 0) { const char* e = getenv("MR_G256_C256"); c256_cost = e ? atoi(e) : 180; }
-    if (c192_cost < 0) { const char* e = getenv("MR_G256_C192"); c192_cost = e ? atoi(e) : 150; }
+    if (force_bn < 0) force_bn = mr_env_int("MR_G256_BN", 0);
+    if (grid_mode < 0) grid_mode = mr_env_int("MR_G256_GRID", 0);
+    if (c256_cost < 0) c256_cost = mr_env_int("MR_G256_C256", 180);
+    if (c192_cost < 0) c192_cost = mr_env_int("MR_G256_C192", 150);
     const bool can256 = a->N >= 256, can192 = a->N >= 192;
     {
         const int64_t t128 = tm * ((a->N + 127) / 128), t96 = tm * ((a->N + 95) / 96), t256 = tm * ((a->N + 255) / 256);
@@ -662,7 +661,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     memset(&ga, 0, sizeof(ga));
     ga.count = 1; ga.nwork = (int)nwork; ga.splits = (int)splits; ga.kt_per_split = (int)kps;
     static int xmode_env = -1;
-    if (xmode_env < 0) { const char* e = getenv("MR_G256_XMODE"); xmode_env = e ? atoi(e) : 1; }
+    if (xmode_env < 0) xmode_env = mr_env_int("MR_G256_XMODE", 1);
     if (xmode_env && splits == 1 && gsz == full_grid && nwork >= 2 * full_grid) {
         // choose the XCD partition: fewest rounds first (the slowest XCD sets the time), then least traffic out of L2
         const double a_bytes = 2.0 * a->M * a->K, b_bytes = 2.0 * a->N * a->K;
@@ -695,6 +694,7 @@ int mr_gemm256_launch(const mr_gemm_args* a, hipStream_t s, void (*reduce)(const
     else if (bn == 128) g256::launch<128>(ga, grid, s);
     else g256::launch<96>(ga, grid, s);
     if (splits > 1) reduce(a, splits, s);
+    mr_note_route("g256::gemm256_kernel<%d,%d,%d>%s", bn, (int)a->transA, (int)a->transB, splits > 1 ? " + splitk_reduce" : "");
     return 0;
 }
 
@@ -710,7 +710,7 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     // tile width for the whole group: fewest CU-rounds, a 256-wide tile costing ~1.8 of a 128-wide one (the large model's
     // four weight gradients are 384 tiles of 128 = 1.5 rounds -> 2, but 192 tiles of 256 = one round)
     static int c256_cost = -1;
-    if (c256_cost < 0) { const char* e = getenv("MR_G256_GROUP_C256"); c256_cost = e ? atoi(e) : 180; }
+    if (c256_cost < 0) c256_cost = mr_env_int("MR_G256_GROUP_C256", 180);
     int64_t t128 = 0, t256 = 0;
     bool can256 = true;
     for (int k = 0; k < count; ++k) {
@@ -740,5 +740,6 @@ bool mr_gemm256_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     dim3 grid((unsigned)(tiles < NUM_CU ? tiles : NUM_CU));
     if (bn == 256) g256::launch<256>(ga, grid, s);
     else g256::launch<128>(ga, grid, s);
+    mr_note_route("g256::gemm256_kernel<%d,%d,%d> grouped x%d", bn, (int)list[0].transA, (int)list[0].transB, count);
     return true;
 }

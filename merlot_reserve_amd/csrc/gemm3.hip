@@ -32,6 +32,7 @@
 #include <string.h>
 #include <type_traits>
 #include "gemm256_sched.h"
+#include "mr_options.h"
 
 namespace g3 {
 
@@ -623,24 +624,19 @@ __global__ __launch_bounds__(512, 2) void gemm3_tn_kernel(const TNArgs ta) {
 }  // namespace g3
 
 constexpr int64_t NUM_CU3 = 256;    // MI355X
-extern int g_mr_opt_group_tile_n;
-extern int g_mr_opt_gemm4;           // mr_set_option("gemm4"): -1 = default (MR_GEMM4, or on) | 0 | 1 : the one-wave-per-SIMD kernel for gemm3's bias / residual / plain problems
 bool mr_gemm4_takes(const mr_gemm_args* a);
 int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int64_t gsz, hipStream_t s);
-extern int g_mr_opt_gemm3_ph;        // mr_set_option("gemm3_phases"): 0 = default (MR_G3_PH or 1) | 1 | 2
-extern int g_mr_opt_gemm3;           // mr_set_option("gemm3"): 1 = on (default), 0 = off, 256 / 192 = on with that tile width forced
 
 // The ping-pong kernel takes: NT operands (A [M,K], B [N,K], K % 64 == 0), bf16 output, at least one full round of 256-row tiles'
 // worth of work, and one of the epilogue combinations the step uses -- bias; bias + "rotary"; bias + GELU with the gelu' copy;
 // residual; aux (with or without column sums).
-extern int g_mr_opt_gemm_cus;        // mr_set_option("gemm_cus"): 0 / 256 = all CUs | 64 .. 248: persistent grids of the NT kernels use this many workgroups
 // persistent workgroups = CUs a launch may fill (mr_set_option "gemm_cus": 256, or fewer -- a multiple of 8 -- while a collective
 // kernel holds CUs: a 256-workgroup grid would then run its last workgroups as a second round behind the others)
 static int64_t g3_ncu() { return (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < NUM_CU3) ? (g_mr_opt_gemm_cus & ~7) : NUM_CU3; }
 
 bool mr_gemm3_eligible(const mr_gemm_args* a) {
     static int env = -1;
-    if (env < 0) { const char* e = getenv("MR_GEMM3"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = mr_env_int("MR_GEMM3", 1);
     if (!env || !g_mr_opt_gemm3) return false;
     if (a->transA || !a->transB || a->c_dtype != MR_DT_BF16) return false;
     const bool forced = g_mr_opt_gemm3 == 256 || g_mr_opt_gemm3 == 192;      // tests: any shape the kernel can take
@@ -660,7 +656,7 @@ bool mr_gemm3_eligible(const mr_gemm_args* a) {
     const int64_t tm = (a->M + 255) / 256;
     if (tm * ((a->N + 191) / 192) > 64 * g3_ncu()) return false;     // <= 64 items per workgroup (the kernel keeps them one per lane)
     static int min_tiles = -1;
-    if (min_tiles < 0) { const char* e = getenv("MR_G3_MIN_TILES"); min_tiles = e ? atoi(e) : 128; }
+    if (min_tiles < 0) min_tiles = mr_env_int("MR_G3_MIN_TILES", 128);
     if (!forced && tm * ((a->N + 255) / 256) < min_tiles) return false;
     return true;
 }
@@ -705,7 +701,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     ga.p[0] = *a;
     {   // the one-wave-per-SIMD kernel (gemm4.hip) shares this tile plan
         static int g4_env = -1;
-        if (g4_env < 0) { const char* e = getenv("MR_GEMM4"); g4_env = e ? atoi(e) : 1; }
+        if (g4_env < 0) g4_env = mr_env_int("MR_GEMM4", 1);
         const int g4 = g_mr_opt_gemm4 >= 0 ? g_mr_opt_gemm4 : g4_env;
         if (g4 && mr_gemm4_takes(a)) return mr_gemm4_launch(a, bn, ga, gsz, s);
     }
@@ -716,7 +712,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     else if (a->residual) mode = 3;
     else if (a->aux) mode = 4;
     static int ph_env = -1;
-    if (ph_env < 0) { const char* e = getenv("MR_G3_PH"); ph_env = e ? atoi(e) : 0; }
+    if (ph_env < 0) ph_env = mr_env_int("MR_G3_PH", 0);
     // one phase per k-tile (half the barriers: 2-7 % faster at K <= 4096) except where it measured slower: the 256-wide aux / column-sum
     // epilogue (its prefetch registers + the one-phase schedule's spill: 94 vs 86 us on the fc1 dgrad) and very long k-loops, where B
     // requested one phase ahead by ONE group lands later than the two-phase schedule's (8192^3: 745 vs 729 us)
@@ -740,6 +736,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
         default: G3_LAUNCH(4); break;
     }
 #undef G3_LAUNCH
+    mr_note_route("g3::gemm3_kernel<%d,%d,%d>", bn, mode, ph);
     return 0;
 }
 
@@ -747,7 +744,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
 // epilogue.  Returns false when the group does not qualify (the caller falls back to the one-barrier kernel's grouped launch).
 bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     static int env = -1;
-    if (env < 0) { const char* e = getenv("MR_GEMM3_TN"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = mr_env_int("MR_GEMM3_TN", 1);
     if (!env || !g_mr_opt_gemm3 || count < 1 || count > g3::TN_MAXG) return false;
     if (g_mr_opt_group_tile_n != 0) return false;   // an explicitly requested tile width of the one-barrier kernel
     g3::TNArgs ta;
@@ -772,5 +769,6 @@ bool mr_gemm3_tn_grouped(const mr_gemm_args* list, int count, hipStream_t s) {
     const bool forced = g_mr_opt_gemm3 == 256;
     if (!forced && (tiles < 160 || tiles > 4 * NUM_CU3 || list[0].K < 2048)) return false;
     hipLaunchKernelGGL(g3::gemm3_tn_kernel, dim3((unsigned)tiles), dim3(512), 0, s, ta);
+    mr_note_route("g3::gemm3_tn_kernel grouped x%d", count);
     return true;
 }

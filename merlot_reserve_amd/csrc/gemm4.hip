@@ -31,6 +31,7 @@
 #include <string.h>
 #include <type_traits>
 #include "gemm256_sched.h"
+#include "mr_options.h"
 
 namespace g4 {
 
@@ -294,6 +295,7 @@ int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int
         default: G4_LAUNCH(5); break;
     }
 #undef G4_LAUNCH
+    mr_note_route("g4::gemm4_kernel<%d,%d>", bn, mode);
     MR_CHECK_LAUNCH("mr_gemm (gemm4)");
     return MR_OK;
 }

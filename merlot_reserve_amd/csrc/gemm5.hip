@@ -28,6 +28,7 @@
 #include <string.h>
 #include <type_traits>
 #include "gemm256_sched.h"
+#include "mr_options.h"
 
 namespace g5 {
 
@@ -268,9 +269,6 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
 
 }  // namespace g5
 
-extern int g_mr_opt_gemm_cus;        // mr_set_option("gemm_cus"), see gemm3.hip
-extern int g_mr_opt_gemm5;           // mr_set_option("gemm5"): -1 = default (MR_GEMM5, or the shapes measured faster) | 0 = off | 1 = every problem the kernel can take
-extern int g_mr_opt_gemm5_stagger;   // mr_set_option("gemm5_stagger"): -1 = default | 0 = none | 1 = by wave slot | 2 = upper half of the grid | 3 = by blockIdx bit 3
 
 // Same operand / epilogue contract as the ping-pong kernel (the caller has checked mr_gemm3_eligible's operand conditions).
 bool mr_gemm5_takes(const mr_gemm_args* a) {
@@ -330,8 +328,8 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     else if (a->aux) mode = 4;
     else if (a->bias) mode = 0;
     static int st_env = -2, su_env = -2;
-    if (st_env == -2) { const char* e = getenv("MR_G5_STAGGER"); st_env = e ? atoi(e) : -1; }
-    if (su_env == -2) { const char* e = getenv("MR_G5_STAGGER_PCT"); su_env = e ? atoi(e) : -1; }
+    if (st_env == -2) st_env = mr_env_int("MR_G5_STAGGER", -1);
+    if (su_env == -2) su_env = mr_env_int("MR_G5_STAGGER_PCT", -1);
     int st_mode = g_mr_opt_gemm5_stagger >= 0 ? g_mr_opt_gemm5_stagger : st_env >= 0 ? st_env : 1;
     if (gsz <= ncu) st_mode = 0;                          // one workgroup per CU: nobody to be out of phase with
     // ~ one k-loop alone on the CU: K / 32 steps of 512 MFMA cycles, in units of 2048 cycles (percent knob for experiments)
@@ -340,7 +338,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     dim3 grid((unsigned)gsz), block(256);
     {
         static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("MR_G5_DEBUG"); dbg = e ? atoi(e) : 0; }
+        if (dbg < 0) dbg = mr_env_int("MR_G5_DEBUG", 0);
         if (dbg == 1) {
             dbg = 2;
             int nb = -1;
@@ -361,6 +359,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
         default: G5_LAUNCH(5); break;
     }
 #undef G5_LAUNCH
+    mr_note_route("g5::gemm5_kernel<%d>", mode);
     MR_CHECK_LAUNCH("mr_gemm (gemm5)");
     return MR_OK;
 }
@@ -368,7 +367,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
 // Which problems go to this kernel: mr_set_option("gemm5") 1 = every one it can take (tests, A/B), 0 = none, -1 = the policy below.
 bool mr_gemm5_wanted(const mr_gemm_args* a) {
     static int env = -2;
-    if (env == -2) { const char* e = getenv("MR_GEMM5"); env = e ? atoi(e) : -1; }
+    if (env == -2) env = mr_env_int("MR_GEMM5", -1);
     const int v = g_mr_opt_gemm5 >= 0 ? g_mr_opt_gemm5 : env;
     if (v == 0 || a->colsum != nullptr && !a->aux) return false;
     if (!mr_gemm5_takes(a)) return false;

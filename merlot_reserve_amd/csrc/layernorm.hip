@@ -17,10 +17,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
                                                      int H, float eps) {
     const int lane = threadIdx.x & 63;
-#ifdef MR_DIAG_ACQUIRE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (row0 >= rows) return;
     const bool two = row0 + 1 < rows;

@@ -76,6 +76,8 @@ class NativeComm:
         # the communicator binds to the device that is current inside mr_comm_init: make that the caller's device, and keep it
         # for the collectives (two ranks that both initialise on device 0 hang inside RCCL)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:                    # 'cuda' without an index: the current device, made explicit (the collectives compare indices)
+            self.device = torch.device('cuda', torch.cuda.current_device())
         h = C.c_void_p()
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         with torch.cuda.device(self.device):
@@ -98,6 +100,22 @@ class NativeComm:
         per-rank outcome.  (A rank-0 failure used to skip the broadcast the other ranks were waiting in.)"""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         obj_dev = torch.device(device) if dist.get_backend(group) == 'nccl' else None
+        # (0) everything that can fail LOCALLY -- loading the library, resolving the device -- happens before any rank enters RCCL's
+        # collective initialisation, and its outcome is agreed on first: a rank that dies here must not leave the others inside
+        # ncclCommInitRank, from which no control-plane message can call them back
+        ready, why = 1, ''
+        try:
+            from . import _lib
+            _lib.load()
+            dev_ = torch.device(device)
+            if dev_.type != 'cuda' or (dev_.index is not None and dev_.index >= torch.cuda.device_count()):
+                raise RuntimeError(f'{device} is not a visible GPU')
+        except Exception as e:                                       # noqa: BLE001 -- reported to every rank below
+            ready, why = 0, f'{type(e).__name__}: {e}'
+        flag0 = torch.tensor([ready], device=obj_dev)
+        dist.all_reduce(flag0, op=dist.ReduceOp.MIN, group=group)
+        if int(flag0) == 0:
+            raise RuntimeError(f'the native RCCL communicator cannot be initialised on some rank (this rank: {why or "ready"})')
         box = [None]
         if rank == 0:
             try:

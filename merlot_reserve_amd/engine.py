@@ -524,6 +524,8 @@ class PretrainEngine(TowerEngine):
         self._tower_with_pool_forward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],
                                       self.tables['vit_pool_rows'], self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po,
                                       self.v_probs, self.imgs_seq, self.v_cls)
+        if d.no_vision:                  # pretrain/pretrain_model.py:61-63: imgs_seq *= 0.0 (the cls output still feeds the contrastive loss)
+            self.imgs_seq.zero_()
         main.wait_stream(self.side_stream)
         emb = W['token_encoder/Embed_0/embedding']
 
@@ -664,6 +666,8 @@ class PretrainEngine(TowerEngine):
         ops.segment_sum([Dj, Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
         ops.segment_sum([Dj], self._pl('audT_indptr'), self._pl('audT_idx'), self.d_audio_seq)
         ops.segment_sum([Dj], self._pl('visT_indptr'), self._pl('visT_idx'), self.d_imgs_seq)
+        if d.no_vision:                  # d(imgs_seq * 0) = 0
+            self.d_imgs_seq.zero_()
         ops.segment_sum([self.d_acls_g], self._pl('aclsT_indptr'), self._pl('aclsT_idx'), self.d_a_cls)
 
     def backward_stage_audio(self):

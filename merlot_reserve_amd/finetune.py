@@ -384,10 +384,17 @@ def _finetune_train_step_scanned(state, batch):
     if getattr(model, '_engine1', None) is None:              # an engine for ONE example on the same parameter store
         model._engine1 = VCREngine(model.config, 1, p, model.device)
     e1 = model._engine1
-    acc = torch.zeros_like(p.grad)
+    # Memory: the one-example engine keeps its own activations / scratch beside the B-example one (the price of scan_minibatch here:
+    # ~1/B of the big engine's activations; free it with `model._engine1 = None` when scanning is switched off), and ONE persistent
+    # parameter-sized bf16 accumulator, zeroed in place each step.
+    if getattr(model, '_scan_acc', None) is None or model._scan_acc.shape != p.grad.shape:
+        model._scan_acc = torch.zeros_like(p.grad)
+    acc = model._scan_acc
+    acc.zero_()
     losses = []
     for i in range(eng.d.B):
         micro = {'image': batch['image'][i:i + 1], 'answers': np.asarray(batch['answers'])[i:i + 1], 'labels': np.asarray(batch['labels'])[i:i + 1]}
+        p.grad.zero_()                                        # a leaf this example's backward does not write must contribute 0, not the previous example's value
         e1.forward(micro)
         e1.loss_and_grad_logits()
         e1.backward()

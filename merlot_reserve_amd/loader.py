@@ -21,6 +21,24 @@ import torch
 FLOAT_KEYS = ('images', 'audio_clips')
 
 
+def _stage(dst, src):
+    """dst (pinned) <- src (host), on ONE host thread.  torch's CPU copy_ of a 25 MB tensor fans out over the intra-op thread pool, whose
+    workers spin for a while after the parallel region; on the GPU box that starves the ROCm runtime's own helper threads and every
+    graph-replayed step beside it ran 3-8 ms longer (round 4, scripts/h2d_variants.py: 33-35 ms loader-fed vs 29.5 resident; 30.0 with
+    one host thread or with the staging copy removed).  Same dtype: a plain memcpy through numpy views (no thread pool, releases the
+    GIL); a cast: torch's copy_ with the pool held to one thread for the duration."""
+    if src.dtype == dst.dtype and src.is_contiguous() and src.device.type == 'cpu':
+        w = torch.int16 if dst.element_size() == 2 else torch.int32 if dst.element_size() == 4 else torch.uint8
+        np.copyto(dst.view(w).numpy(), src.view(w).numpy())
+        return
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        dst.copy_(src)
+    finally:
+        torch.set_num_threads(n)
+
+
 class PrefetchLoader:
     def __init__(self, batches, device, depth=2, dtype=torch.bfloat16):
         """batches: an iterable of host batches (numpy arrays or CPU tensors for FLOAT_KEYS; anything else is passed through).
@@ -59,7 +77,7 @@ class PrefetchLoader:
         for k in FLOAT_KEYS:
             src = batch[k]
             src = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src
-            self.pinned[slot][k].copy_(src)                       # host-side cast to the wire dtype + memcpy into pinned memory
+            _stage(self.pinned[slot][k], src)                     # host-side cast to the wire dtype + memcpy into pinned memory
         if self.cuda:
             with torch.cuda.stream(self.copy_stream):
                 if self.consumed[slot] is not None:

@@ -27,8 +27,9 @@ def _ld(t):
     return t.stride(0)
 
 
-# Optional per-launch timing of the dominant kernel (bench.py): a list that receives (start_event, end_event, flops)
-# for every mr_gemm launch, recorded with HIP events on the stream the kernel is launched on.
+# Optional per-launch timing of the dominant kernel (bench.py): a list that receives (start_event, end_event, flops, shape tag,
+# kernel name -- '' unless option 'gemm_trace' is on) for every mr_gemm launch, recorded with HIP events on the stream the kernel
+# is launched on.
 GEMM_PROFILE = None
 # Optional per-launch timing of EVERY op by kernel family (bench.py's breakdown): a dict family -> list of (start, end)
 # HIP events recorded on the stream the op is launched on.
@@ -52,28 +53,78 @@ def _timed(family):
 
 
 def set_option(name, value):
-    """mr_set_option: process-wide tuning knob of the library (include/mreserve_hip.h lists them)."""
+    """mr_set_option: an option of the calling thread's current handle, or of the process defaults when it has none
+    (include/mreserve_hip.h lists the names)."""
     check(_lib.load().mr_set_option(name.encode(), int(value)), 'mr_set_option')
+
+
+def get_option(name):
+    v = C.c_int32(0)
+    check(_lib.load().mr_get_option(name.encode(), C.byref(v)), 'mr_get_option')
+    return v.value
+
+
+class Handle:
+    """mr_create / mr_destroy (include/mreserve_hip.h): an option set of its own (a copy of the process defaults at creation) and,
+    with ws_bytes > 0, a split-K workspace on `device` that mr_gemm uses when the caller passes none.  `with handle:` makes it the
+    calling THREAD's current handle for the block (launches inside run under its options) and restores the previous one after."""
+
+    def __init__(self, device=0, ws_bytes=0):
+        h = C.c_void_p()
+        check(_lib.load().mr_create(int(device), int(ws_bytes), C.byref(h)), 'mr_create')
+        self._h, self._prev = h, []
+
+    def set_option(self, name, value):
+        check(_lib.load().mr_handle_set_option(self._h, name.encode(), int(value)), 'mr_handle_set_option')
+
+    def get_option(self, name):
+        v = C.c_int32(0)
+        check(_lib.load().mr_handle_get_option(self._h, name.encode(), C.byref(v)), 'mr_handle_get_option')
+        return v.value
+
+    def __enter__(self):
+        lib = _lib.load()
+        self._prev.append(lib.mr_get_current())
+        check(lib.mr_make_current(self._h), 'mr_make_current')
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.load().mr_make_current(self._prev.pop()), 'mr_make_current')
+        return False
+
+    def close(self):
+        if self._h is not None:
+            check(_lib.load().mr_destroy(self._h), 'mr_destroy')
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class gemm_cus:
     """with ops.gemm_cus(world): the persistent forward / dgrad GEMM grids launched inside use MR_COMM_GEMM_CUS workgroups (default 240 =
     30 per XCD) when world > 1, i.e. while a gradient bucket's RCCL kernel may hold CUs next to them: a 256-workgroup grid then runs its
     last workgroups as a second round (scripts/bench_contention.py: 16 CUs held -> 111 vs 79 us for the fc1 shape).  Launch parameters
-    are fixed at capture time, so inside a captured step this shapes the graph's kernels, not the replay."""
+    are fixed at capture time, so inside a captured step this shapes the graph's kernels, not the replay.  The option belongs to the
+    calling thread's current handle (or the process defaults) and is put back to the value it HAD on exit, also on an exception."""
 
     def __init__(self, world):
         n = int(os.environ.get('MR_COMM_GEMM_CUS', '240'))
         self.n = n if world > 1 and 64 <= n < 256 else 0
+        self.prev = None
 
     def __enter__(self):
         if self.n:
+            self.prev = get_option('gemm_cus')
             set_option('gemm_cus', self.n)
         return self
 
     def __exit__(self, *exc):
         if self.n:
-            set_option('gemm_cus', 0)
+            set_option('gemm_cus', self.prev)
         return False
 
 
@@ -141,7 +192,8 @@ def gemm(a, b, out, **kw):
         e0.record()
         check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K, (g.M, g.N, g.K, g.transA, g.transB, bool(g.bias), bool(g.rot_tab), bool(g.c2), g.act, bool(g.residual), bool(g.aux))))
+        GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K, (g.M, g.N, g.K, g.transA, g.transB, bool(g.bias), bool(g.rot_tab), bool(g.c2), g.act, bool(g.residual), bool(g.aux)),
+                             lib.mr_last_gemm_kernel().decode()))
         return out
     check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
     return out
@@ -157,7 +209,7 @@ def gemm_grouped(arg_list):
         e0.record()
         check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list), ('grouped', len(arg_list), arg_list[0].K)))
+        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list), ('grouped', len(arg_list), arg_list[0].K), lib.mr_last_gemm_kernel().decode()))
         return
     check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 

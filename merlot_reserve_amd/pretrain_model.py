@@ -40,6 +40,8 @@ class MerlotReservePretrainer:
         """P:38 / M:584-598.  kwargs: device, rank, world, comm (merlot_reserve_amd.dist.Comm), seed."""
         if 'model' not in config or 'data' not in config:
             raise ValueError("config must have 'model' and 'data' sections (the reference's YAML schema)")
+        from .config import Dims
+        Dims(config, 1)             # refuses the flags this build does not implement (do_rotary = False, ...) before any buffer exists
         return cls(config, **kwargs)
 
     # -- parameters -------------------------------------------------------------------------------------------------

@@ -363,6 +363,8 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
                                   cfg.vit_num_layers, cfg.grid_h, cfg.grid_w, cfg.vit_pooling_ratio)
     nvpatch1 = nvpatch0 // (cfg.vit_pooling_ratio ** 2)
     imgs_seq = imgs_enc['seq_attnpool'].reshape(batch_size, num_segment_groups, nspg * nvpatch1, H)
+    if config['model'].get('no_vision', False):          # pretrain/pretrain_model.py:61-63
+        imgs_seq = imgs_seq * 0.0
     vis_seq_length = imgs_seq.shape[-2]
 
     audio_enc = audio_transformer(params['audio_encoder'],

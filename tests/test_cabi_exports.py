@@ -50,7 +50,7 @@ def test_options_are_named_and_unknown_names_rejected(monkeypatch):
     text = open(os.path.join(ROOT, 'include', 'mreserve_hip.h')).read()
     names = re.findall(r'^ \*   "([a-z0-9_]+)"', text, flags=re.M)
     assert {'gemm3', 'gemm3_phases', 'gemm4', 'gemm_cus', 'gemm_tile_n'} <= set(names)
-    defaults = {'gemm3': 1, 'gemm4': -1}
+    defaults = {'gemm3': 1, 'gemm4': -1, 'gemm5': -1}
     for n in names:
         assert lib.mr_set_option(n.encode(), defaults.get(n, 0)) == 0, n
     assert lib.mr_set_option(b'no_such_knob', 1) == -1 and b'no_such_knob' in lib.mr_last_error()
@@ -61,8 +61,60 @@ def test_options_are_named_and_unknown_names_rejected(monkeypatch):
     assert calls == []
     with ops.gemm_cus(8):
         assert calls == [('gemm_cus', 240)]
-    assert calls == [('gemm_cus', 240), ('gemm_cus', 0)]
+    assert calls == [('gemm_cus', 240), ('gemm_cus', 0)]        # (0 = the value the option had on entry)
     monkeypatch.setenv('MR_COMM_GEMM_CUS', '0')
     with ops.gemm_cus(8):
         pass
     assert len(calls) == 2
+
+
+def test_handles_carry_their_own_options():
+    """mr_create / mr_destroy / mr_make_current: a handle's option set is its own; the calling thread launches under its
+    CURRENT handle's options; mr_set_option / mr_get_option address the current handle, or the process defaults without one; another
+    thread is not affected; ops.gemm_cus restores the value it found."""
+    import threading
+    from merlot_reserve_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.mr_version() >= 4
+    assert lib.mr_get_current() is None
+    ops.set_option('gemm_cus', 0)
+    h1, h2 = ops.Handle(0), ops.Handle(0)                # (no workspace: nothing touches a GPU here)
+    h1.set_option('gemm_cus', 240)
+    assert h1.get_option('gemm_cus') == 240 and h2.get_option('gemm_cus') == 0 and ops.get_option('gemm_cus') == 0
+    with h1:
+        assert ops.get_option('gemm_cus') == 240        # the shim reads the current handle
+        ops.set_option('gemm3', 192)                    # ... and writes it
+        seen = []
+        t = threading.Thread(target=lambda: seen.append((lib.mr_get_current(), ops.get_option('gemm_cus'), ops.get_option('gemm3'))))
+        t.start(); t.join()
+        assert seen == [(None, 0, 1)]                   # another thread: no current handle, the process defaults
+        with h2:
+            assert ops.get_option('gemm_cus') == 0
+            with ops.gemm_cus(8):
+                assert ops.get_option('gemm_cus') == 240 and h2.get_option('gemm_cus') == 240
+            assert h2.get_option('gemm_cus') == 0
+        assert ops.get_option('gemm_cus') == 240        # h1 is current again
+        with ops.gemm_cus(8):
+            pass
+        assert h1.get_option('gemm_cus') == 240         # restored to what it was, not to 0 (advisor finding, round 3)
+    assert lib.mr_get_current() is None and ops.get_option('gemm3') == 1 and h1.get_option('gemm3') == 192
+    bad = ctypes.c_int32(0)
+    assert lib.mr_handle_get_option(None, b'no_such_knob', ctypes.byref(bad)) == -1
+    assert lib.mr_create(-1, 0, ctypes.byref(ctypes.c_void_p())) == -1
+    h1.close(); h2.close()
+    assert lib.mr_last_gemm_kernel() == b''             # nothing launched, tracing off
+
+
+def test_grouped_gemm_validates_every_problem_before_launching():
+    """mr_gemm_grouped runs mr_gemm's operand checks per problem BEFORE handing the list to any kernel (advisor finding, round 3)."""
+    from merlot_reserve_amd import _lib
+    lib = _lib.load()
+    arr = (_lib.GemmArgs * 2)()
+    for g in arr:
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.transA = 512, 512, 4096, 512, 512, 512, 1
+        g.A = g.B = g.C = 1 << 20                        # aligned fake addresses: never dereferenced, the second problem is rejected first
+    arr[1].B = (1 << 20) + 2                             # misaligned
+    assert lib.mr_gemm_grouped(arr, 2, None) == -1 and b'problem 1' in lib.mr_last_error() and b'aligned' in lib.mr_last_error()
+    arr[1].B = 1 << 20
+    arr[1].K = 0
+    assert lib.mr_gemm_grouped(arr, 2, None) == -1 and b'problem 1 is empty' in lib.mr_last_error()

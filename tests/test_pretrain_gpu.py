@@ -16,11 +16,11 @@ from tests.util import oracle_batch, oracle_draws, relerr, tiny_setup, tree_to
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, B=2, seed=3, hidden_size=128):
+def _setup(dev, B=2, seed=3, hidden_size=128, model_flags=None):
     from merlot_reserve_amd.config import Dims
     from merlot_reserve_amd.engine import PretrainEngine
     from merlot_reserve_amd.planner import build_plan
-    cfg, store, batch, splits, z = tiny_setup(B=B, seed=seed, device=dev, hidden_size=hidden_size)
+    cfg, store, batch, splits, z = tiny_setup(B=B, seed=seed, device=dev, hidden_size=hidden_size, model_flags=model_flags)
     eng = PretrainEngine(cfg, B, store, dev)
     plan = build_plan(batch, Dims(cfg, B), splits, z)
     eng.forward(batch, plan=plan)
@@ -33,9 +33,10 @@ SECTIONS = (('imgs_to_audio', 'x', 'i2a_x'), ('imgs_to_audio', 'y', 'i2a_y'), ('
             ('stuff_to_span', 'y', 's2s_y'))
 
 
-def test_tiny_forward_and_loss_parity(dev):
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}], ids=['stock', 'no_vision'])     # no_vision: pretrain/pretrain_model.py:61-63
+def test_tiny_forward_and_loss_parity(dev, flags):
     from oracle import ref_torch as R
-    cfg, store, eng, batch, splits, z = _setup(dev)
+    cfg, store, eng, batch, splits, z = _setup(dev, model_flags=flags)
     eng.loss_and_grad_outputs()
     torch.cuda.synchronize()
     params = tree_to(store.work_tree(), torch.float32)
@@ -87,11 +88,12 @@ def test_loss_gradient_wrt_outputs(dev):
         assert e <= 1e-2, (name, e)
 
 
-def test_tiny_backward_parity(dev):
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}], ids=['stock', 'no_vision'])
+def test_tiny_backward_parity(dev, flags):
     """Backward of the whole forward graph for a GIVEN upstream gradient dE (so the check is independent of the
     conditioning of the loss at random init): every parameter gradient against autograd of the oracle."""
     from oracle import ref_torch as R
-    cfg, store, eng, batch, splits, z = _setup(dev)
+    cfg, store, eng, batch, splits, z = _setup(dev, model_flags=flags)
     g = torch.Generator().manual_seed(1)
     dE = (torch.randn(eng.R, eng.d.H, generator=g) * 1e-2).to(torch.bfloat16)
     eng.dE.copy_(dE.to(dev))
