@@ -318,6 +318,17 @@ def main():
         barrier()
         h2d_ms = (time.perf_counter() - t1) / n_h2d * 1e3
 
+    # N > 1 (or --force-comm): one instrumented eager step -- when each gradient bucket became final, when its all-reduce and its
+    # optimizer update ended, against the end of backward on the main stream -- so that the first run on a multi-GPU node shows by
+    # itself whether the collectives hide under backward (the graph-replayed steps above cannot be instrumented)
+    timeline = None
+    if comm is not None:
+        try:
+            timeline = trainer.train_step_timeline(batches[0])
+        except Exception as e:                                   # a diagnostic must not cost the benchmark line
+            timeline = {'error': f'{type(e).__name__}: {e}'}
+        barrier()
+
     roof, breakdown = None, None
     if not args.no_roofline:
         nprof = min(args.steps, 3)
@@ -425,6 +436,8 @@ def main():
         }
         if degraded:
             out['degraded'] = degraded
+        if timeline is not None:
+            out['config']['bucket_timeline_rank0'] = timeline
         if comm is not None:
             # RCCL chooses algorithm / protocol per call (its tuner, from message size and topology) unless the environment pins
             # them; what this run allowed it, and the message sizes it chose for

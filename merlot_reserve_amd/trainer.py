@@ -205,13 +205,26 @@ class Trainer:
         # whole-CU GEMM of either tower waits for CUs, and its HIP-event duration would include that wait)
         cs = producer if os.environ.get('MR_NO_COMM_STREAM') == '1' else self.comm_stream
         cs.wait_stream(producer)
+        tl = getattr(self, 'bucket_timeline', None)          # (eager steps only) HIP events around the bucket's collective: bench.py --gpus N
+
+        def ev():
+            if tl is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
         with torch.cuda.stream(cs):
             g = self.params.grad[lo:hi]
+            e_ready = ev()
             if self.use_comm:
                 ops.nan_to_num_(g)
                 self.comm.allreduce_mean(g)
+            e_reduced = ev()
             if update:
                 self.state.apply_range(lo, hi)
+            e_updated = ev()
+        if tl is not None:
+            tl.append((str(key), (hi - lo) * 2 / 1e6, e_ready, e_reduced, e_updated))
 
     def _backward_reduce_update(self, update=True):
         eng = self.engine
@@ -268,6 +281,34 @@ class Trainer:
         self._program(batch['images'], batch['audio_clips'])
         self.state.finish_step()
         return eng.loss_acc
+
+    def train_step_timeline(self, batch, plan=None):
+        """One EAGER step with HIP events around every gradient bucket's collective (events cannot be read back from a replayed graph):
+        returns {'backward_ms': start of backward -> its last kernel on the main stream, 'buckets': [{bucket, mbytes, ready_ms (its
+        gradients final = the all-reduce may start), reduced_ms, updated_ms}]}, times from the start of backward -- what the first run
+        on more than one GPU needs to see whether the all-reduces hide under backward (pretrain/pretrain_model.py:329 is the pmean
+        they implement).  A diagnostic: the step it times is a real optimizer step."""
+        eng = self.engine
+        if plan is None:
+            plan = self.plan(batch)
+        self.state.prepare_step()
+        eng.set_plan(plan)
+        eng.forward_device(batch['images'], batch['audio_clips'])
+        self._loss_and_exchange()
+        self.bucket_timeline = []
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        try:
+            self._backward_reduce_update(update=True)
+            t1.record()
+            tl = self.bucket_timeline
+        finally:
+            self.bucket_timeline = None
+        self.state.finish_step()
+        torch.cuda.synchronize()
+        return {'backward_ms': t0.elapsed_time(t1),
+                'buckets': [{'bucket': k, 'mbytes': round(mb, 1), 'ready_ms': round(t0.elapsed_time(a), 3), 'reduced_ms': round(t0.elapsed_time(b), 3),
+                             'updated_ms': round(t0.elapsed_time(c), 3)} for k, mb, a, b, c in tl]}
 
     # ---- hipGraph path: the step is a fixed launch sequence over fixed buffers; capture it once, replay per step ----
     def capture(self, batch):
