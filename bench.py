@@ -195,6 +195,7 @@ def main():
     ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL communicator, collectives inside the graph -- with a single rank')
     ap.add_argument('--strict-graph', action='store_true', help='exit non-zero (value null) instead of timing eager steps when the hipGraph capture fails')
     ap.add_argument('--no-secondary', action='store_true', help='skip the short timings of BASELINE configs 3-5 (large, large resadapt, VCR large) at N = 1')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE', help='library option for this run (mr_set_option; A/B of kernel paths), e.g. --option attn_onepass=0')
     ap.add_argument('--comm', default='native', choices=['native', 'torch'], help="native: the library's RCCL communicator (captured into the hipGraph); torch: torch.distributed nccl (eager step)")
     args = ap.parse_args()
 
@@ -208,6 +209,9 @@ def main():
     from merlot_reserve_amd.synthetic import make_batch
     from merlot_reserve_amd.trainer import Trainer
 
+    for kv in args.option:
+        k_, v_ = kv.split('=')
+        ops.set_option(k_, int(v_))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -434,6 +438,8 @@ def main():
                        'step_mfma_frac': step_flops / (dt / args.steps) / MFMA_BF16_PEAK},
             'roofline': roof, 'breakdown': breakdown,
         }
+        if args.option:
+            out['config']['options'] = args.option
         if degraded:
             out['degraded'] = degraded
         if timeline is not None:

@@ -64,6 +64,8 @@ const char* mr_last_error(void);
  *                   "gemm3" admits
  *   "gemm5"         -1 = default (off: measured slower) | 0 | 1 = every NT problem it can take runs on the
  *                   two-workgroups-per-CU kernel (gemm5.hip; tests, A/B);  "gemm5_stagger"  -1 = default | 0 | 1 | 2 | 3 : its start phase
+ *   "attn_onepass"  -1 = default: mr_attention_bwd runs its one-pass kernel (dQ, dK, dV from one sweep, one workgroup per (sequence,
+ *                   head)) for 128 < S <= 256 | 0 = never (the dQ + dK / dV kernel pair) | 1 = whenever S <= 256 (tests, A/B)
  *   "gemm_trace"    1 = every GEMM launch records the kernel it was routed to (mr_last_gemm_kernel; bench.py's per-kernel table)
  * Environment variables (MR_GEMM3, MR_G3_PH, ...: experiment scripts) are read only by a library built with -DMR_DEBUG_ENV
  * (MR_DEBUG_ENV=1 python -m merlot_reserve_amd.build); the product build ignores the environment.

@@ -789,6 +789,314 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ dQ, dK, dV in ONE pass (S <= 256)
+// One workgroup = EIGHT waves = one (sequence, head): wave w owns keys 32 w .. 32 w + 31 (K / 8 and V fragments and the dK^T / dV^T
+// accumulators in registers for the whole kernel, as in the dK / dV kernel above), the workgroup sweeps the queries in tiles of 64.
+// Per tile every score is computed ONCE -- S = Q K^T, dP = dO V^T, P = exp2(S log2 e - lse), dS = P (dP - delta) in the
+// [query rows, key column] layout, so P and dS are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS -- and only dS
+// crosses the LDS, once, for dQ: written TRANSPOSED ([key][query] tiles in the LDS-DMA image format, one 8-byte store per 4 queries)
+// and read back with ds_read_b64_tr_b16 as the B operand of dQ^T = K^T dS^T, whose A operand comes from the K tiles staged once per
+// workgroup -- the same transposed read on both, so the key permutation of the contraction index matches by construction.  Wave w
+// multiplies the 16-dim block w & 3 of dQ^T for the query half w >> 2 over all 256 keys.  5 matrix products and one exponential per
+// score instead of the two-pass kernels' 7 and 2, no delta buffer (rowsum(dO * O) is staged per tile by the whole workgroup), and
+// dQ is complete inside the workgroup: no atomics, no cross-workgroup sum, bitwise reproducible.  The dQ product of tile t runs at the
+// top of iteration t + 1 (its dS buffer is double buffered), so the tile loop keeps ONE barrier per tile.
+// Column sums (qkv bias gradient): ONE partial row per sequence, this head's 64 columns of the q, k and v thirds.
+constexpr int KP = 256;                         // keys per workgroup
+template <bool MASKED>
+__global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+                                                           const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
+                                                           const float* __restrict__ lse, __bf16* __restrict__ dqkv,
+                                                           const float* __restrict__ rot_tab, int64_t rot_rows,
+                                                           float* __restrict__ colsum, int64_t S, int64_t nh) {
+    __shared__ __attribute__((aligned(16))) char Kt[4][TILE_B];          // K of the sequence: tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) char Qs[2][TILE_B];          // row reads (S) and tr reads (dK^T)
+    __shared__ __attribute__((aligned(16))) char Ds[2][TILE_B];          // dO: row reads (dP) and tr reads (dV^T)
+    __shared__ __attribute__((aligned(16))) char dSs[2][4][TILE_B];      // dS^T: [64 keys][64 queries] images, tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
+    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
+    __shared__ __attribute__((aligned(16))) float red[8][64];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const AttnBlock ab_ = attn_block(1, (int)nh);
+    const int64_t seq = ab_.seq, h = ab_.h;
+    const int64_t H = nh * 64, ld = 3 * H;
+    const __bf16* base = qkv + seq * S * ld;
+    const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
+    const float inv_S = 1.0f / (float)S;
+
+    // ---- this wave's keys: K / 8 and V fragments, codes ----
+    bf16x8 kf[2][2], vf[2][2];
+    int ki[2], ck[2];
+    float nkl[2], unil[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        ki[kb] = wave * 32 + kb * 16 + i;
+        const bool ok = ki[kb] < S;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+            if (ok) {
+                v = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
+                w = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
+            }
+            kf[kb][dd] = scale_eighth(v);
+            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
+        }
+        ck[kb] = ok ? (MASKED ? code_seq[ki[kb]] : 0) : CODE_NONE;
+        nkl[kb] = ok ? NEG_BIAS : -INFINITY;
+        unil[kb] = ok ? 1.0f : 0.0f;
+    }
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { dk[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // ---- staging: K tiles once (4 pieces per wave), Q / dO tiles per iteration (1 + 1 piece per wave), per-query scalars ----
+    const __bf16* Qg = base + h * 64;
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Dg = dout + seq * S * H + h * 64;
+    const __bf16* Og = o + seq * S * H + h * 64;
+    const float* Lg = lse + (seq * nh + h) * S;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Dg), 0, (int)(((S - 1) * H + 64) * 2), 0x00020000);
+    const unsigned sq = dma_src(wave, lane, ld), sd = dma_src(wave, lane, H);
+    const unsigned q_step = (unsigned)(TK * ld * 2), d_step = (unsigned)(TK * H * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {               // K rows 64 j + 8 wave .. + 7 -> tile j, piece `wave`
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, Kt[j] + wave * 1024), 16, sq, (unsigned)j * q_step, 0, 0);
+    }
+    auto stage = [&](int t, int b) {             // this wave's piece of query tile t (Q rows, dO rows) -> buffer b
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, Qs[b] + wave * 1024), 16, sq, (unsigned)t * q_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, Ds[b] + wave * 1024), 16, sd, (unsigned)t * d_step, 0, 0);
+    };
+    // per-query scalars of a tile: thread (q = tid >> 3, c = tid & 7) holds 8 dims of dO and O -> delta = rowsum(dO * O) over the 8
+    // lanes of a query; lane c == 0 also fetches the query's lse and code
+    float er = 0.f, lr = 0.f, ur = 0.f;
+    int cr = 0;
+    auto side_load = [&](int64_t q0) {
+        const int64_t q = q0 + (tid >> 3);
+        const bool ok = q < S;
+        u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+        if (ok) {
+            a = *reinterpret_cast<const u32x4*>(Dg + q * H + (tid & 7) * 8);
+            bb = *reinterpret_cast<const u32x4*>(Og + q * H + (tid & 7) * 8);
+        }
+        float x[8], y[8];
+        unpack8(a, x);
+        unpack8(bb, y);
+        float dsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += x[e] * y[e];
+        dsum += __shfl_xor(dsum, 1, 64);
+        dsum += __shfl_xor(dsum, 2, 64);
+        dsum += __shfl_xor(dsum, 4, 64);
+        er = dsum;
+        const float L = ok ? Lg[q] : INFINITY;
+        const bool pad = MASKED && ok && L < PAD_LSE;
+        lr = -L * LOG2E;
+        int c = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
+        cr = (c < 0) ? CODE_PADQ : c;
+        ur = pad ? inv_S : 0.f;
+    };
+    auto side_store = [&](int b) {
+        if ((tid & 7) == 0) { const int q = tid >> 3; Ls[b][q] = lr; Dl[b][q] = er; Cs[b][q] = cr; Us[b][q] = ur; }
+    };
+    stage(0, 0);
+    side_load(0);
+    side_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // dQ^T of one tile: wave (db = wave & 3, query half wave >> 2) over all 256 keys
+    const int qdb = wave & 3, qh = wave >> 2;
+    f32x4 csq = {0.f, 0.f, 0.f, 0.f};
+    auto dq_tile = [&](int t, int b) {
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks2 = 0; ks2 < 4; ++ks2) {          // two 32-key steps per group of reads: 12 transposed reads in flight
+            s16x4 klo[2], khi[2], slo[2][2], shi[2][2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ks = 2 * ks2 + u;
+                tr_frag_d_issue(Kt[ks >> 1], 32 * (ks & 1), 16 * qdb, lane, klo[u], khi[u]);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) tr_frag_d_issue(dSs[b][ks >> 1], 32 * (ks & 1), 16 * (2 * qh + q2), lane, slo[u][q2], shi[u][q2]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 kt = tr_join(klo[u], khi[u]);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+                    dq[q2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, tr_join(slo[u][q2], shi[u][q2]), dq[q2], 0, 0, 0);
+            }
+        }
+        // lane holds dQ^T[d = 16 qdb + 4 g + r][query 64 t + 16 (2 qh + q2) + i]
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int64_t q = (int64_t)t * TK + 16 * (2 * qh + q2) + i;
+            if (q < S) {
+                const int d = qdb * 16 + g * 4;
+                f32x4 x = dq[q2] * 0.125f;
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + q) % rot_rows) * 32 + d);
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; csq[r] += (float)v[r]; }
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + q) * ld + h * 64 + d) = v;
+            }
+        }
+    };
+
+    const int nt = (int)((S + TK - 1) / TK);
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        if (t + 1 < nt) {
+            stage(t + 1, b ^ 1);
+            side_load((int64_t)(t + 1) * TK);
+        }
+        if (t > 0) dq_tile(t - 1, b ^ 1);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            // P and dS of this 32-query half, rounded to bf16 as soon as they exist (they are MFMA operands and the LDS payload as bf16
+            // anyway; as fp32 the four row blocks' values pushed the masked variant past 256 registers, and a spilled or copied result of
+            // the asm transposed reads is read before it lands)
+            bf16x4 pb[2][2], sb[2][2];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qb = 2 * t2 + q2;
+                const bf16x8 q0f = row_frag_d(Qs[b], qb * 16, 0, lane), q1f = row_frag_d(Qs[b], qb * 16, 1, lane);
+                const bf16x8 d0f = row_frag_d(Ds[b], qb * 16, 0, lane), d1f = row_frag_d(Ds[b], qb * 16, 1, lane);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
+                i32x4 c4 = {0, 0, 0, 0};
+                if (MASKED) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+                // rows without allowed key (PAD queries): uniform weight 1 / S over the existing keys, staged per query (0 for every other row)
+                f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
+                if (MASKED) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
+                    f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
+                    f32x4 pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, LOG2E, l4[r]));
+                    }
+                    if (MASKED) {         // (always, no wave-uniform shortcut: this variant only runs masked towers of <= 256 positions)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = (u4[r] > 0.f) ? u4[r] * unil[kb] : pv[r];
+                    }
+                    bf16x4 p4, w4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { p4[r] = (__bf16)pv[r]; w4[r] = (__bf16)(pv[r] * (dp[r] - e4[r])); }
+                    pb[kb][q2] = p4;
+                    sb[kb][q2] = w4;
+                    // dS^T -> LDS: key row 32 wave + 16 kb + i, queries 16 qb + 4 g .. + 3 (8 bytes), in the tiles' swizzled image
+                    {
+                        const int row = 32 * (wave & 1) + 16 * kb + i, col = 16 * qb + 4 * g;
+                        char* dst = dSs[b][wave >> 1] + row * 128 + (((col >> 3) ^ dswz(row)) << 4) + (col & 7) * 2;
+                        *reinterpret_cast<bf16x4*>(dst) = w4;
+                    }
+                }
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                pf[kb] = __builtin_shufflevector(pb[kb][0], pb[kb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                dsf[kb] = __builtin_shufflevector(sb[kb][0], sb[kb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                tr_frag_d_issue(Ds[b], 32 * t2, 16 * db, lane, dlo[db], dhi[db]);
+                tr_frag_d_issue(Qs[b], 32 * t2, 16 * db, lane, qlo[db], qhi[db]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                if (db == 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bf16x8 dot = tr_join(dlo[db], dhi[db]);
+                const bf16x8 qt = tr_join(qlo[db], qhi[db]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], dv[kb][db], 0, 0, 0);
+                    dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[kb][db], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < nt) side_store(b ^ 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 1 have landed; its dS stores are out
+        __syncthreads();
+    }
+    dq_tile(nt - 1, (nt - 1) & 1);
+
+    // ---- dK / dV of this wave's 32 keys (as in the two-pass kernel) + the column sums of everything this workgroup stored ----
+    f32x4 csk[4], csv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { csk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (ki[kb] < S) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int d = db * 16 + g * 4;
+                f32x4 x = dk[kb][db] * 0.125f;
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + ki[kb]) % rot_rows) * 32 + d);
+                bf16x4 a, c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r];
+                    csk[db][r] += (float)a[r]; csv[db][r] += (float)c[r];
+                }
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + H + h * 64 + d) = a;
+                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + 2 * H + h * 64 + d) = c;
+            }
+        }
+    }
+    if (colsum != nullptr) {      // wave-uniform: ONE partial row per sequence; this head's 64 columns of q, k, v
+        float* prow = colsum + seq * ld;
+        // k and v: every wave holds all 64 dims for its keys -> sum over the 16 lanes of a DPP row, then over the 8 waves
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            f32x4 (&cs)[4] = part ? csv : csk;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[db][r] = row16_sum(cs[db][r]);
+                if (i == 0) *reinterpret_cast<f32x4*>(&red[wave][db * 16 + g * 4]) = cs[db];
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum += red[w][tid];
+                prow[(1 + part) * H + h * 64 + tid] = sum;
+            }
+            __syncthreads();
+        }
+        // q: wave (qdb, qh) holds dims 16 qdb + 4 g .. + 3 for its query half
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csq[r] = row16_sum(csq[r]);
+        if (i == 0) *reinterpret_cast<f32x4*>(&red[qh][qdb * 16 + g * 4]) = csq;
+        __syncthreads();
+        if (tid < 64) prow[h * 64 + tid] = red[0][tid] + red[1][tid];
+    }
+}
+
 // MR_ATTN_QB_S (diagnostic): sequences longer than this use two query / key blocks per workgroup (default 64)
 static int64_t attn_qb_threshold() {
     static int64_t v = -1;
@@ -820,7 +1128,16 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     return MR_OK;
 }
 
+// The one-pass kernel takes sequences that one workgroup's 256 keys cover and that are long enough to fill its eight waves (the short
+// towers, S = 31 / 16, stay on the two-pass kernels' 64-key workgroups).  Option "attn_onepass": -1 = this rule | 0 = never | 1 = whenever S <= 256.
+static bool attn_onepass(int64_t S) {
+    const int v = mr_opts().attn_onepass;
+    if (v == 0 || S > KP) return false;
+    return v == 1 || S > 128;
+}
+
 extern "C" int64_t mr_attention_bwd_colsum_rows(int64_t nseq, int64_t S) {
+    if (attn_onepass(S)) return nseq;                                   // one partial row per sequence
     const int64_t per = (S > attn_qb_threshold()) ? 128 : 64;          // queries (keys) per workgroup
     return nseq * ((S + per - 1) / per);
 }
@@ -837,6 +1154,13 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     const __bf16* d = static_cast<const __bf16*>(dout);
     __bf16* g = static_cast<__bf16*>(dqkv);
     const __bf16* oo = static_cast<const __bf16*>(out);       // delta = rowsum(dO * O) is computed by the dQ kernel (for itself and for dK / dV)
+    if (attn_onepass(S)) {
+        const dim3 grid((unsigned)(nh * nseq));
+        if (code) hipLaunchKernelGGL((attn_bwd1_kernel<true>), grid, dim3(512), 0, s, q, code, oo, d, lse, g, rot_tab, rot_rows, colsum, S, nh);
+        else hipLaunchKernelGGL((attn_bwd1_kernel<false>), grid, dim3(512), 0, s, q, code, oo, d, lse, g, rot_tab, rot_rows, colsum, S, nh);
+        MR_CHECK_LAUNCH("mr_attention_bwd (one pass)");
+        return MR_OK;
+    }
     const bool two = S > attn_qb_threshold();
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \

@@ -14,6 +14,7 @@ struct MrOptions {
     int gemm_cus = 0;          // "gemm_cus"
     int gemm5 = -1;            // "gemm5"
     int gemm5_stagger = -1;    // "gemm5_stagger"
+    int attn_onepass = -1;     // "attn_onepass"
     int trace = 0;             // "gemm_trace": record the kernel every GEMM launch is routed to (mr_last_gemm_kernel)
 };
 

@@ -147,6 +147,7 @@ static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[
     auto launch = [&](int v, int set) {
         mr_set_option("gemm5", v == 0 ? 0 : 1);
         if (v) mr_set_option("gemm5_stagger", v - 1);
+        { const char* e = getenv("G5_CUS"); mr_set_option("gemm_cus", (v && e) ? atoi(e) : 0); }      // G5_CUS=128: 256 workgroups = one per CU
         setup_args(&g, c, set, colsum);
         if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); }
     };
@@ -167,6 +168,7 @@ static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[
     for (int v = 0; v < 4; ++v) out_us[v] = tot[v] * 1000.0 / n[v];
     mr_set_option("gemm5", -1);
     mr_set_option("gemm5_stagger", -1);
+    mr_set_option("gemm_cus", 0);
 }
 
 static int check_case(const Case& c, const char* label) {

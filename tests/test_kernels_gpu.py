@@ -219,9 +219,27 @@ ATTN_CASES = [(3, 241, 2, False), (5, 31, 2, False), (2, 640, 3, True), (7, 16, 
               (2, 1312, 16, True), (2, 577, 16, False)]
 
 
-@pytest.mark.parametrize('nseq,S,nh,masked', ATTN_CASES)
-def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
+# (case, attn_onepass): the library's own choice for every case (-1: the one-pass backward for 128 < S <= 256), plus both backward
+# paths forced -- the dQ + dK / dV kernel pair (0) and the one-pass kernel (1) -- wherever one workgroup's 256 keys cover the sequence
+ATTN_RUNS = [(c, -1) for c in ATTN_CASES] + [(c, v) for c in ATTN_CASES + [(2, 256, 2, False), (2, 200, 3, True), (3, 129, 2, False)]
+                                             if c[1] <= 256 for v in (0, 1)]
+
+
+@pytest.fixture
+def attn_path():
     from merlot_reserve_amd import ops
+
+    def use(v):
+        ops.set_option('attn_onepass', v)
+    yield use
+    ops.set_option('attn_onepass', -1)
+
+
+@pytest.mark.parametrize('case,onepass', ATTN_RUNS)
+def test_attention_fwd_bwd(dev, case, onepass, attn_path):
+    from merlot_reserve_amd import ops
+    nseq, S, nh, masked = case
+    attn_path(onepass)
     H = nh * 64
     qkv = rnd((nseq * S, 3 * H), dev, seed=1)
     code = None
@@ -269,13 +287,15 @@ def test_attention_fwd_bwd(dev, nseq, S, nh, masked):
     assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
 
 
+@pytest.mark.parametrize('onepass', [-1, 1])
 @pytest.mark.parametrize('nseq,S,nh,masked', [(2, 241, 2, False), (1, 100, 2, True), (3, 31, 2, False)])
-def test_attention_reads_nothing_past_the_sequence(dev, nseq, S, nh, masked):
+def test_attention_reads_nothing_past_the_sequence(dev, nseq, S, nh, masked, onepass, attn_path):
     """The K / V (Q / dO) tiles are fetched by LDS-DMA in whole 64-row tiles; rows past a sequence's end must come back as zeros (the
     buffer descriptor's extent), never as whatever lies behind: here the operands are leading views of NaN-filled allocations, so a
     read past the LAST sequence meets NaN; and the first sequence computed alone (followed by NaN instead of the second sequence's
     rows) must give bit-identical rows, so nothing of a neighbouring sequence leaks in either."""
     from merlot_reserve_amd import ops
+    attn_path(onepass)
     H = nh * 64
     rows = nseq * S
     big = torch.full((rows + 256, 3 * H), float('nan'), dtype=BF16, device=dev)
@@ -307,12 +327,14 @@ def test_attention_reads_nothing_past_the_sequence(dev, nseq, S, nh, masked):
         assert torch.equal(out1[:S], out[:S]) and torch.equal(lse1[0], lse[0])
 
 
-@pytest.mark.parametrize('nseq,S,nh', [(2, 22, 2), (1, 130, 2)])
-def test_attention_bwd_through_pad_query_rows(dev, nseq, S, nh):
+@pytest.mark.parametrize('onepass', [-1, 0, 1])
+@pytest.mark.parametrize('nseq,S,nh', [(2, 22, 2), (1, 130, 2), (3, 241, 2)])
+def test_attention_bwd_through_pad_query_rows(dev, nseq, S, nh, onepass, attn_path):
     """A PAD query row has no allowed key: every score is exactly -1e10, the reference's softmax is uniform over all S
     keys and autodiff sends its upstream gradient to q, k and v (the VCR head can pool at such a row when a sequence has
     no MASK).  Its LSE (-1e10 + ln S) is not representable in fp32, so the backward must not recompute P from it."""
     from merlot_reserve_amd import ops
+    attn_path(onepass)
     H = nh * 64
     qkv = rnd((nseq * S, 3 * H), dev, seed=4)
     c = torch.zeros(nseq, S, dtype=torch.int32)
