@@ -372,5 +372,11 @@ bool mr_gemm5_wanted(const mr_gemm_args* a) {
     if (v == 0 || a->colsum != nullptr && !a->aux) return false;
     if (!mr_gemm5_takes(a)) return false;
     if (v == 1) return true;
-    return false;
+    // Default policy (measured, scripts/micro/gemm3_test g5time): the few-tile short-K problems -- at most one 256 x 128 tile per CU, K <= 1024:
+    // the audio / span towers' 768-wide projections, the span and VCR-ViT QKV -- run 8-13 % faster here than on the one-barrier kernel's
+    // 96-wide tiles (16.3 vs 18.0, 20.6 vs 23.4, 15.3 vs 17.4, 24.5 vs 26.9 us); everything with more tiles or a longer K is slower
+    // (the 256 x 128 tile pair of a CU writes 1.5 x the operand bytes into LDS: DESIGN.md section 3).
+    if (a->colsum != nullptr || a->M < 1024) return false;
+    const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
+    return tiles <= 256 && a->K <= 1024 && a->N >= 256;
 }

@@ -183,18 +183,24 @@ class VCREngine(TowerEngine):
         self.gemm(dl, self.pooled_h, G['proj/kernel'], transA=True)                   # d proj [1, H] = dlogits^T . pooled_h
         self.gemm(dl, W['proj/kernel'], self.d_pooled)                                # d pooled_h = dlogits . proj^T
         ops.segment_sum([self.d_pooled], self._pl('poolT_indptr'), self._pl('poolT_idx'), self.Dj)   # zero except the pooled rows
-        Dj = self.encoder_backward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'), self.Dj)
+        # the tower-level reductions (final / pre LayerNorm) are deferred into ONE mr_reduce_partials launch each side of the layers, as in
+        # the pretraining engine (they were two-level immediate reductions here: 19 launches of ~68 us per VCR step, round-3 profile)
+        tr = self._begin_tower_reductions()
+        Dj = self.encoder_backward(tj, 'joint_transformer', self.joint_rot, self._pl('joint_code'), self.Dj, tr=tr)
+        self._flush_tower_reductions(tr)
         ops.segment_sum([Dj], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])
         ops.segment_sum([Dj], self.visT[0], self.visT[1], self.d_imgs_seq)
 
     def backward_stage_vision(self, layer_done=None):
         d, G, tv = self.d, self.p.g, self.tv
+        tr = self._begin_tower_reductions()
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.vit_rot, self.vit_pool_rows,
                                             self.v_qin, self.v_q, self.v_k, self.v_v, self.v_po, self.v_probs, self.d_imgs_seq,
-                                            self.d_v_cls, self.Dv, layer_done=layer_done)
+                                            self.d_v_cls, self.Dv, layer_done=layer_done, tr=tr)
         Dp = self.cur.Dpatch[:d.B * d.hw]
         ops.segment_sum([Dv], self.unpad_v[0], self.unpad_v[1], Dp)
-        ops.colsum(Dp, G['vision_encoder/embedding/bias'], self.cur.cs_ws)
+        self._t_colsum(tr, Dp, G['vision_encoder/embedding/bias'])
+        self._flush_tower_reductions(tr)
         self.gemm(self._images2d, Dp, G['vision_encoder/embedding/kernel'], transA=True)
 
     def loss_info(self):
