@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
         }                                                                                                               \
     } while (0)
 #define G5_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef MR_G5_STAMPS        /* diagnostic build: s_memtime at the start of a tile's k-loop, at its end and at the end of its epilogue -> workspace */
+#define G5_STAMP(slot)                                                                                         \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        if (tid == 0 && qc < 8) static_cast<unsigned long long*>(p0.workspace)[(blockIdx.x * 8 + qc) * 4 + (slot)] = t_; \
+    } while (0)
+#else
+#define G5_STAMP(slot) do {} while (0)
+#endif
 #ifdef MR_G5_NOREAD        /* timing-only diagnostic builds (wrong results): scripts/build_g5_variants.sh */
 #define G5_RD(dst, ptr) asm volatile("" : "+v"(dst))
 #else
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
             if constexpr (!LAST) rs = (rs == NSTG - 1) ? 0 : rs + 1;
             G5_ADVANCE();
         };
+        G5_STAMP(0);
         step(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
         for (int t = 1; t + 2 < nks; t += 2) {
             step(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
@@ -239,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
         }
         step(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});          // (K % 64 == 0: an even number of steps >= 4)
 
+        G5_STAMP(1);
         // ---------------- epilogue (bf16 output; registers + ordinary loads, no LDS) ----------------
         {
             const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
             have_stores = true;
 #endif
         }
+        G5_STAMP(2);
         ++qc;
         cm0 = item_m0(qc);
         cn0 = item_n0(qc);

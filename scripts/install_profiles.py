@@ -1,4 +1,4 @@
-"""Copies the evidence scripts/r03_profiles.sh left under gpurun_out/ into profiles/ under the round's names (the judged, committed
+"""Copies the evidence scripts/r0N_profiles.sh left under gpurun_out/ into profiles/ under the round's names (the judged, committed
 copies): rocprofv3 kernel summaries of BASELINE configs 2-5, the PMC passes, the vendor-library comparison.
 python scripts/install_profiles.py [round tag, default r03]"""
 import json, os, shutil, sys
@@ -16,12 +16,13 @@ with open(os.path.join(G, f'{tag}_gemm_vs_hipblaslt.txt')) as f:
     lines = [l for l in f if 'amdgpu.ids' not in l]
 open(os.path.join(P, f'{tag}_gemm_vs_hipblaslt.txt'), 'w').writelines(lines)
 k = json.load(open(os.path.join(G, 'pmc_step.json')))
+commit = os.environ.get('MR_COMMIT') or (open(os.path.join(G, 'profile_commit.txt')).read().strip() if os.path.exists(os.path.join(G, 'profile_commit.txt')) else 'not recorded')
 nsteps = 4        # bench.py --no-graph --steps 2 --warmup 1: 1 eager first step + 1 warm-up + 2 timed
 tot = lambda sel: sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for n, v in k.items() if sel(n)) / nsteps
 out = {'_about': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/pmc_step.sh) over "bench.py --no-graph --steps 2 --warmup 1 '
                  '--no-roofline --no-h2d --no-secondary" (base, 4 records/GPU; incl. the eager first step: 4 steps of launches); bytes per launch, '
                  'FETCH_SIZE x2 x1024 per the gfx950 correction (MI355X_MICROARCH.md, HBM section), WRITE_SIZE x1024',
        'bytes_per_step_all_kernels': tot(lambda n: 'cast_params' not in n), 'bytes_per_step_gemm': tot(lambda n: 'gemm' in n or 'splitk' in n),
-       'kernels': k, 'workload': {'model': 'base', 'records_per_gpu': 4}}
+       'kernels': k, 'workload': {'model': 'base', 'records_per_gpu': 4}, 'commit': commit}
 json.dump(out, open(os.path.join(P, f'{tag}_pmc_hbm_traffic.json'), 'w'), indent=1, sort_keys=True)
 print(f"installed {tag}_pmc_hbm_traffic.json: {out['bytes_per_step_all_kernels'] / 1e9:.1f} GB / step, {out['bytes_per_step_gemm'] / 1e9:.1f} GB in GEMMs")

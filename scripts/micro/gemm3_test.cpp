@@ -318,6 +318,39 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+
+    if (!strcmp(what, "g5stamps")) {
+        // in-kernel timeline of the two workgroups of a CU (library built with -DMR_G5_STAMPS): per tile, k-loop start / end, epilogue end
+        const int mode = argc > 2 ? atoi(argv[2]) : 2, st = argc > 3 ? atoi(argv[3]) : 1;
+        const Case c = {15424, 3072, 768, mode, "stamps"};
+        mr_gemm_args g;
+        mr_set_option("gemm5", 1);
+        mr_set_option("gemm5_stagger", st);
+        for (int r = 0; r < 20; ++r) { setup_args(&g, c, r % 3, mode == 4); mr_gemm(&g, nullptr); }
+        CK(hipDeviceSynchronize());
+        CK(hipMemset(dWs, 0, 512 * 8 * 4 * 8));
+        setup_args(&g, c, 0, mode == 4);
+        mr_gemm(&g, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(512 * 8 * 4);
+        CK(hipMemcpy(h.data(), dWs, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 512; ++b) if (h[b * 32] && h[b * 32] < t0) t0 = h[b * 32];
+        printf("mode %d stagger %d: blocks b and b + 256 share a CU; cycles from the first k-loop start\n", mode, st);
+        for (int b : {0, 1, 8, 100, 255}) {
+            for (int w = 0; w < 2; ++w) {
+                const int bb = b + 256 * w;
+                printf("  block %3d:", bb);
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long* e = &h[(bb * 8 + q) * 4];
+                    if (!e[0]) break;
+                    printf("  [k %6llu-%6llu e -%6llu]", e[0] - t0, e[1] - t0, e[2] - t0);
+                }
+                printf("\n");
+            }
+        }
+        mr_set_option("gemm5", -1); mr_set_option("gemm5_stagger", -1);
+    }
     if (!strcmp(what, "tn") || !strcmp(what, "all")) {
         // weight gradients of a layer (x 2 layers): A = activations [K = tokens, in], B = upstream gradients [K, out]
         struct WG { int64_t M, N; };
