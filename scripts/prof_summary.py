@@ -1,20 +1,20 @@
 """Summarise a rocprofv3 kernel_stats.csv: per-kernel total / avg, normalised per step.
 usage: prof_summary.py kernel_stats.csv [bench args as given to bench.py ...]   (steps are derived from --steps / --warmup /
---no-roofline: 1 eager + warm-up + timed + 2 x min(timed, 3) instrumented eager steps)"""
+--no-roofline: 1 eager + warm-up + timed + 3 x min(timed, 3) instrumented eager steps)"""
 import csv, sys
 path, args = sys.argv[1], sys.argv[2:]
 def opt(name, default):
     return int(args[args.index(name) + 1]) if name in args else default
 K, W = opt('--steps', 10), opt('--warmup', 3)
 h2d = 0 if "--no-h2d" in args or "--no-graph" in args else max(3 * K, 30) + 2          # bench.py's host-fed leg
-steps = 1 + W + K + (0 if "--no-roofline" in args else 2 * min(K, 3)) + h2d
+steps = 1 + W + K + (0 if "--no-roofline" in args else 3 * min(K, 3)) + h2d
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'cast_params' not in r['Name'])
 if '--total-steps' in args:      # a run that is not bench.py (scripts/bench_vcr.py): the number of steps that launched kernels, given by the caller
     steps = opt('--total-steps', steps)
     print(f'# steps in the profiled run: {steps}')
 else:
-    print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 2 x {min(K, 3)} instrumented eager')
+    print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 3 x {min(K, 3)} instrumented eager')
           + (f' + {h2d} replays fed from host memory' if h2d else '') + ')')
 if '--bench-log' in args:      # the bench line of the SAME run: under rocprofv3 every dispatch is serialised and stamped, so the step is
     import json                # slower than un-profiled and ~equal to the kernel sum; the un-profiled step overlaps the towers' tails
