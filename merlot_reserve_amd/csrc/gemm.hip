@@ -88,9 +88,9 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* tile, int own0, int kk
 
 // gridDim.y = number of K splits: split s handles k-tiles [s*kt_per_split, min((s+1)*kt_per_split, nk)) and, when
 // gridDim.y > 1, stores its fp32 partial tile to p.workspace[s][M][N] (summed by splitk_reduce_kernel).
+// One 128 x 128 output tile (`wgid` of a problem with tiles_n column tiles), K range blockIdx.y when the grid has a y extent.
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p, int tiles_n, int kt_per_split) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * TILE_ELEMS];
+__device__ __forceinline__ void gemm_bf16_tile(const mr_gemm_args& p, __bf16* smem, int wgid, int tiles_n, int kt_per_split) {
     __bf16* As = smem;
     __bf16* Bs = smem + TILE_ELEMS;
 
@@ -99,11 +99,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, li = lane & 15;
-
-    // XCD-aware (bijective) block -> tile map: blocks that share an XCD's L2 get neighbouring tiles.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
     const int64_t m0 = (int64_t)(wgid / tiles_n) * BM;
     const int64_t n0 = (int64_t)(wgid % tiles_n) * BN;
 
@@ -263,6 +258,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p,
     }
 }
 
+// gridDim.y = number of K splits (see gemm_bf16_tile)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const mr_gemm_args p, int tiles_n, int kt_per_split) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * TILE_ELEMS];
+    // XCD-aware (bijective) block -> tile map: blocks that share an XCD's L2 get neighbouring tiles.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    gemm_bf16_tile<TA, TB>(p, smem, wgid, tiles_n, kt_per_split);
+}
+
+// Several small problems of ONE operand layout in one launch (the contrastive loss's six logits / d-query / d-key products, each a
+// 17-23 us latency chain of 12 k-tiles on one or two workgroups when launched alone): block -> (problem, tile), no split-K.
+constexpr int SMALL_MAXG = 8;
+struct SmallGroup {
+    int count;
+    int tile_start[SMALL_MAXG + 1];
+    int tiles_n[SMALL_MAXG];
+    mr_gemm_args p[SMALL_MAXG];
+};
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_grouped_kernel(const SmallGroup ga) {
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * TILE_ELEMS];
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < SMALL_MAXG; ++k) j += (k < ga.count && (int)blockIdx.x >= ga.tile_start[k]);
+    const mr_gemm_args& p = ga.p[j];
+    gemm_bf16_tile<TA, TB>(p, smem, (int)blockIdx.x - ga.tile_start[j], ga.tiles_n[j], (int)((p.K + BK - 1) / BK));
+}
+
 // C[m,n] = sum_s partial[s][m][n] (+ bias[n]); bf16 or fp32 output; N % 4 == 0
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t M, int64_t N, const __bf16* __restrict__ bias,
                                      void* __restrict__ C, int64_t ldc, int c_dtype) {
@@ -399,6 +424,39 @@ extern "C" int mr_gemm_grouped(const mr_gemm_args* list, int32_t count, void* st
     if (use_gemm256() && count <= 20 && mr_gemm3_tn_grouped(list, count, s)) {      // weight gradients: the TN ping-pong kernel
         MR_CHECK_LAUNCH("mr_gemm_grouped (ping-pong kernel)");
         return MR_OK;
+    }
+    // small problems of one layout (none of which the big kernels would take): ONE launch of the 128 x 128 kernel over all their tiles
+    if (count > 1 && count <= SMALL_MAXG) {
+        bool small = true;
+        int64_t tiles = 0;
+        SmallGroup sg;
+        for (int k = 0; small && k < count; ++k) {
+            const mr_gemm_args* a = &list[k];
+            small = a->transA == list[0].transA && a->transB == list[0].transB && !(use_gemm256() && (mr_gemm5_wanted(a) || mr_gemm3_eligible(a) || mr_gemm256_eligible(a)));
+            small = small && ((a->transA ? a->M : a->K) + 7) / 8 * 8 <= a->lda && ((a->transB ? a->K : a->N) + 7) / 8 * 8 <= a->ldb;
+            small = small && (a->c_dtype == MR_DT_BF16 || (a->c_dtype == MR_DT_F32 && !a->residual && !a->aux && !a->c2 && a->act == MR_ACT_NONE && a->out_grp == 0));
+            small = small && !a->colsum && (!a->rot_tab || a->rot_rows > 0);
+            small = small && (a->c_dtype != MR_DT_BF16 || ((!a->residual || a->ldr % 8 == 0) && (!a->aux || a->ldaux % 8 == 0)));
+            if (!small) break;
+            const int64_t tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
+            sg.tile_start[k] = (int)tiles;
+            sg.tiles_n[k] = (int)tn;
+            sg.p[k] = *a;
+            tiles += tm * tn;
+        }
+        if (small && tiles <= 4096) {
+            sg.count = count;
+            for (int k = count; k <= SMALL_MAXG; ++k) sg.tile_start[k] = (int)tiles;
+            dim3 grid((unsigned)tiles), block(256);
+            const bool ta = list[0].transA, tb = list[0].transB;
+            if (!ta && !tb) hipLaunchKernelGGL((gemm_bf16_grouped_kernel<false, false>), grid, block, 0, s, sg);
+            else if (!ta && tb) hipLaunchKernelGGL((gemm_bf16_grouped_kernel<false, true>), grid, block, 0, s, sg);
+            else if (ta && !tb) hipLaunchKernelGGL((gemm_bf16_grouped_kernel<true, false>), grid, block, 0, s, sg);
+            else hipLaunchKernelGGL((gemm_bf16_grouped_kernel<true, true>), grid, block, 0, s, sg);
+            mr_note_route("gemm_bf16_grouped_kernel<%d,%d> x%d", (int)ta, (int)tb, count);
+            MR_CHECK_LAUNCH("mr_gemm_grouped (small problems)");
+            return MR_OK;
+        }
     }
     if (count > 4) {        // the one-barrier kernel groups <= 4 problems per launch
         for (int k = 0; k < count; k += 4) {

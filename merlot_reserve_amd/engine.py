@@ -103,6 +103,22 @@ class TowerEngine:
     def gemm_args(self, a, b, out, **kw):
         return ops.gemm_args(a, b, out, ws=None if self.cur is None else self.cur.gemm_ws, **kw)
 
+    def fgemm_grouped(self, items):
+        """Several independent forward Dense layers [(a, weight name, out, kwargs)] in one mr_gemm_grouped call (small problems of one
+        operand layout share a launch; anything else falls back to one launch each inside the library)."""
+        wT = getattr(self.p, 'wT', None) if self.dtype == BF16 else None
+        if self.dtype != BF16 or os.environ.get('MR_NO_SMALL_GROUPING') == '1':
+            for a, name, out, kw in items:
+                self.fgemm(a, name, out, **kw)
+            return
+        args = []
+        for a, name, out, kw in items:
+            if wT and name in wT and os.environ.get('MR_NO_WT') != '1':
+                args.append(self.gemm_args(a, wT[name], out, transB=True, **kw))
+            else:
+                args.append(self.gemm_args(a, self.W[name], out, **kw))
+        ops.gemm_grouped(args)
+
     # tower-level deferred reductions: between _begin_tower_reductions() and _flush_tower_reductions() every LayerNorm /
     # colsum issued through _t_ln_bwd / _t_colsum leaves its partial rows in a workspace of its own
     def _begin_tower_reductions(self):
@@ -324,9 +340,10 @@ class TowerEngine:
         W, nh = self.W, st.H // 64
         ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
         self.encoder_forward(st, prefix_t, rot, None)
-        self.fgemm(self._cls_view(st.xf, st.nseq, st.S), f'{prefix_t}/cls_proj/kernel', out_cls, bias=W[f'{prefix_t}/cls_proj/bias'])
         ops.rows_mean_fwd(st.xf, pool_rows, qin)
-        self.fgemm(qin, f'{prefix_pool}/query/kernel', q, bias=W[f'{prefix_pool}/query/bias'])
+        # the CLS head and the pool's query projection are independent small GEMMs (64 / 1152 rows): one grouped launch
+        self.fgemm_grouped([(self._cls_view(st.xf, st.nseq, st.S), f'{prefix_t}/cls_proj/kernel', out_cls, dict(bias=W[f'{prefix_t}/cls_proj/bias'])),
+                            (qin, f'{prefix_pool}/query/kernel', q, dict(bias=W[f'{prefix_pool}/query/bias']))])
         self.fgemm(st.xf, f'{prefix_pool}/key/kernel', k, bias=W[f'{prefix_pool}/key/bias'])
         self.fgemm(st.xf, f'{prefix_pool}/value/kernel', v, bias=W[f'{prefix_pool}/value/bias'])
         ops.poolattn_fwd(q, k, v, pool_rows, po, probs, nh)
@@ -339,12 +356,22 @@ class TowerEngine:
         Gn = qin.shape[0]
         d_po, d_q, d_qin = self.cur.d_pool_po[:Gn], self.cur.d_pool_q[:Gn], self.cur.d_pool_qin[:Gn]
         d_k, d_v = self.cur.d_k[:M], self.cur.d_v[:M]
+        # the small weight gradients of the head (pool out / query projections, cls_proj: K = 1152 / 1152 / 64 rows) feed nothing in this
+        # backward: they leave the chain of data gradients and run as ONE grouped launch at its end
+        small_wgrads = []
+        defer = self.dtype == BF16 and os.environ.get('MR_NO_SMALL_GROUPING') != '1'
+
+        def wgrad(x, dy, out):
+            if defer:
+                small_wgrads.append(self.gemm_args(x, dy, out, transA=True))
+            else:
+                self.gemm(x, dy, out, transA=True)
         self._t_colsum(tr, d_seq, G[f'{prefix_pool}/out/bias'])
-        self.gemm(po, d_seq, G[f'{prefix_pool}/out/kernel'], transA=True)
+        wgrad(po, d_seq, G[f'{prefix_pool}/out/kernel'])
         self.gemm(d_seq, W[f'{prefix_pool}/out/kernel'], d_po, transB=True)
         ops.poolattn_bwd(q, k, v, pool_rows, probs, d_po, d_q, d_k, d_v, nh)
         self._t_colsum(tr, d_q, G[f'{prefix_pool}/query/bias'])
-        self.gemm(qin, d_q, G[f'{prefix_pool}/query/kernel'], transA=True)
+        wgrad(qin, d_q, G[f'{prefix_pool}/query/kernel'])
         self.gemm(d_q, W[f'{prefix_pool}/query/kernel'], d_qin, transB=True)
         self._t_colsum(tr, d_k, G[f'{prefix_pool}/key/bias'])
         self.gemm(d_k, W[f'{prefix_pool}/key/kernel'], D, transB=True)
@@ -356,9 +383,11 @@ class TowerEngine:
         # cls head
         cls_in = self._cls_view(st.xf, st.nseq, st.S)
         self._t_colsum(tr, d_cls, G[f'{prefix_t}/cls_proj/bias'])
-        self.gemm(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'], transA=True)
+        wgrad(cls_in, d_cls, G[f'{prefix_t}/cls_proj/kernel'])
         Dc = self._cls_view(D, st.nseq, st.S)
         self.gemm(d_cls, W[f'{prefix_t}/cls_proj/kernel'], Dc, transB=True, residual=Dc)
+        if small_wgrads:
+            ops.gemm_grouped(small_wgrads)
         D = self.encoder_backward(st, prefix_t, rot, None, D, layer_done=layer_done, tr=tr, extra_wgrads=extra)
         ops.sum_rows_strided(D, st.nseq, st.S, 0, G[f'{prefix_t}/cls'])
         return D
@@ -583,11 +612,17 @@ class PretrainEngine(TowerEngine):
         self.dE.zero_()
         self.loss_acc.zero_()
         self.diag.zero_()
-        for p in self.cprob:
-            q = self.E[p['q_off']:p['q_off'] + p['Lq']]
+        # The six (objective, direction) problems are independent: each of the three products runs as ONE grouped launch over all of
+        # them (bf16 program; alone, every one of these 18 GEMMs is a 17-23 us latency chain of k-tiles on one or two workgroups).
+        grouped = not self.fwd_only and os.environ.get('MR_NO_LOSS_GROUPING') != '1'
+        qs = [self.E[p['q_off']:p['q_off'] + p['Lq']] for p in self.cprob]
+        if grouped:
+            ops.gemm_grouped([self.gemm_args(q, self.Kcat[p['kb']:p['kb'] + p['V']], p['logits'], transB=True) for p, q in zip(self.cprob, qs)])
+        for p, q in zip(self.cprob, qs):
             kb, V, ldv = p['kb'], p['V'], p['ldv']
             logits = p['logits']
-            self.gemm(q, self.Kcat[kb:kb + V], logits, transB=True)               # rank-major columns (:290)
+            if not grouped:
+                self.gemm(q, self.Kcat[kb:kb + V], logits, transB=True)               # rank-major columns (:290)
             is_s2s = p['name'] == 'stuff_to_span'
             ops.contrastive_lse(logits[:, :V], rank * p['nk'], 0.5 / p['Lq'], self._pl('t2sp_src') if is_s2s else None,
                                 self.loss_acc[p['oi']:p['oi'] + 1], self.diag[p['di']] if is_s2s else None, self.lse_rows)
@@ -595,8 +630,14 @@ class PretrainEngine(TowerEngine):
                 continue
             dl = p['dl']                                                           # [Lq, hi(ldv) | lo(ldv)]; pad columns stay 0
             ops.split_hilo_rows(logits[:, :V], dl[:, :V], dl[:, ldv:ldv + V])
-            self.gemm(dl, self.Kcat[kb:kb + 2 * ldv], self.dE[p['q_off']:p['q_off'] + p['Lq']])     # d(query side) = dlogits . keys
-            self.gemm(dl, q, self.DK[kb:kb + 2 * ldv], transA=True)               # d(key side)   = dlogits^T . queries (hi rows, lo rows)
+            if not grouped:
+                self.gemm(dl, self.Kcat[kb:kb + 2 * ldv], self.dE[p['q_off']:p['q_off'] + p['Lq']])     # d(query side) = dlogits . keys
+                self.gemm(dl, q, self.DK[kb:kb + 2 * ldv], transA=True)               # d(key side)   = dlogits^T . queries (hi rows, lo rows)
+        if grouped:
+            ops.gemm_grouped([self.gemm_args(p['dl'], self.Kcat[p['kb']:p['kb'] + 2 * p['ldv']], self.dE[p['q_off']:p['q_off'] + p['Lq']])
+                              for p in self.cprob])                                # d(query side) = dlogits . keys
+            ops.gemm_grouped([self.gemm_args(p['dl'], q, self.DK[p['kb']:p['kb'] + 2 * p['ldv']], transA=True)
+                              for p, q in zip(self.cprob, qs)])                    # d(key side)   = dlogits^T . queries (hi rows, lo rows)
         if not self.fwd_only:
             if world == 1:
                 ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], self.dE, accumulate=True)
