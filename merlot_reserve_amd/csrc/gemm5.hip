@@ -42,32 +42,41 @@ using namespace g256;
 #endif
 
 constexpr int BN5 = 128;
-constexpr int STG_A = 256 * 64, STG_B = BN5 * 64, STG = STG_A + STG_B, NSTG = 3;
-constexpr int LDS5 = NSTG * STG;
-static_assert(LDS5 == 72 * 1024 && 2 * LDS5 <= 160 * 1024, "two workgroups per CU");
+constexpr int STG_A = 256 * 64, NSTG = 3;
+// NW = 4: the two-workgroups-per-CU geometry (256 x 128 tile, 72 KiB).  NW = 8 (experiment, option "gemm5" = 2): ONE workgroup of eight
+// waves as 2 x 4 on a 256 x 256 tile (96 KiB) -- the ping-pong kernel's geometry and operand traffic under THIS kernel's k-loop (BK = 32
+// steps, one barrier per step, no wave-group phases).
+template <int NW> struct Geo5 {
+    static constexpr int BN = NW == 4 ? 128 : 256;
+    static constexpr int STG_B = BN * 64, STG = STG_A + STG_B, LDS = NSTG * STG;
+    static constexpr int PA = 16 / NW, PB = (BN / 16) / NW, ND = PA + PB;         // 1-KiB pieces per wave and step: A, B, both
+};
+static_assert(Geo5<4>::LDS == 72 * 1024 && 2 * Geo5<4>::LDS <= 160 * 1024 && Geo5<8>::LDS == 96 * 1024, "LDS budgets");
 
 __device__ __forceinline__ int swz5(int row) { return (0 - ((row >> 2) & 3)) & 3; }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const int stagger_mode, const int stagger_units) {
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, const int stagger_mode, const int stagger_units) {
     constexpr int NJ = 4, WCOLS = 64;
+    using GEO = Geo5<NW>;
+    constexpr int STG = GEO::STG, PA = GEO::PA, PB = GEO::PB, ND = GEO::ND, BNT = GEO::BN;
     // store instructions a wave issues per tile (all unconditional, see gemm3_epilogue.inc): the first step behind an epilogue may
     // leave them -- and its own 6 requests -- outstanding while it waits for the stage requested AHEAD of the epilogue
     constexpr int NST = 8 * (NJ / 2) * (MODE == 2 ? 2 : 1);
-    constexpr int WAIT_FIRST = 6 + NST;
+    constexpr int WAIT_FIRST = ND + NST;
     static_assert(WAIT_FIRST <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) char smem[LDS5];
+    __shared__ __attribute__((aligned(16))) char smem[GEO::LDS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = NW == 4 ? wave >> 1 : wave >> 2, wc = NW == 4 ? wave & 1 : wave & 3;
     const int g = lane >> 4, li = lane & 15;
 
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     int m0v, n0v;
-    item_pp(ga, bperm, lane, G, BN5, m0v, n0v);
+    item_pp(ga, bperm, lane, G, BNT, m0v, n0v);
     auto item_m0 = [&](int q) -> int { const int r = __builtin_amdgcn_readlane(m0v, q & 63); return q < 64 ? r : -1; };
     auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
     if (item_m0(0) < 0) return;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
         return (unsigned)row * ld2 + (unsigned)(((lane & 3) ^ swz5(row)) * 16);
     };
     // one per-lane offset per operand: a wave's pieces are 16 rows apart, a wave-uniform stride that rides in the scalar offset
-    const unsigned pao = rel(wave * 4, lda2), pbo = rel(wave * 2, ldb2);
+    const unsigned pao = rel(wave * PA, lda2), pbo = rel(wave * PB, ldb2);
     const unsigned pstep_a = 16u * lda2, pstep_b = 16u * ldb2;
     // fragment reads: lane (g, li) of a 16-row block reads k-chunk g of row li
     const int fo = li * 64 + ((g ^ swz5(li)) << 4);
@@ -112,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
     do {                                                                                                                \
         char* st_ = smem + ist * STG;                                                                                   \
         const unsigned so_ = (unsigned)ik * 64u;                                                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * 4096 + j_ * 1024), 16, pao, so_ + j_ * pstep_a, 0, 0); \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * 2048 + j_ * 1024), 16, pbo, so_ + j_ * pstep_b, 0, 0); \
+        _Pragma("unroll") for (int j_ = 0; j_ < PA; ++j_) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * (PA * 1024) + j_ * 1024), 16, pao, so_ + j_ * pstep_a, 0, 0); \
+        _Pragma("unroll") for (int j_ = 0; j_ < PB; ++j_) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * (PB * 1024) + j_ * 1024), 16, pbo, so_ + j_ * pstep_b, 0, 0); \
     } while (0)
 #define G5_ADVANCE()                                                                                                    \
     do {                                                                                                                \
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
 
     // prologue: stages 0, 1, 2 requested; stage 0 has landed when only the last two are in flight
     G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE();
-    wait_vmcnt<12>();
+    wait_vmcnt<2 * ND>();
     G5_SB();
     __builtin_amdgcn_s_barrier();
     G5_SB();
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
         a67[1][0] = *reinterpret_cast<const bf16x8*>(st + fa + 7 * 1024);
     };
     read_frags0(smem);
-    wait_vmcnt<6>();
+    wait_vmcnt<ND>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G5_SB();
     __builtin_amdgcn_s_barrier();
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
                     if (r < 4) G5_RD(b[r][NXT], rd + fb + r * 1024);
                     else if (r < 6) G5_RD(a67[r - 4][NXT], rd + fa + (r + 2) * 1024);
                 }
-                if (r < 4) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * 4096 + r * 1024), 16, pao, so_ + r * pstep_a, 0, 0);
-                else if (r < 6) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * 2048 + (r - 4) * 1024), 16, pbo, so_ + (r - 4) * pstep_b, 0, 0);
+                if (r < PA) MR_DMA(ra_c, MR_LDS_PTR(void, st_ + wave * (PA * 1024) + r * 1024), 16, pao, so_ + r * pstep_a, 0, 0);
+                else if (r < ND) MR_DMA(rb_c, MR_LDS_PTR(void, st_ + STG_A + wave * (PB * 1024) + (r - PA) * 1024), 16, pbo, so_ + (r - PA) * pstep_b, 0, 0);
                 G5_SB();
                 acc[r][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2][CUR], ar, acc[r][2], 0, 0, 0);
                 acc[r][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[3][CUR], ar, acc[r][3], 0, 0, 0);
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm5_kernel(const G256Args ga, const 
                 G5_SB();
             }
             if (FIRST && have_stores) wait_vmcnt<WAIT_FIRST>();
-            else wait_vmcnt<6>();
+            else wait_vmcnt<ND>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G5_SB();
             G5_BARRIER();
@@ -303,8 +312,10 @@ bool mr_gemm5_takes(const mr_gemm_args* a) {
 
 int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
-    const int64_t slots = 2 * ncu;                      // two workgroups per CU
-    const int64_t tm = (a->M + 255) / 256, tn = (a->N + g5::BN5 - 1) / g5::BN5, nwork = tm * tn;
+    const bool eight = mr_opts().gemm5 == 2;            // (experiment) one eight-wave workgroup per CU on 256 x 256 tiles
+    const int64_t slots = eight ? ncu : 2 * ncu;        // two workgroups per CU
+    const int64_t bn = eight ? 256 : g5::BN5;
+    const int64_t tm = (a->M + 255) / 256, tn = (a->N + bn - 1) / bn, nwork = tm * tn;
     const int64_t gsz = nwork < slots ? nwork : slots;
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
@@ -344,25 +355,29 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     if (st_env == -2) st_env = mr_env_int("MR_G5_STAGGER", -1);
     if (su_env == -2) su_env = mr_env_int("MR_G5_STAGGER_PCT", -1);
     int st_mode = g_mr_opt_gemm5_stagger >= 0 ? g_mr_opt_gemm5_stagger : st_env >= 0 ? st_env : 1;
-    if (gsz <= ncu) st_mode = 0;                          // one workgroup per CU: nobody to be out of phase with
+    if (gsz <= ncu || eight) st_mode = 0;                 // one workgroup per CU: nobody to be out of phase with
     // ~ one k-loop alone on the CU: K / 32 steps of 512 MFMA cycles, in units of 2048 cycles (percent knob for experiments)
     const int pct = su_env >= 0 ? su_env : 100;
     const int st_units = (int)((a->K / 32) * 600 * pct / 100 / 2048);
-    dim3 grid((unsigned)gsz), block(256);
+    dim3 grid((unsigned)gsz), block(eight ? 512 : 256);
     {
         static int dbg = -1;
         if (dbg < 0) dbg = mr_env_int("MR_G5_DEBUG", 0);
         if (dbg == 1) {
             dbg = 2;
             int nb = -1;
-            hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g5::gemm5_kernel<5>, 256, 0);
+            hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, g5::gemm5_kernel<5, 4>, 256, 0);
             hipFuncAttributes fa_;
-            hipError_t e2_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void*>(g5::gemm5_kernel<5>));
+            hipError_t e2_ = hipFuncGetAttributes(&fa_, reinterpret_cast<const void*>(g5::gemm5_kernel<5, 4>));
             fprintf(stderr, "[gemm5] occupancy query: %d blocks / CU (err %d); regs %d, static LDS %zu, scratch %zu (err %d); grid %ld, stagger mode %d units %d\n", nb, (int)e_,
                     fa_.numRegs, fa_.sharedSizeBytes, fa_.localSizeBytes, (int)e2_, (long)gsz, st_mode, st_units);
         }
     }
-#define G5_LAUNCH(MODE) hipLaunchKernelGGL((g5::gemm5_kernel<MODE>), grid, block, 0, s, ga, st_mode, st_units)
+#define G5_LAUNCH(MODE)                                                                                       \
+    do {                                                                                                      \
+        if (eight) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 8>), grid, block, 0, s, ga, st_mode, st_units); \
+        else hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4>), grid, block, 0, s, ga, st_mode, st_units);       \
+    } while (0)
     switch (mode) {
         case 0: G5_LAUNCH(0); break;
         case 1: G5_LAUNCH(1); break;
@@ -372,7 +387,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
         default: G5_LAUNCH(5); break;
     }
 #undef G5_LAUNCH
-    mr_note_route("g5::gemm5_kernel<%d>", mode);
+    mr_note_route("g5::gemm5_kernel<%d,%d>", mode, eight ? 8 : 4);
     MR_CHECK_LAUNCH("mr_gemm (gemm5)");
     return MR_OK;
 }
@@ -384,7 +399,7 @@ bool mr_gemm5_wanted(const mr_gemm_args* a) {
     const int v = g_mr_opt_gemm5 >= 0 ? g_mr_opt_gemm5 : env;
     if (v == 0 || a->colsum != nullptr && !a->aux) return false;
     if (!mr_gemm5_takes(a)) return false;
-    if (v == 1) return true;
+    if (v == 1 || v == 2) return true;
     // Default policy (measured, scripts/micro/gemm3_test g5time): the few-tile short-K problems -- at most one 256 x 128 tile per CU, K <= 1024:
     // the audio / span towers' 768-wide projections, the span and VCR-ViT QKV -- run 8-13 % faster here than on the one-barrier kernel's
     // 96-wide tiles (16.3 vs 18.0, 20.6 vs 23.4, 15.3 vs 17.4, 24.5 vs 26.9 us); everything with more tiles or a longer K is slower

@@ -145,7 +145,7 @@ static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[
     hipEvent_t e0[4], e1[4];
     for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
     auto launch = [&](int v, int set) {
-        mr_set_option("gemm5", v == 0 ? 0 : 1);
+        mr_set_option("gemm5", v == 0 ? 0 : (getenv("G5_EIGHT") ? 2 : 1));      // G5_EIGHT=1: the eight-wave 256 x 256 variant
         if (v) mr_set_option("gemm5_stagger", v - 1);
         { const char* e = getenv("G5_CUS"); mr_set_option("gemm_cus", (v && e) ? atoi(e) : 0); }      // G5_CUS=128: 256 workgroups = one per CU
         setup_args(&g, c, set, colsum);
@@ -284,8 +284,8 @@ int main(int argc, char** argv) {
             {3072, 2304, 768, 1, "span qkv"}, {4616, 4096, 1024, 4, "ragged M aux"}, {2000, 1000, 192, 0, "ragged M N"},
             {1024, 256, 128, 3, "small"}, {1312, 3072, 128, 0, "four steps"}, {40000, 192, 128, 5, "four steps, narrow"}, {300, 192, 256, 1, "tiny ragged rot"},
         };
-        mr_set_option("gemm5", 1);
-        for (int st = 0; st < 3; ++st) {
+        mr_set_option("gemm5", getenv("G5_EIGHT") ? 2 : 1);
+        for (int st = 0; st < (getenv("G5_EIGHT") ? 1 : 3); ++st) {
             mr_set_option("gemm5_stagger", st);
             char label[32]; snprintf(label, sizeof label, "g5/st%d", st);
             for (const Case& c : checks) fails += check_case(c, label);
