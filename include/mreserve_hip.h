@@ -319,6 +319,37 @@ int mr_f32_unit_norm_scale_fwd(const float* x, int64_t ldx, const float* log_sca
 int mr_f32_fill_rows(const float* vec, float* dst, int64_t ldd, int64_t ngroups, int64_t grp_stride, int64_t off,
                      int64_t H, void* stream);
 
+/* ---- fp32 BACKWARD (round 4): the reference's `use_bfloat16 = False` training arithmetic -- its GPU-debug mode, pretrain/train.py:61-67;
+ *      the `use_bfloat16_grads = False` branch of train_step, pretrain/pretrain_model.py:323-333.  Every operand fp32; fixed-order
+ *      reductions; written for exactness, not speed.  mr_f32_gemm (above) takes the training epilogues too: c2 = gelu'(v) beside
+ *      act = GELU (v itself without an activation), aux = elementwise multiplier of the stored output. */
+/* LayerNorm backward (M:272,277,360,366): statistics recomputed from x; dx may alias dy; dx_add (optional) is added to dx;
+ * dgamma / dbeta (both or neither) are full column reductions in row order; stat_ws: 2 * rows floats of scratch. */
+int mr_f32_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
+                         const float* dx_add, int64_t ldadd, float* dgamma, float* dbeta, float* stat_ws, int64_t rows, int64_t H,
+                         float eps, void* stream);
+int mr_f32_colsum(const float* x, int64_t ldx, int64_t rows, int64_t N, float* out, void* stream);
+/* backward of mr_f32_attention_fwd (M:188-200 with the -1e10 bias of M:353-356): dqkv [nseq*S, 3H] (q / k thirds scaled by rot_tab's
+ * first 32 dims per head when given, like mr_attention_bwd); delta [nseq, nh, S] scratch. */
+int mr_f32_attention_bwd(const float* qkv, const int32_t* code, const float* out, const float* dout, const float* lse, float* delta,
+                         float* dqkv, const float* rot_tab, int64_t rot_rows, int64_t nseq, int64_t S, int64_t nh, void* stream);
+/* backward of mr_f32_poolattn_fwd (probabilities recomputed); dk / dv are written at the groups' key rows only */
+int mr_f32_poolattn_bwd(const float* q, const float* k, const float* v, int64_t ldkv, const int32_t* key_rows, const float* dout,
+                        float* dq, float* dk, float* dv, int64_t G, int64_t R, int64_t nh, void* stream);
+/* dst[rows[g, r]] += dsrc[g] / R */
+int mr_f32_rows_mean_bwd(const float* dsrc, const int32_t* rows, float* dst, int64_t ldd, int64_t G, int64_t R, int64_t H, void* stream);
+/* backward of mr_f32_unit_norm_scale_fwd: dx (+= when accumulate), *dls += d(log_scale); dls_rows: `rows` floats of scratch */
+int mr_f32_unit_norm_scale_bwd(const float* x, int64_t ldx, const float* log_scale, const float* dy, int64_t lddy, float* dx, int64_t lddx,
+                               int32_t accumulate, float* dls, float* dls_rows, int64_t rows, int64_t H, void* stream);
+int mr_f32_sum_rows_strided(const float* x, int64_t ldx, int64_t ngroups, int64_t grp_stride, int64_t off, int64_t H, float* out, void* stream);
+/* y = a * x + b * y;  jnp.nan_to_num in place (P:328) */
+int mr_f32_axpby(float* y, const float* x, float a, float b, int64_t n, void* stream);
+int mr_f32_nan_to_num(float* y, int64_t n, void* stream);
+/* mr_adam_bf16_update_dev with fp32 gradients (no bf16 round trip, nan_to_num at fp32 range): the pretraining chain of O:180-190 */
+int mr_adam_f32grad_update_dev(float* master, void* work_bf16, const float* grad_f32, void* mu_bf16, void* nu_bf16,
+                               const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2, float eps, float weight_decay,
+                               const float* hyper_dev, void* stream);
+
 /* ---- data-parallel collectives over RCCL / xGMI (one process per GPU) ------------------------------------------------
  * Replace the XLA collectives of the pmap'ed step: jax.lax.all_gather of the packed contrastive embeddings (P:290) and its
  * transpose in backward (a reduce-scatter), jax.lax.pmean of the bf16 gradient pytree (P:329) and of the fp32 metrics

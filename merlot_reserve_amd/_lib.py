@@ -88,6 +88,16 @@ PROTOTYPES = {
     'mr_f32_rows_mean_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_f32_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_f32_fill_rows': (i32, [vp, vp, i64, i64, i64, i64, i64, vp]),
+    'mr_f32_layernorm_bwd': (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, f32, vp]),
+    'mr_f32_colsum': (i32, [vp, i64, i64, i64, vp, vp]),
+    'mr_f32_attention_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    'mr_f32_poolattn_bwd': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    'mr_f32_rows_mean_bwd': (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    'mr_f32_unit_norm_scale_bwd': (i32, [vp, i64, vp, vp, i64, vp, i64, i32, vp, vp, i64, i64, vp]),
+    'mr_f32_sum_rows_strided': (i32, [vp, i64, i64, i64, i64, i64, vp, vp]),
+    'mr_f32_axpby': (i32, [vp, vp, f32, f32, i64, vp]),
+    'mr_f32_nan_to_num': (i32, [vp, i64, vp]),
+    'mr_adam_f32grad_update_dev': (i32, [vp, vp, vp, vp, vp, vp, i64, f64, f64, f32, f32, vp, vp]),
     'mr_comm_unique_id': (i32, [vp]),
     'mr_comm_init': (i32, [i32, i32, vp, C.POINTER(vp)]),
     'mr_comm_destroy': (i32, [vp]),

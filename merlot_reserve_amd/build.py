@@ -17,8 +17,8 @@ LIB = os.path.join(HERE, 'libmreserve_hip.so')
 # results in every mode.  These kernels are HBM-bound: no cost.  adam.hip also -ffp-contract=off: the optimizer state is byte data
 # (pretrain/optimization.py:36-51), the oracle evaluates (1 - b) * g + b * m without fused multiply-adds.
 EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'layernorm.hip': ['-fno-slp-vectorize'], 'rowops.hip': ['-fno-slp-vectorize'],
-               'adam.hip': ['-fno-slp-vectorize', '-ffp-contract=off']}
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'mr_error.cpp', 'comm.cpp']
+               'adam.hip': ['-fno-slp-vectorize', '-ffp-contract=off'], 'f32bwd.hip': ['-fno-slp-vectorize']}
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'f32bwd.hip', 'mr_error.cpp', 'comm.cpp']
 
 
 def _needs_build():

@@ -22,9 +22,11 @@ __device__ __forceinline__ float nan_to_num_f(float g) {
 // u += wd * parameter, both under the same mask.
 // DEV: the four per-step scalars (schedule value, -lr, 1/bias_corr1, 1/bias_corr2) are read from device memory, so the
 // launch can live inside a captured hipGraph (or be issued before the host has computed them for a later step).
-template <bool FT, bool DEV = false>
+// GF: the gradients are fp32 (the reference's use_bfloat16_grads = False branch, pretrain_model.py:323-333: no bf16 round trip of
+// the gradients; nan_to_num at fp32 range) -- same chain otherwise.
+template <bool FT, bool DEV = false, bool GF = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, __bf16* __restrict__ work,
-                                                   const __bf16* __restrict__ grad, __bf16* __restrict__ mu,
+                                                   const void* __restrict__ grad_, __bf16* __restrict__ mu,
                                                    __bf16* __restrict__ nu, const __bf16* __restrict__ orig,
                                                    const uint8_t* __restrict__ decay_flag, float c1,
                                                    float b1, float c2, float b2, float eps, float wd, float sched, float neg_lr,
@@ -37,7 +39,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, _
     // copy: 5.5 -> 5.9-6.1 TB/s for the kernel alone; the bf16 working copy, which the next forward reads, is stored normally
 #define MR_LD(T, p) __builtin_nontemporal_load(reinterpret_cast<const T*>(p))
 #define MR_ST(T, p, v) __builtin_nontemporal_store((v), reinterpret_cast<T*>(p))
-    unpack8(MR_LD(u32x4, grad + i), g);
+    if (GF) {
+        const float* gp = static_cast<const float*>(grad_) + i;
+        const f32x4 g0 = MR_LD(f32x4, gp), g1 = MR_LD(f32x4, gp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] = g0[e]; g[4 + e] = g1[e]; }
+    } else {
+        unpack8(MR_LD(u32x4, static_cast<const __bf16*>(grad_) + i), g);
+    }
     unpack8(MR_LD(u32x4, mu + i), m);
     unpack8(MR_LD(u32x4, nu + i), v);
     const f32x4 p0 = MR_LD(f32x4, master + i), p1 = MR_LD(f32x4, master + i + 4);
@@ -47,7 +56,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, _
     if (FT) unpack8(*reinterpret_cast<const u32x4*>(orig + i), og);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float ge = nan_to_num_f(g[e]);
+        const float ge = GF ? ((g[e] != g[e]) ? 0.f : fminf(fmaxf(g[e], -3.4028234663852886e38f), 3.4028234663852886e38f)) : nan_to_num_f(g[e]);
         const float nm = c1 * ge + b1 * m[e];                                   // optimization.py:83-87
         float va = fabsf(v[e]);
         if (!(v[e] >= 0.f)) va *= MISSING_PRECISION;                             // :38-41 (v >= 0 also true for -0.0)
@@ -173,6 +182,20 @@ extern "C" int mr_adam_bf16_update_dev(float* master, void* work_bf16, const voi
                            static_cast<const __bf16*>(nullptr), decay_flag_per_block, c1, (float)b1, c2, (float)b2, eps, weight_decay, 0.f, 0.f,
                            1.f, 1.f, hyper_dev);
     MR_CHECK_LAUNCH("mr_adam_bf16_update_dev");
+    return MR_OK;
+}
+
+// fp32 gradients (use_bfloat16_grads = False), per-step scalars in device memory; pretraining chain only.
+extern "C" int mr_adam_f32grad_update_dev(float* master, void* work_bf16, const float* grad_f32, void* mu_bf16, void* nu_bf16,
+                                          const uint8_t* decay_flag_per_block, int64_t n, double b1, double b2, float eps, float weight_decay,
+                                          const float* hyper_dev, void* stream) {
+    MR_CHECK_ARG(master && work_bf16 && grad_f32 && mu_bf16 && nu_bf16 && decay_flag_per_block && hyper_dev, "mr_adam_f32grad_update_dev: null pointer");
+    MR_CHECK_ARG(n > 0 && n % 2048 == 0, "mr_adam_f32grad_update_dev: n must be a positive multiple of 2048 (got %ld)", (long)n);
+    const float c1 = (float)(1.0 - b1), c2 = (float)(1.0 - b2);
+    hipLaunchKernelGGL((adam_kernel<false, true, true>), dim3((unsigned)(n / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                       static_cast<__bf16*>(work_bf16), static_cast<const void*>(grad_f32), static_cast<__bf16*>(mu_bf16), static_cast<__bf16*>(nu_bf16),
+                       (const __bf16*)nullptr, decay_flag_per_block, c1, (float)b1, c2, (float)b2, eps, weight_decay, 0.f, 0.f, 1.f, 1.f, hyper_dev);
+    MR_CHECK_LAUNCH("mr_adam_f32grad_update_dev");
     return MR_OK;
 }
 

@@ -169,10 +169,18 @@ __global__ __launch_bounds__(256) void f32_gemm_kernel(const mr_gemm_args p, int
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bv;
                 if (rot) v *= p.rot_tab[(m % p.rot_rows) * 32 + (n & 63)];
-                if (p.act == MR_ACT_GELU1702) v = v / (1.0f + expf(-1.702f * v));
                 int64_t orow = m;
                 if (p.out_grp > 0) orow = (m / p.out_grp) * p.out_grp_stride + p.out_grp_off + m % p.out_grp;
+                if (p.act == MR_ACT_GELU1702) {
+                    const float sg = 1.0f / (1.0f + expf(-1.702f * v));
+                    // training: c2 = gelu'(v), the factor the backward multiplies d(activation) with (the bf16 path stores the same)
+                    if (p.c2 != nullptr) static_cast<float*>(p.c2)[orow * p.ldc + n] = sg + 1.702f * v * sg * (1.0f - sg);
+                    v = v * sg;
+                } else if (p.c2 != nullptr) {
+                    static_cast<float*>(p.c2)[orow * p.ldc + n] = v;
+                }
                 if (R != nullptr) v += R[orow * p.ldr + n];
+                if (p.aux != nullptr) v *= static_cast<const float*>(p.aux)[orow * p.ldaux + n];
                 C[orow * p.ldc + n] = v;
             }
     }
@@ -442,7 +450,6 @@ extern "C" int mr_f32_gemm(const mr_gemm_args* a, void* stream) {
     MR_CHECK_ARG(a && a->A && a->B && a->C, "mr_f32_gemm: null pointer");
     MR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "mr_f32_gemm: empty problem %lld x %lld x %lld", (long long)a->M, (long long)a->N, (long long)a->K);
     MR_CHECK_ARG(a->c_dtype == MR_DT_F32, "mr_f32_gemm: c_dtype must be MR_DT_F32");
-    MR_CHECK_ARG(a->c2 == nullptr && a->aux == nullptr, "mr_f32_gemm: c2 / aux epilogues are training-only (bf16 path)");
     MR_CHECK_ARG(a->rot_tab == nullptr || a->rot_rows > 0, "mr_f32_gemm: rot_rows must be positive with a rot_tab");
     const int vecA = aligned16(a->A) && a->lda % 4 == 0, vecB = aligned16(a->B) && a->ldb % 4 == 0;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -24,7 +24,7 @@ BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 class TowerState:
     """Saved activations of one TransformerEncoder (modeling.py:283-376) over M = nseq*S rows."""
 
-    def __init__(self, M, H, L, nseq, S, dev, dtype=BF16):
+    def __init__(self, M, H, L, nseq, S, dev, dtype=BF16, keep_hpre=None):
         nh = H // 64
         z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
@@ -34,7 +34,8 @@ class TowerState:
         self.ln1, self.ln2, self.xmid, self.att = z(L, M, H), z(L, M, H), z(L, M, H), z(L, M, H)
         self.qkv = z(L, M, 3 * H)
         self.hact = z(L, M, 4 * H)
-        self.hpre = z(L, M, 4 * H) if dtype == BF16 else None      # gelu'(pre-activation), only kept for backward
+        keep_hpre = dtype == BF16 if keep_hpre is None else keep_hpre
+        self.hpre = z(L, M, 4 * H) if keep_hpre else None           # gelu'(pre-activation), only kept for backward
         self.lse = f(L, nseq, nh, S)
         self.stats = f(2 * L + 2, 2, M)       # [ln index][mean|rstd][row]; index 0 = pre_ln, 1+2l / 2+2l = layer l, last = final
 
@@ -48,8 +49,12 @@ class TowerEngine:
 
     def _make_scratch(self, Ms, Gs, Ps, H, nh):
         dev = self.dev
-        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=self.dtype, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        f32 = self.dtype == F32
+        # fp32 program (use_bfloat16_grads = False): the reductions are immediate, a LayerNorm backward wants 2 floats per row
+        ln_ws_shared = f(2 * Ms) if f32 else None
+        ln_ws = (lambda: ln_ws_shared) if f32 else (lambda: ops.layernorm_bwd_workspace(H, dev))
 
         class Scratch:
             pass
@@ -64,13 +69,13 @@ class TowerEngine:
         sc.WG = WG
         sc.delta = f(Ms * nh)
         sc.gemm_ws = f(32 * 1024 * 1024)                       # 128 MiB of fp32 split-K partials
-        sc.ln_ws = ops.layernorm_bwd_workspace(H, dev)
+        sc.ln_ws = ln_ws()
         sc.cs_ws = ops.colsum_workspace(4 * H, dev)
         # A layer's four deferred reductions (2 LayerNorm, 2 bias) keep their partial rows until ONE mr_reduce_partials launch per
         # weight-gradient GROUP of layers (engine._wgrad_group: 2 base, 4 large) -- the gradients are not needed before the group's
         # layer_done: one set of partial-row workspaces per position in the group
-        sc.ln_wsA = [ops.layernorm_bwd_workspace(H, dev) for _ in range(WG)]
-        sc.ln_wsB = [ops.layernorm_bwd_workspace(H, dev) for _ in range(WG)]
+        sc.ln_wsA = [ln_ws() for _ in range(WG)]
+        sc.ln_wsB = [ln_ws() for _ in range(WG)]
         sc.cs_wsA = [ops.colsum_workspace(4 * H, dev) for _ in range(WG)]
         sc.cs_wsB = [ops.colsum_workspace(4 * H, dev) for _ in range(WG)]
         # per-(tile, wave) column-sum partials written by the d(pre-activation) GEMM's epilogue (the fc1 bias gradient)
@@ -80,7 +85,7 @@ class TowerEngine:
         sc.cs_attn = [f(((Ms + 15) // 16 + 64) * 3 * H) for _ in range(WG)]
         # tower-level reductions (pre / final LayerNorm, pooling and projection biases) keep their partial rows in these until
         # the tower's ONE mr_reduce_partials launch (they used to be two latency-bound launches each)
-        sc.tower_ln_ws = [ops.layernorm_bwd_workspace(H, dev) for _ in range(2)]
+        sc.tower_ln_ws = [ln_ws() for _ in range(2)]
         sc.tower_cs_ws = [ops.colsum_workspace(H, dev) for _ in range(6)]
         sc.d_pool_q, sc.d_pool_po, sc.d_pool_qin = z(Gs, H), z(Gs, H), z(Gs, H)
         sc.d_k, sc.d_v = z(Ms, H), z(Ms, H)                    # CLS rows stay zero
@@ -122,7 +127,7 @@ class TowerEngine:
     # tower-level deferred reductions: between _begin_tower_reductions() and _flush_tower_reductions() every LayerNorm /
     # colsum issued through _t_ln_bwd / _t_colsum leaves its partial rows in a workspace of its own
     def _begin_tower_reductions(self):
-        off = os.environ.get('MR_NO_BATCH_REDUCE') == '1' or os.environ.get('MR_NO_TOWER_DEFER') == '1'      # (A/B switches)
+        off = os.environ.get('MR_NO_BATCH_REDUCE') == '1' or os.environ.get('MR_NO_TOWER_DEFER') == '1' or self.dtype == F32   # (A/B switches; fp32: immediate)
         return {'jobs': None if off else [], 'ln': 0, 'cs': 0, 'sc': self.cur}
 
     def _t_ln_bwd(self, tr, *a, **k):
@@ -264,7 +269,7 @@ class TowerEngine:
         extra_wgrads: [(x, dy, out)] weight gradients of the tower's head over the SAME tokens (attention-pool key / value
         projections, the joint head): they join the FIRST group's launch when its tiles still fit the same number of CU rounds
         (base: 216 + 9 per extra of 256) -- alone each is a 9-tile split-K launch of ~65 us --, else they are launched here."""
-        W, G, H, nh, M = self.p.w, self.p.g, st.H, st.H // 64, st.M
+        W, G, H, nh, M = self.W, self.G, st.H, st.H // 64, st.M
         T_a = self.cur.T_a[:M]
         # [M, H] gradient buffers: a layer reads Dcur, writes Dmid and Dnext; Dcur / Dmid (and the layer's T_q / T_h) stay untouched
         # until the group's weight gradients have been issued
@@ -289,7 +294,7 @@ class TowerEngine:
         # everything above the layers (heads, pooling, final LayerNorm) is reduced here: a data-parallel trainer hands the
         # tower's LAST layers' gradient bucket -- which holds these leaves -- to the all-reduce at the first layer_done
         self._flush_tower_reductions(tr)
-        jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' else []      # (A/B switch) immediate reductions
+        jobs = None if os.environ.get('MR_NO_BATCH_REDUCE') == '1' or self.dtype == F32 else []      # (A/B switch) immediate reductions
         for l in reversed(range(st.L)):
             n = self._names(prefix, l)
             T_q, T_h = T_qs[len(done_layers)], T_hs[len(done_layers)]
@@ -352,7 +357,7 @@ class TowerEngine:
     def _tower_with_pool_backward(self, st, prefix_t, prefix_pool, rot, pool_rows, qin, q, k, v, po, probs, d_seq, d_cls, D,
                                   layer_done=None, tr=None):
         """d_seq: grad wrt the pooled sequence output; d_cls: grad wrt the cls output.  Returns D = grad wrt st.xin."""
-        W, G, nh, M = self.p.w, self.p.g, st.H // 64, st.M
+        W, G, nh, M = self.W, self.G, st.H // 64, st.M
         Gn = qin.shape[0]
         d_po, d_q, d_qin = self.cur.d_pool_po[:Gn], self.cur.d_pool_q[:Gn], self.cur.d_pool_qin[:Gn]
         d_k, d_v = self.cur.d_k[:M], self.cur.d_v[:M]
@@ -395,25 +400,31 @@ class TowerEngine:
 
 
 class PretrainEngine(TowerEngine):
-    def __init__(self, config, B, params, device, rank=0, world=1, dtype=BF16):
-        """dtype = torch.float32 builds the FORWARD-ONLY fp32 program (forward + loss on the fp32 master weights through
-        the mr_f32_* kernels: the reference's use_bfloat16 = False arithmetic, used for the 1e-3 forward-parity check);
-        the default bf16 program is the training path."""
+    def __init__(self, config, B, params, device, rank=0, world=1, dtype=BF16, train=None):
+        """dtype = torch.float32 builds the fp32 program on the fp32 master weights through the mr_f32_* kernels (the reference's
+        use_bfloat16 = False arithmetic): forward + loss only by default (the 1e-3 forward-parity check); with train=True also the
+        backward, gradients in fp32 (params.grad32) -- the reference's use_bfloat16_grads = False step (pretrain_model.py:323-333), a
+        plain correctness path (no fused reductions, no grouped launches).  The default bf16 program is the fast training path."""
         self.config, self.p, self.dev = config, params, torch.device(device)
         self.d = d = Dims(config, B)
         self.rank, self.world = rank, world
         self.dtype = dtype
-        self.fwd_only = dtype != BF16
+        train = dtype == BF16 if train is None else train
+        self.fwd_only = not train
         self.W = params.w if dtype == BF16 else params.wm
+        if train and dtype == F32:
+            params.enable_f32_grads()
+        self.G = params.g if dtype == BF16 else getattr(params, 'g32', None)
+        hp = train
         dev, H = self.dev, d.H
         self.tables = {k: torch.as_tensor(v).to(dev) for k, v in static_tables(d).items()}
         z = lambda *s: torch.zeros(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
 
-        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype)
-        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype)
-        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype)
-        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype)
+        self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype, hp)
+        self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype, hp)
+        self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype, hp)
+        self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype, hp)
         Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
 
         # attention pools
@@ -448,7 +459,7 @@ class PretrainEngine(TowerEngine):
         self.loss_acc = f(3)
         self.diag = f(2, 6)
         self.dls = f(3)
-        self.dls_part = f((self.R + 3) // 4 + 8)
+        self.dls_part = f(((self.R + 3) // 4 if dtype == BF16 else self.R) + 8)
         # objectives: (name, x section, y sections (gathered across ranks), scale index)
         self.objectives = [('imgs_to_audio', 'i2a_x', ('i2a_y',), 0), ('text_to_audio', 't2a_x', ('t2a_y', 't2a_ye'), 1),
                            ('stuff_to_span', 's2s_x', ('s2s_y',), 2)]
@@ -466,7 +477,7 @@ class PretrainEngine(TowerEngine):
                 V = world * nk
                 ldv = (V + 7) // 8 * 8
                 self.cprob.append(dict(oi=oi, di=di, name=name, q_off=q_off, Lq=Lq, k_off=k_off, nk=nk, V=V, ldv=ldv, kb=kb,
-                                       logits=f(Lq, ldv), dl=None if self.fwd_only else z(Lq, 2 * ldv)))
+                                       logits=f(Lq, ldv), dl=None if self.fwd_only or dtype == F32 else z(Lq, 2 * ldv)))
                 kb += 2 * ldv
         self.Kcat = z(kb, H)
         self.lse_rows = f(max(p['Lq'] for p in self.cprob))
@@ -486,6 +497,7 @@ class PretrainEngine(TowerEngine):
         assert sorted(src_of) == list(range(world * self.R)), 'every gathered row is a key of exactly one problem'
         if not self.fwd_only:
             self.DK = z(kb, H)
+            self.dE_keys = z(self.R, H) if dtype == F32 and world == 1 else None
             self.kunpack = (torch.arange(0, 2 * world * self.R + 1, 2, dtype=I32, device=dev),
                             torch.tensor([v for e in range(world * self.R) for v in src_of[e]], dtype=I32, device=dev))
 
@@ -528,6 +540,8 @@ class PretrainEngine(TowerEngine):
     def forward_device(self, images, audio_clips):
         """Device part of forward(): the plan is already in its device buffers."""
         d, W, H = self.d, self.W, self.d.H
+        if images.dtype != self.dtype:          # the wire format is bf16 (pretrain/dataloader.py:786-788); the fp32 program casts up, like the
+            images, audio_clips = images.to(self.dtype), audio_clips.to(self.dtype)     # reference model's first op (M: x.astype(self.dtype))
         batch = {'images': images, 'audio_clips': audio_clips}
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
 
@@ -540,6 +554,7 @@ class PretrainEngine(TowerEngine):
                 a_view = self.a_in[:, :d.a_patch * 65]
             else:
                 a_view = audio
+            self._audio2d = a_view
             self.fgemm(a_view, 'audio_encoder/embedding/kernel', ta.xin, bias=W['audio_encoder/embedding/bias'], row_map=(d.a_len, d.Sa, 1))
             self._tower_with_pool_forward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
                                           self.tables['audio_pool_rows'], self.a_qin, self.a_q, self.a_k, self.a_v, self.a_po,
@@ -614,7 +629,7 @@ class PretrainEngine(TowerEngine):
         self.diag.zero_()
         # The six (objective, direction) problems are independent: each of the three products runs as ONE grouped launch over all of
         # them (bf16 program; alone, every one of these 18 GEMMs is a 17-23 us latency chain of k-tiles on one or two workgroups).
-        grouped = not self.fwd_only and os.environ.get('MR_NO_LOSS_GROUPING') != '1'
+        grouped = not self.fwd_only and self.dtype == BF16 and os.environ.get('MR_NO_LOSS_GROUPING') != '1'
         qs = [self.E[p['q_off']:p['q_off'] + p['Lq']] for p in self.cprob]
         if grouped:
             ops.gemm_grouped([self.gemm_args(q, self.Kcat[p['kb']:p['kb'] + p['V']], p['logits'], transB=True) for p, q in zip(self.cprob, qs)])
@@ -628,6 +643,11 @@ class PretrainEngine(TowerEngine):
                                 self.loss_acc[p['oi']:p['oi'] + 1], self.diag[p['di']] if is_s2s else None, self.lse_rows)
             if self.fwd_only:
                 continue
+            if self.dtype == F32:        # fp32 program: dL/dlogits (left in `logits` by the LSE kernel) feeds both products as it is; the
+                dlf = logits[:, :V]      # "lo" rows of DK stay zero
+                self.gemm(dlf, self.Kcat[kb:kb + V], self.dE[p['q_off']:p['q_off'] + p['Lq']])
+                self.gemm(dlf, q, self.DK[kb:kb + V], transA=True)
+                continue
             dl = p['dl']                                                           # [Lq, hi(ldv) | lo(ldv)]; pad columns stay 0
             ops.split_hilo_rows(logits[:, :V], dl[:, :V], dl[:, ldv:ldv + V])
             if not grouped:
@@ -639,7 +659,10 @@ class PretrainEngine(TowerEngine):
             ops.gemm_grouped([self.gemm_args(p['dl'], q, self.DK[p['kb']:p['kb'] + 2 * p['ldv']], transA=True)
                               for p, q in zip(self.cprob, qs)])                    # d(key side)   = dlogits^T . queries (hi rows, lo rows)
         if not self.fwd_only:
-            if world == 1:
+            if world == 1 and self.dtype == F32:
+                ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], self.dE_keys)
+                ops.add_(self.dE, self.dE_keys)
+            elif world == 1:
                 ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], self.dE, accumulate=True)
             else:
                 ops.segment_sum([self.DK], self.kunpack[0], self.kunpack[1], dE_all.view(world * self.R, H))
@@ -647,7 +670,7 @@ class PretrainEngine(TowerEngine):
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self):
-        assert not self.fwd_only, 'the fp32 program is forward-only'
+        assert not self.fwd_only, 'this program was built forward-only (PretrainEngine(..., train=True) for the fp32 backward)'
         self._backward()
 
     def _backward(self):
@@ -662,7 +685,7 @@ class PretrainEngine(TowerEngine):
         main.wait_stream(self.side_stream)
 
     def backward_stage_joint(self):
-        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        d, W, G, H = self.d, self.W, self.G, self.d.H
         tv, ta, tj, ts = self.tv, self.ta, self.tj, self.ts
         self.dls.zero_()
         n1, n2 = self.sec['i2a_x'][1], self.sec['t2a_x'][1]
@@ -671,7 +694,10 @@ class PretrainEngine(TowerEngine):
             o, n = self.sec[names[0]][0], sum(self.sec[k][1] for k in names)
             ops.unit_norm_scale_bwd(src, W['contrastive_scales'][si:si + 1], self.inv_norm[o:o + n], self.dE[o:o + n], dst,
                                     self.dls[si:si + 1], self.dls_part, accumulate=True)
-        ops.cast_f32_to_bf16(self.dls, G['contrastive_scales'])
+        if self.dtype == F32:
+            G['contrastive_scales'].copy_(self.dls)
+        else:
+            ops.cast_f32_to_bf16(self.dls, G['contrastive_scales'])
 
         def span_bwd():
             # span tower (only its cls output is used: gradient enters at the CLS rows)
@@ -712,7 +738,7 @@ class PretrainEngine(TowerEngine):
         ops.segment_sum([self.d_acls_g], self._pl('aclsT_indptr'), self._pl('aclsT_idx'), self.d_a_cls)
 
     def backward_stage_audio(self):
-        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        d, W, G, H = self.d, self.W, self.G, self.d.H
         ta = self.ta
         tr = self._begin_tower_reductions()
         Da = self._tower_with_pool_backward(ta, 'audio_encoder/transformer', 'audio_encoder/seq_attnpool', self.tables['audio_rot'],
@@ -722,9 +748,9 @@ class PretrainEngine(TowerEngine):
         ops.segment_sum([Da], self.unpad_a[0], self.unpad_a[1], Dp)
         self._t_colsum(tr, Dp, G['audio_encoder/embedding/bias'])
         self._flush_tower_reductions(tr)
-        self.gemm(self.a_in[:, :d.a_patch * 65], Dp, G['audio_encoder/embedding/kernel'], transA=True)
+        self.gemm(self._audio2d, Dp, G['audio_encoder/embedding/kernel'], transA=True)
     def backward_stage_vision(self, layer_done=None):
-        d, W, G, H = self.d, self.p.w, self.p.g, self.d.H
+        d, W, G, H = self.d, self.W, self.G, self.d.H
         tv = self.tv
         tr = self._begin_tower_reductions()
         Dv = self._tower_with_pool_backward(tv, 'vision_encoder/transformer', 'vision_encoder/seq_attnpool', self.tables['vit_rot'],

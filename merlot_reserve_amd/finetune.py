@@ -87,7 +87,7 @@ class VCREngine(TowerEngine):
     def __init__(self, config, B, params, device):
         self.config, self.p, self.dev = config, params, torch.device(device)
         self.d = d = VCRDims(config, B)
-        self.dtype, self.fwd_only, self.W = BF16, False, params.w
+        self.dtype, self.fwd_only, self.W, self.G = BF16, False, params.w, params.g
         dev, H = self.dev, d.H
         z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
         f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)

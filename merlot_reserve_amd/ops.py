@@ -137,10 +137,11 @@ def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, ro
     Kb, N = (b.shape[1], b.shape[0]) if transB else (b.shape[0], b.shape[1])
     assert K == Kb, f'gemm: K mismatch {K} vs {Kb}'
     assert a.dtype == b.dtype and a.dtype in (BF16, F32)
-    if a.dtype == F32:       # fp32 forward path (mr_f32_gemm): every operand fp32, forward-only epilogues
-        assert out.dtype == F32 and c2 is None and aux is None
-        assert all(t is None or t.dtype == F32 for t in (bias, residual))
+    if a.dtype == F32:       # fp32 path (mr_f32_gemm): every operand fp32
+        assert out.dtype == F32 and colsum is None
+        assert all(t is None or t.dtype == F32 for t in (bias, residual, aux, c2))
     g = GemmArgs()
+    g._f32_operands = a.dtype == F32
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.transA = a.data_ptr(), _ld(a), int(transA)
     g.B, g.ldb, g.transB = b.data_ptr(), _ld(b), int(transB)
@@ -203,6 +204,11 @@ def gemm(a, b, out, **kw):
 def gemm_grouped(arg_list):
     """Several independent GEMMs (built with gemm_args) in one persistent launch when they qualify."""
     lib = _lib.load()
+    if arg_list and arg_list[0].c_dtype == MR_DT_F32 and getattr(arg_list[0], '_f32_operands', False):     # fp32 program: no grouped kernel
+        for g in arg_list:
+            g.workspace, g.workspace_bytes = None, 0
+            check(lib.mr_f32_gemm(C.byref(g), _stream()), 'mr_f32_gemm')
+        return
     arr = (GemmArgs * len(arg_list))(*arg_list)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -219,6 +225,9 @@ def gemm_colsum_job(a, b, out, colsum_ws, bias_grad, jobs, **kw):
     for this problem (per-tile partial rows in colsum_ws, reduced later with the other deferred jobs); otherwise the GEMM
     and a separate column-sum pass over `out`.  Returns True when fused."""
     lib = _lib.load()
+    if a.dtype == F32:
+        gemm(a, b, out, **kw)
+        return False
     M = a.shape[1] if kw.get('transA') else a.shape[0]
     N = out.shape[1]
     rows = lib.mr_gemm_colsum_rows(M)
@@ -256,6 +265,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, partials, add_to_
     if add_to_dx:
         dx_add = dx
     lib = _lib.load()
+    if x.dtype == F32:       # fp32 program: statistics recomputed, the parameter gradients reduced at once (`partials`: >= 2 * rows floats)
+        assert partials.numel() >= 2 * rows
+        check(lib.mr_f32_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), dx.data_ptr(), _ld(dx), _ptr(dx_add),
+                                       0 if dx_add is None else _ld(dx_add), dgamma.data_ptr(), dbeta.data_ptr(), partials.data_ptr(), rows, H,
+                                       1e-5, _stream()), 'mr_f32_layernorm_bwd')
+        return dx
     defer = jobs is not None
     check(lib.mr_layernorm_bwd(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(), mean.data_ptr(),
                                rstd.data_ptr(), dx.data_ptr(), _ld(dx), _ptr(dx_add), 0 if dx_add is None else _ld(dx_add),
@@ -275,6 +290,9 @@ def colsum(x, out, partials, jobs=None):
     """out[n] = sum_m x[m, n]; with `jobs` the final reduction is deferred to reduce_partials() (see layernorm_bwd)."""
     rows, N = x.shape
     lib = _lib.load()
+    if x.dtype == F32:
+        check(lib.mr_f32_colsum(x.data_ptr(), _ld(x), rows, N, out.data_ptr(), _stream()), 'mr_f32_colsum')
+        return out
     check(lib.mr_colsum(x.data_ptr(), _ld(x), rows, N, None if jobs is not None else out.data_ptr(), partials.data_ptr(), _stream()),
           'mr_colsum')
     if jobs is not None:
@@ -311,6 +329,12 @@ def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh, 
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     rr = 0 if rot_tab is None else rot_tab.numel() // 32
     lib = _lib.load()
+    if qkv.dtype == F32:
+        check(lib.mr_f32_attention_bwd(qkv.data_ptr(), _ptr(code), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                       dqkv.data_ptr(), _ptr(rot_tab), rr, nseq, S, nh, _stream()), 'mr_f32_attention_bwd')
+        if bias_grad is not None and jobs is not None:
+            check(lib.mr_f32_colsum(dqkv.data_ptr(), _ld(dqkv), dqkv.shape[0], dqkv.shape[1], bias_grad.data_ptr(), _stream()), 'mr_f32_colsum')
+        return dqkv
     cs = None
     if jobs is not None and colsum_ws is not None:
         rows, n3 = lib.mr_attention_bwd_colsum_rows(nseq, S), dqkv.shape[1]
@@ -341,6 +365,10 @@ def poolattn_fwd(q, k, v, key_rows, out, probs, nh):
 def poolattn_bwd(q, k, v, key_rows, probs, dout, dq, dk, dv, nh):
     G, R = key_rows.shape
     assert _ld(k) == _ld(v) == _ld(dk) == _ld(dv)
+    if q.dtype == F32:
+        check(_lib.load().mr_f32_poolattn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), dout.data_ptr(),
+                                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), G, R, nh, _stream()), 'mr_f32_poolattn_bwd')
+        return
     check(_lib.load().mr_poolattn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(k), key_rows.data_ptr(), probs.data_ptr(),
                                       dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), G, R, nh, _stream()),
           'mr_poolattn_bwd')
@@ -382,6 +410,10 @@ def rows_mean_fwd(src, rows, dst):
 @_timed('rowops')
 def rows_mean_bwd(ddst, rows, dsrc):
     G, R = rows.shape
+    if ddst.dtype == F32:
+        check(_lib.load().mr_f32_rows_mean_bwd(ddst.data_ptr(), rows.data_ptr(), dsrc.data_ptr(), _ld(dsrc), G, R, ddst.shape[1], _stream()),
+              'mr_f32_rows_mean_bwd')
+        return
     check(_lib.load().mr_rows_mean_bwd(ddst.data_ptr(), rows.data_ptr(), dsrc.data_ptr(), _ld(dsrc), G, R, ddst.shape[1],
                                        _stream()), 'mr_rows_mean_bwd')
 
@@ -406,6 +438,10 @@ def fill_rows(vec, dst, ngroups, grp_stride, off):
 
 @_timed('rowops')
 def sum_rows_strided(src, ngroups, grp_stride, off, out):
+    if src.dtype == F32:
+        check(_lib.load().mr_f32_sum_rows_strided(src.data_ptr(), _ld(src), ngroups, grp_stride, off, src.shape[1], out.data_ptr(), _stream()),
+              'mr_f32_sum_rows_strided')
+        return out
     check(_lib.load().mr_sum_rows_strided(src.data_ptr(), _ld(src), ngroups, grp_stride, off, src.shape[1], out.data_ptr(),
                                           _stream()), 'mr_sum_rows_strided')
     return out
@@ -414,6 +450,10 @@ def sum_rows_strided(src, ngroups, grp_stride, off, out):
 @_timed('rowops')
 def add_(a, b, y=None):
     y = a if y is None else y
+    if a.dtype == F32:
+        assert y is a
+        check(_lib.load().mr_f32_axpby(a.data_ptr(), b.data_ptr(), 1.0, 1.0, a.numel(), _stream()), 'mr_f32_axpby')
+        return y
     check(_lib.load().mr_add_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), 'mr_add_bf16')
     return y
 
@@ -435,6 +475,14 @@ def unit_norm_scale_fwd(x, log_scale, y, inv_norm=None):
 def unit_norm_scale_bwd(x, log_scale, inv_norm, dy, dx, dlog_scale, partials, accumulate=False):
     """dlog_scale[0] = (accumulate ? old : 0) + this call's temperature gradient; partials: >= (rows + 3) // 4 fp32 scratch."""
     rows, H = x.shape
+    if x.dtype == F32:
+        assert partials.dtype == F32 and partials.numel() >= rows
+        if not accumulate:
+            dlog_scale.zero_()
+        check(_lib.load().mr_f32_unit_norm_scale_bwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), dy.data_ptr(), _ld(dy), dx.data_ptr(), _ld(dx),
+                                                     0, dlog_scale.data_ptr(), partials.data_ptr(), rows, H, _stream()),   # (dx overwritten; dls += )
+              'mr_f32_unit_norm_scale_bwd')
+        return dx
     assert partials.dtype == F32 and partials.numel() >= (rows + 3) // 4
     check(_lib.load().mr_unit_norm_scale_bwd(x.data_ptr(), _ld(x), log_scale.data_ptr(), inv_norm.data_ptr(), dy.data_ptr(),
                                              _ld(dy), dx.data_ptr(), _ld(dx), dlog_scale.data_ptr(), int(accumulate),
@@ -481,6 +529,9 @@ def adam_bf16_update(master, work, grad, mu, nu, decay_flags, b1, b2, eps, weigh
 
 @_timed('optimizer')
 def nan_to_num_(g):
+    if g.dtype == F32:
+        check(_lib.load().mr_f32_nan_to_num(g.data_ptr(), g.numel(), _stream()), 'mr_f32_nan_to_num')
+        return
     check(_lib.load().mr_nan_to_num_bf16(g.data_ptr(), g.numel(), _stream()), 'mr_nan_to_num_bf16')
 
 
@@ -513,6 +564,12 @@ def softmax_xent(logits, row_stride, class_stride, labels, rows, C, coef, loss_o
 @_timed('optimizer')
 def adam_bf16_update_dev(master, work, grad, mu, nu, orig, decay_flags, b1, b2, eps, weight_decay, hyper):
     """Adam chain on (a sub-range of) the flat buffers with the per-step scalars in the device vector `hyper` [4]."""
+    if grad.dtype == F32:       # use_bfloat16_grads = False: fp32 gradients straight into the chain
+        assert orig is None
+        check(_lib.load().mr_adam_f32grad_update_dev(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
+                                                     decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay, hyper.data_ptr(), _stream()),
+              'mr_adam_f32grad_update_dev')
+        return
     check(_lib.load().mr_adam_bf16_update_dev(master.data_ptr(), work.data_ptr(), grad.data_ptr(), mu.data_ptr(), nu.data_ptr(),
                                               _ptr(orig), decay_flags.data_ptr(), master.numel(), b1, b2, eps, weight_decay,
                                               hyper.data_ptr(), _stream()), 'mr_adam_bf16_update_dev')

@@ -232,6 +232,17 @@ class ParamStore:
         last = sel[-1]
         ops.transpose_leaves(self.work, self.workT, self._tr_dev, len(self._tr), sel[0][3], last[3] + (last[1] // 64) * (last[2] // 64))
 
+    def enable_f32_grads(self):
+        """use_bfloat16_grads = False (pretrain/pretrain_model.py:323-333): the step differentiates the fp32 master parameters and the
+        gradients stay fp32 -- a second flat gradient buffer (4 B / parameter) with the same offsets, allocated on first use."""
+        if getattr(self, 'grad32', None) is None:
+            self.grad32 = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            self.g32 = {}
+            for name, fshape, vshape, kind, fan in self.specs:
+                o, n = self.offsets[name]
+                self.g32[name] = self.grad32[o:o + n].view(*vshape)
+        return self.grad32
+
     def _to_tree(self, flat):
         host = flat.detach().to('cpu')
         tree = {}
@@ -248,6 +259,9 @@ class ParamStore:
 
     def grad_tree(self):
         return self._to_tree(self.grad)
+
+    def grad32_tree(self):
+        return self._to_tree(self.grad32)
 
 
 def _set(tree, path, val):

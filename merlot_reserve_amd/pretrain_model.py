@@ -32,6 +32,9 @@ class _Preds(dict):
 class MerlotReservePretrainer:
     def __init__(self, config, device='cuda:0', rank=0, world=1, comm=None, seed=0):
         self.config, self.device, self.rank, self.world, self.comm, self.seed = config, torch.device(device), rank, world, comm, seed
+        # config['model']['use_bfloat16'] (M:594; train.py:61-67 clears it off-TPU): False = the whole step in fp32 -- the fp32 program of
+        # the engine, fp32 gradients (train_step(use_bfloat16_grads=False), which train.py:106 ties to this flag)
+        self.use_bfloat16 = bool(config['model'].get('use_bfloat16', True))
         self.trainer = None
         self._last_tree = None
 
@@ -48,7 +51,8 @@ class MerlotReservePretrainer:
     def _ensure(self, batch):
         B = int(batch['images'].shape[0])
         if self.trainer is None:
-            self.trainer = Trainer(self.config, B, self.device, rank=self.rank, world=self.world, seed=self.seed, comm=self.comm)
+            self.trainer = Trainer(self.config, B, self.device, rank=self.rank, world=self.world, seed=self.seed, comm=self.comm,
+                                   bf16_grads=self.use_bfloat16)
         elif self.trainer.B != B:
             raise ValueError(f'this model was initialised for {self.trainer.B} records per device, got a batch of {B} '
                              '(buffers and hipGraphs are shape-specialised; build another model for another batch size)')
@@ -140,15 +144,22 @@ def construct_train_state(opt_config, model, params=None):
     if params is not None:
         model._load({'params': params})
     model.trainer.state = _trainer.construct_train_state(opt_config, model.trainer.params)
+    model.trainer.state.f32_grads = model.trainer.f32
     return TrainState(model, model.trainer.state)
 
 
 def train_step(state, batch, use_bfloat16_grads=True, split_from_here=None, gumbel_z=None):
     """P:306-340: bf16 parameter copy -> forward -> loss -> backward -> nan_to_num -> mean over ranks -> optimizer.
-    Returns (state, loss_info) with loss_info as host floats, averaged over ranks like the reference's pmean (:335)."""
-    if not use_bfloat16_grads:
-        raise NotImplementedError('gradients are kept in bf16 (the reference pretraining configs: use_bfloat16 = True)')
-    tr = state._model._ensure(batch)
+    Returns (state, loss_info) with loss_info as host floats, averaged over ranks like the reference's pmean (:335).
+    use_bfloat16_grads follows the model's precision, as in the reference's launcher (train.py:106 passes
+    config['model']['use_bfloat16']): True with a bf16 model (the fast path: bf16 working copy, bf16 gradients), False with a model
+    built from use_bfloat16 = False (fp32 program, fp32 gradients into the same Adam chain).  The two mixed combinations
+    (fp32 accumulation of a bf16 model's gradients; an fp32 model on bf16-rounded parameters) are not built and raise."""
+    model = state._model
+    if bool(use_bfloat16_grads) != model.use_bfloat16:
+        raise NotImplementedError(f"train_step(use_bfloat16_grads={bool(use_bfloat16_grads)}) on a model with config['model']['use_bfloat16'] = "
+                                  f'{model.use_bfloat16}: only the combinations the reference launches (train.py:106: equal flags) are implemented')
+    tr = model._ensure(batch)
     draws = None if split_from_here is None else (split_from_here, gumbel_z)
     tr.train_step(batch, draws=draws)
     info = tr.loss_info(reduce=True)           # mean over ranks (P:336)

@@ -40,6 +40,7 @@ class TrainState:
         self.params = params
         self.opt_config = dict(opt_config)
         self.step = 0
+        self.f32_grads = False          # use_bfloat16_grads = False: the chain reads params.grad32 (set by Trainer(bf16_grads=False))
 
     def _scalars(self):
         """(sched, neg_lr, bias_corr1, bias_corr2) of the current step: scale_by_schedule uses its own count, evaluated
@@ -57,6 +58,11 @@ class TrainState:
     def apply_gradients(self):
         """optax chain of optimization.py:180-190 + apply_updates, one fused launch over the flat buffers."""
         oc, p = self.opt_config, self.params
+        if self.f32_grads:               # fp32 gradients: the device-scalar form of the same chain over the whole buffer
+            self.prepare_step()
+            self.apply_range(0, p.total)
+            self.finish_step()
+            return
         sched, neg_lr, bc1, bc2 = self._scalars()
         ops.adam_bf16_update(p.master, p.work, p.grad, p.mu, p.nu, p.decay_flags, oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                              oc.get('eps', 1e-8), oc['weight_decay_rate'], sched, neg_lr, bc1, bc2)
@@ -87,7 +93,8 @@ class TrainState:
     def apply_range(self, lo, hi):
         oc, p = self.opt_config, self.params
         assert lo % 2048 == 0 and hi % 2048 == 0
-        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], None,
+        grad = p.grad32 if self.f32_grads else p.grad
+        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], None,
                                  p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                                  oc.get('eps', 1e-8), oc['weight_decay_rate'], self.hyper)
         p.update_transposed(lo, hi)
@@ -132,12 +139,25 @@ def construct_train_state(opt_config, params):
 
 
 class Trainer:
-    def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None):
+    f32 = False          # (instances built by __init__ set it from bf16_grads)
+
+    def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None, bf16_grads=True):
+        """bf16_grads = False is the reference's use_bfloat16_grads = False step (pretrain/pretrain_model.py:323-333; train.py:61-67): the
+        fp32 master parameters are differentiated, the gradients stay fp32 through nan_to_num / pmean and enter the Adam chain as
+        fp32 -- the fp32 program of the engine (mr_f32_* kernels, eager, several times slower than the bf16 step: the correctness
+        path, not the benchmarked one).  Data parallel with a torch.distributed comm (dist.Comm); the library communicator's
+        all-gather / reduce-scatter of the contrastive embeddings are bf16 only."""
         self.config, self.B, self.rank, self.world = config, B, rank, world
         self.device = torch.device(device)
+        self.f32 = not bf16_grads
         self.params = ParamStore(config, self.device, seed=seed)          # same seed on every rank: replicated init
         self.state = construct_train_state(config['optimizer'], self.params)
-        self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world)
+        self.state.f32_grads = self.f32
+        self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world,
+                                     dtype=torch.float32 if self.f32 else torch.bfloat16, train=True)
+        if self.f32 and comm is not None and world > 1 and getattr(comm, 'capturable', False):
+            raise NotImplementedError('bf16_grads=False with the library communicator: its embedding all-gather / reduce-scatter are bf16 only; '
+                                      'use dist.Comm (torch.distributed)')
         self.comm = comm
         # the collective path runs whenever a comm is given -- also with a single rank, which is how the RCCL calls
         # themselves are exercised on a 1-GPU box (tests/test_dist_gpu.py)
@@ -149,7 +169,7 @@ class Trainer:
         if self.use_comm:
             assert comm.world == world and comm.rank == rank
             R, H = self.engine.R, self.engine.d.H
-            z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)
+            z = lambda *s: torch.zeros(*s, dtype=self.engine.dtype, device=self.device)
             self.E_all, self.dE_all, self.dE_red = z(world, R, H), z(world, R, H), z(R, H)
             self.metrics = torch.zeros(8, dtype=torch.float32, device=self.device)
 
@@ -214,7 +234,7 @@ class Trainer:
             e.record()
             return e
         with torch.cuda.stream(cs):
-            g = self.params.grad[lo:hi]
+            g = (self.params.grad32 if self.f32 else self.params.grad)[lo:hi]
             e_ready = ev()
             if self.use_comm:
                 ops.nan_to_num_(g)
@@ -224,7 +244,7 @@ class Trainer:
                 self.state.apply_range(lo, hi)
             e_updated = ev()
         if tl is not None:
-            tl.append((str(key), (hi - lo) * 2 / 1e6, e_ready, e_reduced, e_updated))
+            tl.append((str(key), (hi - lo) * g.element_size() / 1e6, e_ready, e_reduced, e_updated))
 
     def _backward_reduce_update(self, update=True):
         eng = self.engine
@@ -316,6 +336,7 @@ class Trainer:
         Call after at least one eager train_step (buffers, plan capacities and the communicator's lazy state exist).
         A torch.distributed comm cannot be captured (its collectives are host-scheduled): such a trainer steps eagerly."""
         assert not self.use_comm or self.comm.capturable, 'only the library RCCL communicator (dist.NativeComm) can be captured'
+        assert not self.f32, 'the fp32-gradient step runs eagerly (train_step)'
         eng = self.engine
         self.images_in = torch.zeros_like(batch['images'])
         self.audio_in = torch.zeros_like(batch['audio_clips'])
