@@ -156,12 +156,18 @@ class TowerEngine:
             with torch.cuda.stream(self.side_stream):
                 return fn()
         self.cur = self.sc_side
+        side_cus = int(os.environ.get('MR_SIDE_CUS', '0'))       # (experiment) persistent GEMM grids of the side stream's tower
+        prev = ops.get_option('gemm_cus') if side_cus else 0
         try:
+            if side_cus:
+                ops.set_option('gemm_cus', side_cus)
             if os.environ.get('MR_NO_SIDE_STREAM') == '1':       # (A/B switch) same work, issued in line
                 return fn()
             with torch.cuda.stream(self.side_stream):
                 return fn()
         finally:
+            if side_cus:
+                ops.set_option('gemm_cus', prev)
             self.cur = self.sc_main
 
     def _unpad_csr(self, nseq, S):
