@@ -1,8 +1,11 @@
 """Do the parallel branches of a replayed hipGraph run CONCURRENTLY on this box?  Two chains of N single-workgroup kernels of ~50 us each
 (mr_f32_sum_rows_strided over one 256-column block and many row groups: one workgroup, a serial loop) -- on one stream, on two streams eagerly, and the
 same two captured as one graph with a fork and a join.  Concurrent branches halve the time."""
+import os
+import sys
 import time
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from merlot_reserve_amd import _lib
 
 lib = _lib.load()
