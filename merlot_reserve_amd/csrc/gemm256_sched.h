@@ -213,7 +213,7 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
 // The persistent kernels of gemm3.hip / gemm4.hip decode their items once per workgroup (lane q = the workgroup's q-th item) for ANY
 // grid size G (a multiple of 8 when the XCD partition is on: G / 8 workgroups per XCD): 256 = the whole chip, 240 = 30 per XCD, which
 // leaves two CUs of every XCD to a resident collective kernel (mr_set_option "gemm_cus").  Single problem, no split-K.
-__device__ __forceinline__ void item_pp(const G256Args& ga, int bperm, int q, int G, int bn, int& m0, int& n0) {
+__device__ __forceinline__ void item_pp(const G256Args& ga, int bperm, int q, int G, int bn, int& m0, int& n0, int bm = BM) {
     if (ga.xmode == 1) {
         const int px_ = G >> 3;                                             // workgroups per XCD
         const int x = bperm / px_, sl = bperm - x * px_;
@@ -225,11 +225,11 @@ __device__ __forceinline__ void item_pp(const G256Args& ga, int bperm, int q, in
         const int panel = qq / (hm * gw), rem = qq - panel * hm * gw;
         const int left = hn - panel * gw, pw = left < gw ? left : gw;          // the last panel may be narrower
         const int m = rem / (pw > 0 ? pw : 1), n = panel * gw + rem - m * pw;
-        m0 = qq < hm * hn ? (m_lo + m) * BM : -1;
+        m0 = qq < hm * hn ? (m_lo + m) * bm : -1;
         n0 = (n_lo + n) * bn;
     } else {
         const int w = bperm + q * G, tn = ga.tiles_n[0];
-        m0 = w < ga.nwork ? (w / tn) * BM : -1;
+        m0 = w < ga.nwork ? (w / tn) * bm : -1;
         n0 = (w % tn) * bn;
     }
 }

@@ -447,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
         if (EPI_SYNC && wr == 0) G3_BARRIER();
         {
             const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
+            constexpr int MR_EPI_MI = 8;
 #define MR_EPI_ROW_FENCE() do {} while (0)
 #include "gemm3_epilogue.inc"
 #undef MR_EPI_ROW_FENCE

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const G256Args ga) {
         // ---------------- epilogue (bf16 output; registers + ordinary loads, no LDS) ----------------
         {
             const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
+            constexpr int MR_EPI_MI = 8;
 #define MR_EPI_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #include "gemm3_epilogue.inc"
 #undef MR_EPI_ROW_FENCE

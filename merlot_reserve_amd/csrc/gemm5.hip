@@ -21,6 +21,13 @@
 // Per step and wave: 32 MFMAs, 12 ds_read_b128, 6 LDS-DMA requests (4 A + 2 B pieces of 1 KiB), each behind a pair of MFMAs in
 // source order pinned by scheduling barriers (as in gemm4.hip).  The requests are unconditional (a cursor without an item requests
 // from an empty descriptor: zero fill into a stage nobody reads), the cursor runs across output tiles, and so do the fragment reads.
+// TM = 128 (round 4, option "gemm5" = 3 / the few-tile policy): the same kernel on 128 x 128 tiles -- four waves as 2 x 2 of 64 x 64 (4 x 4
+// accumulators, 16 MFMAs per step and wave), an EIGHT-stage ring (128 KiB, one workgroup per CU) -- for problems whose 256-row tile grids
+// leave most of the chip empty (M = 2308 / 3072 rows, N = 768 / 1024: the VCR ViT, the span tower): twice the tiles, half the k-loop per tile,
+// at 1.33 x the operand bytes per FLOP of the 256 x 128 tile (LDS-bound: 48 KiB through the LDS per 256 MFMA cycles; 550 TF/s at best).
+// Measured (gemm3_test g5time, us; ping-pong / one-barrier kernels | this geometry): 2308 x 1024 x 4096 46-52 | 35, x 3072 46 | 30, x 1024 20 | 13;
+// 3072 x 768 x 3072 38-48 | 30, x 768 17.5 | 11.7.  (A three-stage ring with three workgroups per CU was 10 % slower on the long-K shapes, a
+// six-stage ring on 256 x 128 tiles never faster than two workgroups per CU: both removed.)
 // 64-byte rows: a 16-row fragment block is one 1-KiB LDS-DMA piece (lane l -> row l >> 2, 16-byte slot l & 3); slot = chunk ^
 // ((0 - (row >> 2)) & 3) on the SOURCE address and on the ds_read_b128 address makes the reads conflict-free over the hardware's
 // four 16-lane groups (checked by enumeration: every group covers 16 distinct 16-byte columns of the 256-byte bank row).
@@ -42,28 +49,37 @@ using namespace g256;
 #endif
 
 constexpr int BN5 = 128;
-constexpr int STG_A = 256 * 64, NSTG = 3;
 // NW = 4: the two-workgroups-per-CU geometry (256 x 128 tile, 72 KiB).  NW = 8 (experiment, option "gemm5" = 2): ONE workgroup of eight
 // waves as 2 x 4 on a 256 x 256 tile (96 KiB) -- the ping-pong kernel's geometry and operand traffic under THIS kernel's k-loop (BK = 32
 // steps, one barrier per step, no wave-group phases).
-template <int NW> struct Geo5 {
+// NS = ring stages.  3: a request has ONE step to land (it is waited for at the end of the step after the one that issued it) -- fine beside a
+// second resident workgroup.  The 128-row geometry (one workgroup per CU: its problems have fewer tiles than the chip has CUs) requests NS = 8
+// steps ahead and waits for the stage two steps ahead, leaving six steps for the L2 round trip.
+template <int NW, int TM = 256, int NS = 3> struct Geo5 {
+    static_assert(TM == 256 || (TM == 128 && NW == 4), "tile heights");
+    static constexpr int NSTG = NS;
     static constexpr int BN = NW == 4 ? 128 : 256;
-    static constexpr int STG_B = BN * 64, STG = STG_A + STG_B, LDS = NSTG * STG;
-    static constexpr int PA = 16 / NW, PB = (BN / 16) / NW, ND = PA + PB;         // 1-KiB pieces per wave and step: A, B, both
+    static constexpr int MI = TM / 32;                                             // 16-row blocks per wave (two wave rows)
+    static constexpr int STG_A = TM * 64, STG_B = BN * 64, STG = STG_A + STG_B, LDS = NSTG * STG;
+    static constexpr int PA = (TM / 16) / NW, PB = (BN / 16) / NW, ND = PA + PB;   // 1-KiB pieces per wave and step: A, B, both
+    static constexpr int OCC = NS > 3 ? 1 : TM == 128 ? 3 : 2;                     // workgroups per CU
 };
 static_assert(Geo5<4>::LDS == 72 * 1024 && 2 * Geo5<4>::LDS <= 160 * 1024 && Geo5<8>::LDS == 96 * 1024, "LDS budgets");
+static_assert(Geo5<4, 128, 8>::LDS == 128 * 1024, "LDS budget of the 128 x 128 geometry");
 
 __device__ __forceinline__ int swz5(int row) { return (0 - ((row >> 2) & 3)) & 3; }
 
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, const int stagger_mode, const int stagger_units) {
+template <int MODE, int NW, int TM = 256, int NS = 3>
+__global__ __launch_bounds__(NW * 64, (Geo5<NW, TM, NS>::OCC)) void gemm5_kernel(const G256Args ga, const int stagger_mode, const int stagger_units) {
     constexpr int NJ = 4, WCOLS = 64;
-    using GEO = Geo5<NW>;
-    constexpr int STG = GEO::STG, PA = GEO::PA, PB = GEO::PB, ND = GEO::ND, BNT = GEO::BN;
+    using GEO = Geo5<NW, TM, NS>;
+    constexpr int NSTG = NS;
+    constexpr int STG = GEO::STG, STG_A = GEO::STG_A, PA = GEO::PA, PB = GEO::PB, ND = GEO::ND, BNT = GEO::BN, MI = GEO::MI;
     // store instructions a wave issues per tile (all unconditional, see gemm3_epilogue.inc): the first step behind an epilogue may
     // leave them -- and its own 6 requests -- outstanding while it waits for the stage requested AHEAD of the epilogue
-    constexpr int NST = 8 * (NJ / 2) * (MODE == 2 ? 2 : 1);
-    constexpr int WAIT_FIRST = ND + NST;
+    constexpr int NST = MI * (NJ / 2) * (MODE == 2 ? 2 : 1);
+    constexpr int WAIT_RING = (NSTG - 2) * ND;        // requests that may stay in flight at a step's end: the stages three and more steps ahead
+    constexpr int WAIT_FIRST = WAIT_RING + NST;
     static_assert(WAIT_FIRST <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) char smem[GEO::LDS];
 
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
     const int xcd = blockIdx.x & 7, qd = G >> 3, rm = G & 7;
     const int bperm = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     int m0v, n0v;
-    item_pp(ga, bperm, lane, G, BNT, m0v, n0v);
+    item_pp(ga, bperm, lane, G, BNT, m0v, n0v, TM);
     auto item_m0 = [&](int q) -> int { const int r = __builtin_amdgcn_readlane(m0v, q & 63); return q < 64 ? r : -1; };
     auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
     if (item_m0(0) < 0) return;
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
     const unsigned pstep_a = 16u * lda2, pstep_b = 16u * ldb2;
     // fragment reads: lane (g, li) of a 16-row block reads k-chunk g of row li
     const int fo = li * 64 + ((g ^ swz5(li)) << 4);
-    const int fa = wr * 8192 + fo, fb = STG_A + wc * 4096 + fo;
+    const int fa = wr * (TM * 32) + fo, fb = STG_A + wc * 4096 + fo;
 
     // The phase between the two workgroups of a CU (see the header): the one whose waves sit in the odd wave slots waits ~ one k-loop.
     if (stagger_mode != 0) {
@@ -178,9 +194,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
     };
     fetch_bias(cn0);
 
-    // prologue: stages 0, 1, 2 requested; stage 0 has landed when only the last two are in flight
-    G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE(); G5_ISSUE_ALL(); G5_ADVANCE();
-    wait_vmcnt<2 * ND>();
+    // prologue: the first NSTG stages requested; stage 0 has landed when only the later ones are in flight
+#pragma unroll
+    for (int s_ = 0; s_ < NSTG; ++s_) { G5_ISSUE_ALL(); G5_ADVANCE(); }
+    wait_vmcnt<(NSTG - 1) * ND>();
     G5_SB();
     __builtin_amdgcn_s_barrier();
     G5_SB();
@@ -188,17 +205,19 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
     // tile's first step has parity 0); A row blocks 0-5 are replaced IN PLACE behind their own MFMAs (72 registers instead of 96:
     // beside the 128 accumulators the rotary / GELU / column-sum epilogues spill with 96).  The in-place read of row block 5 is the
     // step's last: it has the 8 MFMAs of row blocks 6 and 7 to land before the step's closing wait.
-    bf16x8 a[6], a67[2][2], b[NJ][2];
-    auto read_frags0 = [&](const char* st) {          // all 12 fragments of a stage into parity 0 (prologue, tile switch)
+    // (TM = 128: four row blocks -- 0, 1 in place, 2, 3 double buffered; "a67" = the last two row blocks of either geometry)
+    constexpr int MIP = MI - 2;                       // row blocks replaced in place
+    bf16x8 a[MIP], a67[2][2], b[NJ][2];
+    auto read_frags0 = [&](const char* st) {          // all fragments of a stage into parity 0 (prologue, tile switch)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) b[j][0] = *reinterpret_cast<const bf16x8*>(st + fb + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + fa + i * 1024);
-        a67[0][0] = *reinterpret_cast<const bf16x8*>(st + fa + 6 * 1024);
-        a67[1][0] = *reinterpret_cast<const bf16x8*>(st + fa + 7 * 1024);
+        for (int i = 0; i < MIP; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + fa + i * 1024);
+        a67[0][0] = *reinterpret_cast<const bf16x8*>(st + fa + MIP * 1024);
+        a67[1][0] = *reinterpret_cast<const bf16x8*>(st + fa + (MIP + 1) * 1024);
     };
     read_frags0(smem);
-    wait_vmcnt<ND>();
+    wait_vmcnt<WAIT_RING>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G5_SB();
     __builtin_amdgcn_s_barrier();
@@ -207,9 +226,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
 
     while (cm0 >= 0) {
         // accumulators TRANSPOSED (mfma(B-frag, A-frag)): the lane holds C[m = .. + li][n = .. + 4 g + r]; bias modes start from the bias
-        f32x4 acc[8][NJ];
+        f32x4 acc[MI][NJ];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = binit[j];
 
@@ -222,12 +241,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
             char* const st_ = smem + ist * STG;
             const unsigned so_ = (unsigned)ik * 64u;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const bf16x8 ar = r < 6 ? a[r < 6 ? r : 0] : a67[r - 6 < 0 ? 0 : r - 6][CUR];
+            for (int r = 0; r < MI; ++r) {
+                const bf16x8 ar = r < MIP ? a[r < MIP ? r : 0] : a67[r - MIP < 0 ? 0 : r - MIP][CUR];
                 acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][CUR], ar, acc[r][0], 0, 0, 0);
                 acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][CUR], ar, acc[r][1], 0, 0, 0);
                 G5_SB();
-                if constexpr (!LAST) {               // the double-buffered fragments first: b0..b3, then row blocks 6, 7
+                if constexpr (!LAST) {               // the double-buffered fragments first: b0..b3, then (eight row blocks) row blocks 6, 7
                     if (r < 4) G5_RD(b[r][NXT], rd + fb + r * 1024);
                     else if (r < 6) G5_RD(a67[r - 4][NXT], rd + fa + (r + 2) * 1024);
                 }
@@ -238,12 +257,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
                 acc[r][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[3][CUR], ar, acc[r][3], 0, 0, 0);
                 G5_SB();
                 if constexpr (!LAST) {
-                    if (r < 6) G5_RD(a[r], rd + fa + r * 1024);       // in place: this row block's MFMAs are issued
+                    if (r < MIP) G5_RD(a[r < MIP ? r : 0], rd + fa + r * 1024);       // in place: this row block's MFMAs are issued
+                    else if (MI == 4) G5_RD(a67[(r - MIP) & 1][NXT], rd + fa + r * 1024);   // four row blocks: the double-buffered pair rides in these slots
                 }
                 G5_SB();
             }
             if (FIRST && have_stores) wait_vmcnt<WAIT_FIRST>();
-            else wait_vmcnt<ND>();
+            else wait_vmcnt<WAIT_RING>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             G5_SB();
             G5_BARRIER();
@@ -262,7 +282,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm5_kernel(const G256Args ga, co
         G5_STAMP(1);
         // ---------------- epilogue (bf16 output; registers + ordinary loads, no LDS) ----------------
         {
-            const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
+            const int wrow0 = cm0 + wr * (TM / 2), wcol0 = cn0 + wc * WCOLS;
+            constexpr int MR_EPI_MI = MI;
 #define MR_EPI_ROW_FENCE() do {} while (0)
 #include "gemm3_epilogue.inc"
 #undef MR_EPI_ROW_FENCE
@@ -306,16 +327,29 @@ bool mr_gemm5_takes(const mr_gemm_args* a) {
     if (a->colsum && !a->aux) return false;
     if (a->bias && (a->residual || a->aux)) return false;
     const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
-    if (((a->M + 255) / 256) * ((a->N + 127) / 128) > 64 * 2 * ncu) return false;          // <= 64 items per workgroup
+    if (((a->M + 127) / 128) * ((a->N + 127) / 128) > 64 * 2 * ncu) return false;          // <= 64 items per workgroup (either tile height)
     return true;
+}
+
+// Tile height of a problem: 128 x 128 tiles (deep ring, one workgroup per CU) where even the 128-row grid has no more tiles than the chip has
+// CUs, or on request (option "gemm5" = 3); 256 x 128 (two workgroups per CU) otherwise.
+static bool g5_rows128(const mr_gemm_args* a) {
+    const int v = mr_opts().gemm5;
+    if (v == 3) return true;
+    if (v == 1 || v == 2) return false;
+    static int env = -2;
+    if (env == -2) env = mr_env_int("MR_G5_ROWS128", -1);
+    if (env >= 0) return env != 0;
+    return ((a->M + 127) / 128) * ((a->N + 127) / 128) <= 256;
 }
 
 int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
     const bool eight = mr_opts().gemm5 == 2;            // (experiment) one eight-wave workgroup per CU on 256 x 256 tiles
-    const int64_t slots = eight ? ncu : 2 * ncu;        // two workgroups per CU
+    const bool r128 = !eight && g5_rows128(a);          // 128 x 128 tiles, deep ring, one workgroup per CU
+    const int64_t slots = (eight || r128) ? ncu : 2 * ncu;        // workgroups per CU
     const int64_t bn = eight ? 256 : g5::BN5;
-    const int64_t tm = (a->M + 255) / 256, tn = (a->N + bn - 1) / bn, nwork = tm * tn;
+    const int64_t tm = (a->M + (r128 ? 127 : 255)) / (r128 ? 128 : 256), tn = (a->N + bn - 1) / bn, nwork = tm * tn;
     const int64_t gsz = nwork < slots ? nwork : slots;
     g256::G256Args ga;
     memset(&ga, 0, sizeof(ga));
@@ -355,7 +389,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     if (st_env == -2) st_env = mr_env_int("MR_G5_STAGGER", -1);
     if (su_env == -2) su_env = mr_env_int("MR_G5_STAGGER_PCT", -1);
     int st_mode = g_mr_opt_gemm5_stagger >= 0 ? g_mr_opt_gemm5_stagger : st_env >= 0 ? st_env : 1;
-    if (gsz <= ncu || eight) st_mode = 0;                 // one workgroup per CU: nobody to be out of phase with
+    if (gsz <= ncu || eight || r128) st_mode = 0;         // one workgroup per CU: nobody to be out of phase with (three per CU: no phase is set)
     // ~ one k-loop alone on the CU: K / 32 steps of 512 MFMA cycles, in units of 2048 cycles (percent knob for experiments)
     const int pct = su_env >= 0 ? su_env : 100;
     const int st_units = (int)((a->K / 32) * 600 * pct / 100 / 2048);
@@ -376,6 +410,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
 #define G5_LAUNCH(MODE)                                                                                       \
     do {                                                                                                      \
         if (eight) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 8>), grid, block, 0, s, ga, st_mode, st_units); \
+        else if (r128) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4, 128, 8>), grid, block, 0, s, ga, st_mode, st_units); \
         else hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4>), grid, block, 0, s, ga, st_mode, st_units);       \
     } while (0)
     switch (mode) {
@@ -387,7 +422,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
         default: G5_LAUNCH(5); break;
     }
 #undef G5_LAUNCH
-    mr_note_route("g5::gemm5_kernel<%d,%d>", mode, eight ? 8 : 4);
+    mr_note_route(r128 ? "g5::gemm5_kernel<%d,%d,128,8>" : "g5::gemm5_kernel<%d,%d>", mode, eight ? 8 : 4);
     MR_CHECK_LAUNCH("mr_gemm (gemm5)");
     return MR_OK;
 }
@@ -399,12 +434,15 @@ bool mr_gemm5_wanted(const mr_gemm_args* a) {
     const int v = g_mr_opt_gemm5 >= 0 ? g_mr_opt_gemm5 : env;
     if (v == 0 || a->colsum != nullptr && !a->aux) return false;
     if (!mr_gemm5_takes(a)) return false;
-    if (v == 1 || v == 2) return true;
+    if (v >= 1 && v <= 3) return true;
     // Default policy (measured, scripts/micro/gemm3_test g5time): the few-tile short-K problems -- at most one 256 x 128 tile per CU, K <= 1024:
     // the audio / span towers' 768-wide projections, the span and VCR-ViT QKV -- run 8-13 % faster here than on the one-barrier kernel's
     // 96-wide tiles (16.3 vs 18.0, 20.6 vs 23.4, 15.3 vs 17.4, 24.5 vs 26.9 us); everything with more tiles or a longer K is slower
     // (the 256 x 128 tile pair of a CU writes 1.5 x the operand bytes into LDS: DESIGN.md section 3).
-    if (a->colsum != nullptr || a->M < 1024) return false;
+    // Round 4, 128 x 128 tiles: problems with at most one such tile per CU (M = 2308 / 3072, N = 768 / 1024, any K) run 25-40 % faster there than
+    // on either of the above (the header's table); with more tiles the 256-row geometries win (audio tower, M = 5952: 36-38 vs 52 us at K = 3072).
+    if (a->colsum != nullptr || a->M < 1024 || a->N < 256) return false;
+    if (g5_rows128(a)) return true;
     const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
-    return tiles <= 256 && a->K <= 1024 && a->N >= 256;
+    return tiles <= 256 && a->K <= 1024;
 }

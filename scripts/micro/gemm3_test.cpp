@@ -145,8 +145,12 @@ static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[
     hipEvent_t e0[4], e1[4];
     for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
     auto launch = [&](int v, int set) {
-        mr_set_option("gemm5", v == 0 ? 0 : (getenv("G5_EIGHT") ? 2 : 1));      // G5_EIGHT=1: the eight-wave 256 x 256 variant
-        if (v) mr_set_option("gemm5_stagger", v - 1);
+        // columns 1..3 = "gemm5" option values, G5_COLS (default 1,3,-1: 256 x 128 two per CU | 128 x 128 deep ring | the default policy; 2: eight waves)
+        static int cols[4] = {0, 1, 3, -1};
+        static bool init = false;
+        if (!init) { init = true; if (const char* e = getenv("G5_COLS")) sscanf(e, "%d,%d,%d", &cols[1], &cols[2], &cols[3]); }
+        mr_set_option("gemm5", cols[v]);
+        mr_set_option("gemm5_stagger", -1);
         { const char* e = getenv("G5_CUS"); mr_set_option("gemm_cus", (v && e) ? atoi(e) : 0); }      // G5_CUS=128: 256 workgroups = one per CU
         setup_args(&g, c, set, colsum);
         if (mr_gemm(&g, nullptr) != 0) { printf("mr_gemm failed: %s\n", mr_last_error()); exit(3); }
@@ -284,8 +288,8 @@ int main(int argc, char** argv) {
             {3072, 2304, 768, 1, "span qkv"}, {4616, 4096, 1024, 4, "ragged M aux"}, {2000, 1000, 192, 0, "ragged M N"},
             {1024, 256, 128, 3, "small"}, {1312, 3072, 128, 0, "four steps"}, {40000, 192, 128, 5, "four steps, narrow"}, {300, 192, 256, 1, "tiny ragged rot"},
         };
-        mr_set_option("gemm5", getenv("G5_EIGHT") ? 2 : 1);
-        for (int st = 0; st < (getenv("G5_EIGHT") ? 1 : 3); ++st) {
+        mr_set_option("gemm5", getenv("G5_EIGHT") ? 2 : getenv("G5_R128") ? atoi(getenv("G5_R128")) : 1);      // G5_R128=3: the 128 x 128 geometry
+        for (int st = 0; st < ((getenv("G5_EIGHT") || getenv("G5_R128")) ? 1 : 3); ++st) {
             mr_set_option("gemm5_stagger", st);
             char label[32]; snprintf(label, sizeof label, "g5/st%d", st);
             for (const Case& c : checks) fails += check_case(c, label);
@@ -301,10 +305,12 @@ int main(int argc, char** argv) {
             {5952, 3072, 768, 2, "audio fc1 fwd"}, {5952, 3072, 768, 4, "audio fc1 dgrad"}, {5952, 768, 3072, 3, "audio fc2 fwd"}, {5952, 2304, 768, 1, "audio qkv"}, {5952, 768, 768, 3, "audio proj"},
             {3072, 3072, 768, 2, "span fc1 fwd"}, {3072, 768, 3072, 3, "span fc2 fwd"}, {3072, 2304, 768, 1, "span qkv"}, {3072, 768, 768, 3, "span proj"},
             {2308, 4096, 1024, 2, "vcr vit fc1"}, {2308, 1024, 4096, 3, "vcr vit fc2"}, {2308, 3072, 1024, 1, "vcr vit qkv"},
+            {2308, 1024, 4096, 5, "vcr vit d ln2"}, {2308, 1024, 3072, 5, "vcr vit d ln1"}, {2308, 1024, 1024, 3, "vcr vit proj"}, {2308, 4096, 1024, 4, "vcr vit fc1 dgrad"},
+            {5952, 768, 3072, 5, "audio d ln2"}, {5952, 768, 2304, 5, "audio d ln1"}, {5952, 768, 768, 5, "audio d att"}, {3072, 768, 3072, 5, "span d ln2"}, {3072, 3072, 768, 4, "span fc1 dgrad"},
             {15424, 4096, 1024, 2, "large fc1 fwd"}, {15424, 4096, 1024, 4, "large fc1 dgrad"}, {15424, 1024, 4096, 3, "large fc2 fwd"},
             {15424, 3072, 1024, 1, "large qkv"}, {15424, 1024, 1024, 3, "large proj"}, {8192, 8192, 8192, 5, "8192^3"},
         };
-        printf("%-26s %18s | %9s %9s %9s %9s | TF/s default -> best g5   (sustained, interleaved; [0] default path, g5 stagger 0 / 1 (wave slot) / 2 (grid half))\n", "shape", "M x N x K", "default", "g5/st0", "g5/st1", "g5/st2");
+        printf("%-26s %18s | %9s %9s %9s %9s | TF/s default -> best g5   (sustained, interleaved; [0] gemm5 off (ping-pong / one-wave / one-barrier kernels), then the gemm5 option values of G5_COLS, default 1,3,-1 = 256 x 128 two per CU | 128 x 128 deep ring | the default policy)\n", "shape", "M x N x K", "g5 off", "col1", "col2", "col3");
         const char* sel = getenv("G5_SHAPES");          // e.g. "0,2,26": only these rows of the table
         int idx = -1;
         for (const Case& c : shapes) {

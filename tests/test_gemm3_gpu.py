@@ -1,4 +1,5 @@
-"""The ping-pong GEMM (csrc/gemm3.hip) and the one-wave-per-SIMD GEMM (csrc/gemm4.hip) forced onto every NT problem they can take, at
+"""The ping-pong GEMM (csrc/gemm3.hip), the one-wave-per-SIMD GEMM (csrc/gemm4.hip) and the few-tile GEMM (csrc/gemm5.hip: 256 x 128 tiles with
+two workgroups per CU, 128 x 128 tiles with the deep ring) forced onto every NT problem they can take, at
 both tile widths (gemm3: both barrier schedules, one / two phases per k-tile), against a plain PyTorch fp32 reference of the same op: plain products (ragged M and N, one and two
 k-tiles, several tiles per workgroup), every fused epilogue of the transformer layers (flax Dense / DenseGeneral, mreserve/modeling.py:
 228-236, 252-255), and the grouped weight-gradient (TN) kernel.  By default these shapes would partly run on the one-barrier kernel
@@ -27,19 +28,32 @@ def assert_close(got, ref, rel, name=''):
     assert bad < 1e-3, f'{name}: {bad * 100:.3f}% of elements outside tolerance'
 
 
-# (tile width, ping-pong phases per k-tile, one-wave-per-SIMD kernel for the epilogues it takes: bias / residual / plain)
-@pytest.fixture(params=[(256, 1, 0), (192, 1, 0), (256, 2, 0), (192, 2, 0), (256, 0, 1), (192, 0, 1)],
-                ids=lambda p: f'w{p[0]}-' + ('g4' if p[2] else f'ph{p[1]}'))
+# (tile width, ping-pong phases per k-tile, one-wave-per-SIMD kernel for the epilogues it takes: bias / residual / plain, "gemm5" option:
+#  1 = 256 x 128 tiles, two workgroups per CU; 3 = 128 x 128 tiles, deep ring -- every epilogue)
+@pytest.fixture(params=[(256, 1, 0, 0), (192, 1, 0, 0), (256, 2, 0, 0), (192, 2, 0, 0), (256, 0, 1, 0), (192, 0, 1, 0), (256, 1, 0, 1), (256, 1, 0, 3)],
+                ids=lambda p: f'g5-{"256x128" if p[3] == 1 else "128x128"}' if p[3] else f'w{p[0]}-' + ('g4' if p[2] else f'ph{p[1]}'))
 def forced(request):
     from merlot_reserve_amd import _lib
     lib = _lib.load()
     _lib.check(lib.mr_set_option(b'gemm3', request.param[0]), 'mr_set_option')
     _lib.check(lib.mr_set_option(b'gemm3_phases', request.param[1]), 'mr_set_option')
     _lib.check(lib.mr_set_option(b'gemm4', request.param[2]), 'mr_set_option')
+    _lib.check(lib.mr_set_option(b'gemm5', request.param[3]), 'mr_set_option')
+    _lib.check(lib.mr_set_option(b'gemm_trace', 1), 'mr_set_option')
     yield request.param
     lib.mr_set_option(b'gemm3', 1)
     lib.mr_set_option(b'gemm3_phases', 0)
     lib.mr_set_option(b'gemm4', -1)
+    lib.mr_set_option(b'gemm5', -1)
+    lib.mr_set_option(b'gemm_trace', 0)
+
+
+def routed_as_forced(forced, K):
+    """The launch went to the kernel the fixture asked for (gemm5 takes K % 64 == 0, K >= 128; shorter K falls to the ping-pong kernel)."""
+    from merlot_reserve_amd import _lib
+    name = _lib.load().mr_last_gemm_kernel().decode()
+    if forced[3] and K % 64 == 0 and K >= 128:
+        assert name.startswith('g5::gemm5_kernel') and name.endswith(',128,8>') == (forced[3] == 3), name
 
 
 @pytest.fixture
@@ -65,6 +79,7 @@ def test_nt_plain(dev, forced, M, N, K):
     a, b = rnd((M, K), dev, seed=1), rnd((N, K), dev, scale=0.05, seed=2)
     out = torch.full((M + 3, N), float('nan'), dtype=BF16, device=dev)       # three guard rows behind the output
     ops.gemm(a, b, out[:M], transB=True)
+    routed_as_forced(forced, K)
     assert_close(out[:M], a.float() @ b.float().T, 3e-3, f'NT {M}x{N}x{K}')
     assert torch.isnan(out[M:].float()).all(), 'rows past M were written'
 
@@ -88,6 +103,7 @@ def test_nt_epilogues(dev, forced):
     assert_close(out, (ref + bias.float()) * scale, 3e-3, 'bias + rot')
     pre = torch.zeros(M, N, dtype=BF16, device=dev)
     ops.gemm(a, w, out, transB=True, bias=bias, act=ops.ACT_GELU, c2=pre)
+    routed_as_forced(forced, K)
     x = ref + bias.float()
     sg = torch.sigmoid(1.702 * x)
     assert_close(out, x * sg, 4e-3, 'gelu')
@@ -100,6 +116,7 @@ def test_nt_epilogues(dev, forced):
     nrows = _lib.load().mr_gemm_colsum_rows(M)
     cs = torch.full((nrows, N), float('nan'), device=dev)
     ops.gemm(a, w, out, transB=True, aux=aux, colsum=cs)
+    routed_as_forced(forced, K)
     assert_close(out, ref.to(BF16).float() * aux.float(), 4e-3, 'aux multiply')
     assert_close(cs.sum(0), out.float().sum(0), 2e-3, 'column sums of the stored output')
     ops.gemm(a, w, out, transB=True, aux=aux)
