@@ -377,6 +377,9 @@ int mr_allreduce_mean_f32(mr_comm* comm, float* buf, int64_t n, void* stream);
 int mr_allgather(mr_comm* comm, const void* send, void* recv, int64_t n_per_rank, void* stream);
 /* recv[n_per_rank] bf16 = sum over ranks of their send[rank * n_per_rank ...]  (transpose of mr_allgather) */
 int mr_reducescatter_sum(mr_comm* comm, const void* send, void* recv, int64_t n_per_rank, void* stream);
+/* the same on fp32 elements (the fp32 training step, P:323-333 with use_bfloat16_grads = False; its all-gather moves bytes: mr_allgather on
+ * 2 * n_per_rank) */
+int mr_reducescatter_sum_f32(mr_comm* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
 
 #ifdef __cplusplus
 }

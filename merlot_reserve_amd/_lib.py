@@ -107,6 +107,7 @@ PROTOTYPES = {
     'mr_allreduce_mean_f32': (i32, [vp, vp, i64, vp]),
     'mr_allgather': (i32, [vp, vp, vp, i64, vp]),
     'mr_reducescatter_sum': (i32, [vp, vp, vp, i64, vp]),
+    'mr_reducescatter_sum_f32': (i32, [vp, vp, vp, i64, vp]),
 }
 
 _lib = None

@@ -149,3 +149,11 @@ extern "C" int mr_reducescatter_sum(mr_comm* c, const void* send, void* recv, in
     MR_RCCL_CALL("mr_reducescatter_sum", A.ReduceScatter(send, recv, (size_t)n_per_rank, ncclBfloat16, ncclSum, c->comm, static_cast<hipStream_t>(stream)));
     return MR_OK;
 }
+
+// fp32 form (the fp32 training step's dL/dE of the gathered contrastive embeddings); its all-gather is mr_allgather on twice the element count
+extern "C" int mr_reducescatter_sum_f32(mr_comm* c, const float* send, float* recv, int64_t n_per_rank, void* stream) {
+    MR_ARG(c && send && recv && n_per_rank > 0, "mr_reducescatter_sum_f32: bad args");
+    MR_RCCL_READY("mr_reducescatter_sum_f32");
+    MR_RCCL_CALL("mr_reducescatter_sum_f32", A.ReduceScatter(send, recv, (size_t)n_per_rank, ncclFloat32, ncclSum, c->comm, static_cast<hipStream_t>(stream)));
+    return MR_OK;
+}

@@ -156,12 +156,19 @@ class NativeComm:
         return torch.cuda.current_stream().cuda_stream
 
     def gather_embeddings(self, E, E_all):
-        assert E.is_contiguous() and E_all.is_contiguous() and E.dtype == torch.bfloat16 and E_all.numel() == self.world * E.numel()
-        self._lib.check(self._lib.load().mr_allgather(self._h, E.data_ptr(), E_all.data_ptr(), E.numel(), self._stream()), 'mr_allgather')
+        assert E.is_contiguous() and E_all.is_contiguous() and E.dtype in (torch.bfloat16, torch.float32) and E_all.dtype == E.dtype
+        assert E_all.numel() == self.world * E.numel()
+        n16 = E.numel() * (E.element_size() // 2)          # an all-gather moves bytes: fp32 rows travel as pairs of 16-bit elements
+        self._lib.check(self._lib.load().mr_allgather(self._h, E.data_ptr(), E_all.data_ptr(), n16, self._stream()), 'mr_allgather')
         return E_all
 
     def scatter_grad(self, dE_all, out):
-        assert out.is_contiguous() and dE_all.is_contiguous() and out.dtype == torch.bfloat16 and dE_all.numel() == self.world * out.numel()
+        assert out.is_contiguous() and dE_all.is_contiguous() and out.dtype == dE_all.dtype and dE_all.numel() == self.world * out.numel()
+        if out.dtype == torch.float32:                      # the fp32 training step
+            self._lib.check(self._lib.load().mr_reducescatter_sum_f32(self._h, dE_all.data_ptr(), out.data_ptr(), out.numel(), self._stream()),
+                            'mr_reducescatter_sum_f32')
+            return out
+        assert out.dtype == torch.bfloat16
         self._lib.check(self._lib.load().mr_reducescatter_sum(self._h, dE_all.data_ptr(), out.data_ptr(), out.numel(), self._stream()),
                         'mr_reducescatter_sum')
         return out

@@ -145,8 +145,8 @@ class Trainer:
         """bf16_grads = False is the reference's use_bfloat16_grads = False step (pretrain/pretrain_model.py:323-333; train.py:61-67): the
         fp32 master parameters are differentiated, the gradients stay fp32 through nan_to_num / pmean and enter the Adam chain as
         fp32 -- the fp32 program of the engine (mr_f32_* kernels, eager, several times slower than the bf16 step: the correctness
-        path, not the benchmarked one).  Data parallel with a torch.distributed comm (dist.Comm); the library communicator's
-        all-gather / reduce-scatter of the contrastive embeddings are bf16 only."""
+        path, not the benchmarked one).  Data parallel through either communicator (fp32 all-gather / reduce-scatter of the contrastive
+        embeddings, fp32 all-reduce of the gradient buckets)."""
         self.config, self.B, self.rank, self.world = config, B, rank, world
         self.device = torch.device(device)
         self.f32 = not bf16_grads
@@ -155,9 +155,6 @@ class Trainer:
         self.state.f32_grads = self.f32
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world,
                                      dtype=torch.float32 if self.f32 else torch.bfloat16, train=True)
-        if self.f32 and comm is not None and world > 1 and getattr(comm, 'capturable', False):
-            raise NotImplementedError('bf16_grads=False with the library communicator: its embedding all-gather / reduce-scatter are bf16 only; '
-                                      'use dist.Comm (torch.distributed)')
         self.comm = comm
         # the collective path runs whenever a comm is given -- also with a single rank, which is how the RCCL calls
         # themselves are exercised on a 1-GPU box (tests/test_dist_gpu.py)

@@ -284,7 +284,27 @@ def _native_single_rank(_i, ret):
     torch.cuda.synchronize()
     ret['collectives_identity'] = bool(torch.equal(E_all[0], E) and torch.equal(out, E) and torch.equal(flat, E.view(-1))
                                        and torch.equal(m.cpu(), torch.arange(8, dtype=torch.float32)))
+    # the fp32 forms (the fp32 training step): all-gather as bytes, mr_reducescatter_sum_f32, fp32 bucket all-reduce
+    E32 = torch.randn(10, 64, device=dev)
+    E32_all, out32, flat32 = torch.zeros(1, 10, 64, device=dev), torch.zeros(10, 64, device=dev), E32.clone().view(-1)
+    comm.gather_embeddings(E32, E32_all)
+    comm.scatter_grad(E32_all, out32)
+    comm.allreduce_mean(flat32)
+    torch.cuda.synchronize()
+    ret['collectives_identity_f32'] = bool(torch.equal(E32_all[0], E32) and torch.equal(out32, E32) and torch.equal(flat32, E32.view(-1)))
     comm.close()
+    # one fp32 training step through the communicator (one rank: every collective is the identity) == the same step without it
+    masters = []
+    for use in (False, True):
+        comm = NativeComm() if use else None
+        tr = Trainer(cfg, B, dev, seed=2, comm=comm, bf16_grads=False)
+        for b in batches[:2]:
+            tr.train_step(b, plan=tr.plan(b))
+        torch.cuda.synchronize()
+        masters.append(tr.params.master.detach().cpu())
+        if comm is not None:
+            comm.close()
+    ret['f32_step_rccl_equals_plain'] = bool(torch.equal(masters[0], masters[1]))
 
 
 def test_rccl_collectives_single_rank(dev):
@@ -299,6 +319,8 @@ def test_rccl_collectives_single_rank(dev):
     L = ret['losses']
     assert all(v == v and abs(v) < 1e9 for k in L for v in L[k])
     assert ret['collectives_identity']
+    assert ret['collectives_identity_f32']
+    assert ret['f32_step_rccl_equals_plain'], 'the fp32 step through the one-rank communicator differs from the step without it'
     assert ret['plain_eager_equals_graph'], 'hipGraph replay differs from eager execution'
     assert ret['eager_equals_graph'], 'the captured RCCL step differs from the eager RCCL step'
     assert ret['buckets'] == EXPECTED_BUCKETS
