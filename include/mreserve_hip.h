@@ -64,7 +64,7 @@ const char* mr_last_error(void);
  *                   "gemm3" admits
  *   "gemm5"         -1 = default: the few-tile problems (gemm5.hip: at most one 128 x 128 tile per CU -> that geometry; at most one
  *                   256 x 128 tile per CU and K <= 1024 -> two workgroups per CU) | 0 = never | 1 = every NT problem it can take on 256 x 128
- *                   tiles | 3 = on 128 x 128 tiles (tests, A/B; 2 = the eight-wave experiment);  "gemm5_stagger"  -1 = default | 0..3 : the
+ *                   tiles | 3 = on 128 x 128 tiles (tests, A/B);  "gemm5_stagger"  -1 = default | 0..3 : the
  *                   start phase of two workgroups sharing a CU
  *   "attn_onepass"  -1 = default: mr_attention_bwd runs its one-pass kernel (dQ, dK, dV from one sweep, one workgroup per (sequence,
  *                   head)) for 128 < S <= 256 | 0 = never (the dQ + dK / dV kernel pair) | 1 = whenever S <= 256 (tests, A/B)

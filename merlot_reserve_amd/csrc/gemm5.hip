@@ -49,22 +49,21 @@ using namespace g256;
 #endif
 
 constexpr int BN5 = 128;
-// NW = 4: the two-workgroups-per-CU geometry (256 x 128 tile, 72 KiB).  NW = 8 (experiment, option "gemm5" = 2): ONE workgroup of eight
-// waves as 2 x 4 on a 256 x 256 tile (96 KiB) -- the ping-pong kernel's geometry and operand traffic under THIS kernel's k-loop (BK = 32
-// steps, one barrier per step, no wave-group phases).
+// NW = 4 waves.  (An eight-wave workgroup on 256 x 256 tiles under this k-loop -- the ping-pong kernel's geometry and operand traffic, BK = 32
+// steps, no wave-group phases -- was slower than the ping-pong kernel on every shape: commit 502fd27, removed.)
 // NS = ring stages.  3: a request has ONE step to land (it is waited for at the end of the step after the one that issued it) -- fine beside a
 // second resident workgroup.  The 128-row geometry (one workgroup per CU: its problems have fewer tiles than the chip has CUs) requests NS = 8
 // steps ahead and waits for the stage two steps ahead, leaving six steps for the L2 round trip.
 template <int NW, int TM = 256, int NS = 3> struct Geo5 {
-    static_assert(TM == 256 || (TM == 128 && NW == 4), "tile heights");
+    static_assert(NW == 4 && (TM == 256 || TM == 128), "geometries");
     static constexpr int NSTG = NS;
-    static constexpr int BN = NW == 4 ? 128 : 256;
+    static constexpr int BN = 128;
     static constexpr int MI = TM / 32;                                             // 16-row blocks per wave (two wave rows)
     static constexpr int STG_A = TM * 64, STG_B = BN * 64, STG = STG_A + STG_B, LDS = NSTG * STG;
     static constexpr int PA = (TM / 16) / NW, PB = (BN / 16) / NW, ND = PA + PB;   // 1-KiB pieces per wave and step: A, B, both
     static constexpr int OCC = NS > 3 ? 1 : TM == 128 ? 3 : 2;                     // workgroups per CU
 };
-static_assert(Geo5<4>::LDS == 72 * 1024 && 2 * Geo5<4>::LDS <= 160 * 1024 && Geo5<8>::LDS == 96 * 1024, "LDS budgets");
+static_assert(Geo5<4>::LDS == 72 * 1024 && 2 * Geo5<4>::LDS <= 160 * 1024, "LDS budgets");
 static_assert(Geo5<4, 128, 8>::LDS == 128 * 1024, "LDS budget of the 128 x 128 geometry");
 
 __device__ __forceinline__ int swz5(int row) { return (0 - ((row >> 2) & 3)) & 3; }
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, (Geo5<NW, TM, NS>::OCC)) void gemm5_kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = NW == 4 ? wave >> 1 : wave >> 2, wc = NW == 4 ? wave & 1 : wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;
     const int g = lane >> 4, li = lane & 15;
 
     const int G = gridDim.x;
@@ -336,7 +335,7 @@ bool mr_gemm5_takes(const mr_gemm_args* a) {
 static bool g5_rows128(const mr_gemm_args* a) {
     const int v = mr_opts().gemm5;
     if (v == 3) return true;
-    if (v == 1 || v == 2) return false;
+    if (v == 1) return false;
     static int env = -2;
     if (env == -2) env = mr_env_int("MR_G5_ROWS128", -1);
     if (env >= 0) return env != 0;
@@ -345,10 +344,9 @@ static bool g5_rows128(const mr_gemm_args* a) {
 
 int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     const int64_t ncu = (g_mr_opt_gemm_cus >= 64 && g_mr_opt_gemm_cus < 256) ? (g_mr_opt_gemm_cus & ~7) : 256;
-    const bool eight = mr_opts().gemm5 == 2;            // (experiment) one eight-wave workgroup per CU on 256 x 256 tiles
-    const bool r128 = !eight && g5_rows128(a);          // 128 x 128 tiles, deep ring, one workgroup per CU
-    const int64_t slots = (eight || r128) ? ncu : 2 * ncu;        // workgroups per CU
-    const int64_t bn = eight ? 256 : g5::BN5;
+    const bool r128 = g5_rows128(a);                    // 128 x 128 tiles, deep ring, one workgroup per CU
+    const int64_t slots = r128 ? ncu : 2 * ncu;         // workgroups per CU
+    const int64_t bn = g5::BN5;
     const int64_t tm = (a->M + (r128 ? 127 : 255)) / (r128 ? 128 : 256), tn = (a->N + bn - 1) / bn, nwork = tm * tn;
     const int64_t gsz = nwork < slots ? nwork : slots;
     g256::G256Args ga;
@@ -389,11 +387,11 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     if (st_env == -2) st_env = mr_env_int("MR_G5_STAGGER", -1);
     if (su_env == -2) su_env = mr_env_int("MR_G5_STAGGER_PCT", -1);
     int st_mode = g_mr_opt_gemm5_stagger >= 0 ? g_mr_opt_gemm5_stagger : st_env >= 0 ? st_env : 1;
-    if (gsz <= ncu || eight || r128) st_mode = 0;         // one workgroup per CU: nobody to be out of phase with (three per CU: no phase is set)
+    if (gsz <= ncu || r128) st_mode = 0;         // one workgroup per CU: nobody to be out of phase with (three per CU: no phase is set)
     // ~ one k-loop alone on the CU: K / 32 steps of 512 MFMA cycles, in units of 2048 cycles (percent knob for experiments)
     const int pct = su_env >= 0 ? su_env : 100;
     const int st_units = (int)((a->K / 32) * 600 * pct / 100 / 2048);
-    dim3 grid((unsigned)gsz), block(eight ? 512 : 256);
+    dim3 grid((unsigned)gsz), block(256);
     {
         static int dbg = -1;
         if (dbg < 0) dbg = mr_env_int("MR_G5_DEBUG", 0);
@@ -409,8 +407,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
     }
 #define G5_LAUNCH(MODE)                                                                                       \
     do {                                                                                                      \
-        if (eight) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 8>), grid, block, 0, s, ga, st_mode, st_units); \
-        else if (r128) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4, 128, 8>), grid, block, 0, s, ga, st_mode, st_units); \
+        if (r128) hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4, 128, 8>), grid, block, 0, s, ga, st_mode, st_units); \
         else hipLaunchKernelGGL((g5::gemm5_kernel<MODE, 4>), grid, block, 0, s, ga, st_mode, st_units);       \
     } while (0)
     switch (mode) {
@@ -422,7 +419,7 @@ int mr_gemm5_launch(const mr_gemm_args* a, hipStream_t s) {
         default: G5_LAUNCH(5); break;
     }
 #undef G5_LAUNCH
-    mr_note_route(r128 ? "g5::gemm5_kernel<%d,%d,128,8>" : "g5::gemm5_kernel<%d,%d>", mode, eight ? 8 : 4);
+    mr_note_route(r128 ? "g5::gemm5_kernel<%d,4,128,8>" : "g5::gemm5_kernel<%d,4>", mode);
     MR_CHECK_LAUNCH("mr_gemm (gemm5)");
     return MR_OK;
 }
@@ -434,7 +431,7 @@ bool mr_gemm5_wanted(const mr_gemm_args* a) {
     const int v = g_mr_opt_gemm5 >= 0 ? g_mr_opt_gemm5 : env;
     if (v == 0 || a->colsum != nullptr && !a->aux) return false;
     if (!mr_gemm5_takes(a)) return false;
-    if (v >= 1 && v <= 3) return true;
+    if (v == 1 || v == 3) return true;
     // Default policy (measured, scripts/micro/gemm3_test g5time): the few-tile short-K problems -- at most one 256 x 128 tile per CU, K <= 1024:
     // the audio / span towers' 768-wide projections, the span and VCR-ViT QKV -- run 8-13 % faster here than on the one-barrier kernel's
     // 96-wide tiles (16.3 vs 18.0, 20.6 vs 23.4, 15.3 vs 17.4, 24.5 vs 26.9 us); everything with more tiles or a longer K is slower

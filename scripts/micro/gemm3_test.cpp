@@ -145,7 +145,7 @@ static void time_g5(const Case& c, bool colsum, double budget_ms, double out_us[
     hipEvent_t e0[4], e1[4];
     for (int v = 0; v < 4; ++v) { CK(hipEventCreate(&e0[v])); CK(hipEventCreate(&e1[v])); }
     auto launch = [&](int v, int set) {
-        // columns 1..3 = "gemm5" option values, G5_COLS (default 1,3,-1: 256 x 128 two per CU | 128 x 128 deep ring | the default policy; 2: eight waves)
+        // columns 1..3 = "gemm5" option values, G5_COLS (default 1,3,-1: 256 x 128 two per CU | 128 x 128 deep ring | the default policy)
         static int cols[4] = {0, 1, 3, -1};
         static bool init = false;
         if (!init) { init = true; if (const char* e = getenv("G5_COLS")) sscanf(e, "%d,%d,%d", &cols[1], &cols[2], &cols[3]); }
@@ -288,8 +288,8 @@ int main(int argc, char** argv) {
             {3072, 2304, 768, 1, "span qkv"}, {4616, 4096, 1024, 4, "ragged M aux"}, {2000, 1000, 192, 0, "ragged M N"},
             {1024, 256, 128, 3, "small"}, {1312, 3072, 128, 0, "four steps"}, {40000, 192, 128, 5, "four steps, narrow"}, {300, 192, 256, 1, "tiny ragged rot"},
         };
-        mr_set_option("gemm5", getenv("G5_EIGHT") ? 2 : getenv("G5_R128") ? atoi(getenv("G5_R128")) : 1);      // G5_R128=3: the 128 x 128 geometry
-        for (int st = 0; st < ((getenv("G5_EIGHT") || getenv("G5_R128")) ? 1 : 3); ++st) {
+        mr_set_option("gemm5", getenv("G5_R128") ? atoi(getenv("G5_R128")) : 1);      // G5_R128=3: the 128 x 128 geometry
+        for (int st = 0; st < (getenv("G5_R128") ? 1 : 3); ++st) {
             mr_set_option("gemm5_stagger", st);
             char label[32]; snprintf(label, sizeof label, "g5/st%d", st);
             for (const Case& c : checks) fails += check_case(c, label);
