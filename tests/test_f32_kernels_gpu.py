@@ -172,3 +172,106 @@ def test_f32_rowops(dev):
     z = torch.zeros(3 * 5, H, device=dev)
     ops.fill_rows(t0[7], z, 3, 5, 0)
     assert torch.equal(z.view(3, 5, H)[:, 0], t0[7].expand(3, H)) and float(z.view(3, 5, H)[:, 1:].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- fp32 backward kernels (csrc/f32bwd.hip)
+def test_f32_layernorm_bwd(dev):
+    """dx (+ the residual-path gradient), dgamma, dbeta against fp64 autograd; dx may alias dy (the engine's final / pre LayerNorm)."""
+    from merlot_reserve_amd import ops
+    rows, H = 77, 768
+    x = rnd((rows, H), dev, 3.0, seed=1) + 0.7
+    g = rnd((H,), dev, seed=2) + 1.0
+    dy, add = rnd((rows, H), dev, seed=3), rnd((rows, H), dev, seed=4)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), torch.zeros(H, dtype=F64, device=dev, requires_grad=True)
+    torch.nn.functional.layer_norm(xd, (H,), gd, bd, 1e-5).backward(dy.double())
+    ws = torch.zeros(2 * rows, device=dev)
+    dx, dgam, dbet = torch.zeros_like(x), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    mean = rstd = torch.zeros(rows, device=dev)                      # (the fp32 kernel recomputes the statistics)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dgam, dbet, ws, dx_add=add)
+    assert relerr(dx, xd.grad + add.double()) < 2e-6
+    assert relerr(dgam, gd.grad) < 2e-6 and relerr(dbet, bd.grad) < 2e-6
+    buf = dy.clone()
+    ops.layernorm_bwd(buf, x, g, mean, rstd, buf, dgam, dbet, ws)    # in place
+    assert relerr(buf, xd.grad) < 2e-6
+
+
+@pytest.mark.parametrize('nseq,S,nh,masked', [(3, 16, 2, True), (2, 31, 2, False), (2, 241, 3, False), (2, 200, 2, True)])
+def test_f32_attention_bwd(dev, nseq, S, nh, masked):
+    """dQ, dK, dV (with the "rotary" scaling of dq / dk undone) against fp64 autograd of the reference's attention, PAD query rows included:
+    their scores are all -1e10, the softmax is uniform over the S keys, their dO flows into dV and -- autodiff does not know about the rounding --
+    their dS into dq and dk (modeling.py:343-358)."""
+    from merlot_reserve_amd import ops
+    H = nh * 64
+    qkv = rnd((nseq * S, 3 * H), dev, seed=S)
+    dout = rnd((nseq * S, H), dev, seed=S + 1)
+    code = None
+    if masked:
+        gen = torch.Generator().manual_seed(S)
+        code = torch.randint(0, 3, (nseq * S,), generator=gen, dtype=torch.int32)
+        code[torch.rand(nseq * S, generator=gen) < 0.15] = -1
+        code = code.to(dev)
+    out = torch.zeros(nseq * S, H, dtype=F32, device=dev)
+    lse = torch.zeros(nseq, nh, S, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
+    delta = torch.zeros(nseq * nh * S, device=dev)
+    dqkv = torch.full_like(qkv, float('nan'))
+    ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+    x = qkv.double().requires_grad_(True)
+    xv = x.view(nseq, S, 3, nh, 64)
+    sc = torch.einsum('bqhd,bkhd->bhqk', xv[:, :, 0] / 8.0, xv[:, :, 1])
+    if code is not None:
+        c = code.view(nseq, S)
+        allowed = (c[:, :, None] == c[:, None, :]) & (c[:, :, None] >= 0)
+        sc = sc + torch.where(allowed, 0.0, -1e10)[:, None].double()
+        pad_q = (c < 0)[:, None, :, None]
+        # a PAD query's scores all ROUND to -1e10 in fp32 (|q.k / 8| is far below the 1024 ulp): a uniform softmax in the forward -- but the
+        # reference's autodiff still sees s = raw + bias, ds / draw = 1, so dS = P (dP - delta) of those rows flows into dq and dk: value 0, slope 1
+        sc = torch.where(pad_q, sc - sc.detach(), sc)
+    o = torch.einsum('bhqk,bkhd->bqhd', torch.softmax(sc, -1), xv[:, :, 2]).reshape(nseq * S, H)
+    o.backward(dout.double())
+    assert relerr(dqkv, x.grad) < 2e-5, relerr(dqkv, x.grad)
+
+
+def test_f32_pool_rows_unitnorm_bwd(dev):
+    from merlot_reserve_amd import ops
+    H, nh = 128, 2
+    q, k, v = rnd((2, H), dev, seed=3), rnd((50, H), dev, seed=4), rnd((50, H), dev, seed=5)
+    rows = torch.tensor([[0, 1, 2, 3], [10, 11, 12, 13]], dtype=torch.int32, device=dev)
+    do = rnd((2, H), dev, seed=6)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    outs = []
+    for gi in range(2):
+        kk, vv = kd[rows[gi].long()].view(4, nh, 64), vd[rows[gi].long()].view(4, nh, 64)
+        s = torch.einsum('hd,rhd->hr', qd[gi].view(nh, 64) / 8.0, kk)
+        outs.append(torch.einsum('hr,rhd->hd', torch.softmax(s, -1), vv).reshape(H))
+    torch.stack(outs).backward(do.double())
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.poolattn_bwd(q, k, v, rows, None, do, dq, dk, dv, nh)
+    assert relerr(dq, qd.grad) < 1e-5 and relerr(dk, kd.grad) < 1e-5 and relerr(dv, vd.grad) < 1e-5
+    # rows_mean backward: every row of a group gets ddst / R
+    dsrc = torch.zeros(50, H, device=dev)
+    ops.rows_mean_bwd(do, rows, dsrc)
+    want = torch.zeros(50, H, dtype=F64, device=dev)
+    for gi in range(2):
+        want[rows[gi].long()] += do[gi].double() / 4
+    assert relerr(dsrc, want) < 1e-6
+    # unit_normalize * temperature backward, dx and the temperature's gradient (clipped and not)
+    x, dy = rnd((37, H), dev, seed=7), rnd((37, H), dev, seed=8)
+    for lsv in (0.3, 5.0):
+        ls = torch.tensor([lsv], device=dev)
+        xd, lsd = x.double().requires_grad_(True), ls.double().requires_grad_(True)
+        y = xd / torch.sqrt((xd ** 2).sum(-1, keepdim=True) + 1e-5) * torch.exp(torch.clamp(lsd, max=math.log(100.0)) / 2)
+        y.backward(dy.double())
+        dx, dls, part = torch.zeros_like(x), torch.zeros(1, device=dev), torch.zeros(64, device=dev)
+        ops.unit_norm_scale_bwd(x, ls, None, dy, dx, dls, part)
+        assert relerr(dx, xd.grad) < 2e-6
+        assert abs(float(dls) - float(lsd.grad)) <= 2e-6 * max(1.0, abs(float(lsd.grad))), (float(dls), float(lsd.grad))
+    # strided row sums (the CLS parameter's gradient) and the column sums (bias gradients)
+    z = rnd((3 * 5, H), dev, seed=9)
+    o = torch.zeros(H, device=dev)
+    ops.sum_rows_strided(z, 3, 5, 0, o)
+    assert relerr(o, z.double().view(3, 5, H)[:, 0].sum(0)) < 1e-6
+    cs = torch.zeros(H, device=dev)
+    ops.colsum(z, cs, None)
+    assert relerr(cs, z.double().sum(0)) < 1e-6
