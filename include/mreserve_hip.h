@@ -297,7 +297,8 @@ int mr_transpose_leaves(const void* work_bf16, void* workT_bf16, const int32_t* 
                         int32_t tile_hi, void* stream);
 
 /* ---- fp32 forward path (use_bfloat16 = false: M:594; every zero-shot / feature caller runs fp32, M:999-1000) ----
- * Same operations as above with fp32 storage and fp32 arithmetic (v_mfma_f32_16x16x4_f32 / fp32 VALU), forward only.
+ * Same operations as above with fp32 storage and fp32 arithmetic (v_mfma_f32_16x16x4_f32 / fp32 VALU): the forward; the backward entry points
+ * (mr_f32_*_bwd, round 4) follow below.
  * Leading dims and H must be multiples of 4 (16-byte vectors) except mr_f32_gemm's lda / ldb (unaligned operands take a
  * scalar-load path). */
 /* mr_gemm_args with A, B, C, bias, residual = fp32; c_dtype must be MR_DT_F32; c2 / aux / workspace unused (NULL).

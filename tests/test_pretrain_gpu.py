@@ -223,7 +223,7 @@ def test_fp32_forward_parity_1e3(dev, hidden_size, B):
         assert abs(li[k] - float(info[k])) <= 1e-3 * abs(float(info[k])), (k, li[k], float(info[k]))
     assert abs(li['loss'] - float(loss)) <= 1e-3 * abs(float(loss))
     with pytest.raises(AssertionError):
-        eng.backward()                                      # the fp32 program is forward-only
+        eng.backward()                                      # built without train=True: forward + loss only
 
 
 def test_training_reduces_the_contrastive_loss(dev):
