@@ -1,0 +1,80 @@
+"""Minimal reproducer attempt for the packed-fp32 LayerNorm hazard of DESIGN.md section 4 (round 3: a few LayerNorm rows per launch off by 1-7 bf16 ulp,
+only while a second queue's kernels shared the chip, only in the SLP-vectorised build of layernorm.hip).
+    bash scripts/build_diag.sh slp layernorm                      # layernorm.hip WITHOUT -fno-slp-vectorize -> merlot_reserve_amd/libdiag_slp.so
+    MR_LIB=merlot_reserve_amd/libdiag_slp.so python scripts/slp_repro.py     # packed build
+    python scripts/slp_repro.py                                              # shipped (scalar) build
+ln_fwd / ln_bwd of the base step's shape on stream A, launched REPS times while stream B runs a loop of the step's big GEMMs (persistent whole-CU
+workgroups), attention and Adam-like streaming kernels; every output is compared bit for bit with the same launch made alone on an idle GPU."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from merlot_reserve_amd import ops
+dev = torch.device('cuda:0')
+BF16 = torch.bfloat16
+rows, H = 15424, 768
+g = torch.Generator().manual_seed(0)
+x = (torch.randn(rows, H, generator=g) * 2 + 0.3).to(BF16).to(dev)
+gam, bet = (torch.randn(H, generator=g) * 0.2 + 1).to(BF16).to(dev), (torch.randn(H, generator=g) * 0.1).to(BF16).to(dev)
+dy, add = torch.randn(rows, H, generator=g).to(BF16).to(dev), torch.randn(rows, H, generator=g).to(BF16).to(dev)
+mean, rstd = torch.zeros(rows, device=dev), torch.zeros(rows, device=dev)
+y_ref, dx_ref = torch.zeros_like(x), torch.zeros_like(x)
+dg, db = torch.zeros(H, dtype=BF16, device=dev), torch.zeros(H, dtype=BF16, device=dev)
+ws = ops.layernorm_bwd_workspace(H, dev)
+ops.layernorm_fwd(x, gam, bet, y_ref, mean, rstd)
+ops.layernorm_bwd(dy, x, gam, mean, rstd, dx_ref, dg, db, ws, dx_add=add)
+ytmp, mean2, rstd2 = torch.zeros_like(x), torch.zeros(rows, device=dev), torch.zeros(rows, device=dev)
+if os.environ.get('CHAIN') == '1':
+    ops.layernorm_fwd(x, gam, bet, ytmp, mean, rstd)
+    ops.layernorm_fwd(ytmp, gam, bet, y_ref, mean2, rstd2)
+torch.cuda.synchronize()
+# the neighbour: GEMMs of the step's shapes, an attention forward, a streaming elementwise kernel, in a loop on stream B
+a = torch.randn(5952, 768, generator=g).to(BF16).to(dev)
+w1, w2 = (torch.randn(3072, 768, generator=g) * 0.05).to(BF16).to(dev), (torch.randn(768, 3072, generator=g) * 0.05).to(BF16).to(dev)
+h, o2 = torch.zeros(5952, 3072, dtype=BF16, device=dev), torch.zeros(5952, 768, dtype=BF16, device=dev)
+qkv = torch.randn(192 * 31, 2304, generator=g).to(BF16).to(dev)
+ao, lse = torch.zeros(192 * 31, 768, dtype=BF16, device=dev), torch.zeros(192, 12, 31, device=dev)
+big = torch.zeros(64 * 1024 * 1024, dtype=BF16, device=dev)
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+REPS = int(os.environ.get('REPS', '60'))
+NL = 16                                        # LayerNorm launches per repetition, each into its own buffer, all beside stream B's loop
+ys, dxs = [torch.zeros_like(x) for _ in range(NL)], [torch.zeros_like(x) for _ in range(NL)]
+mode = os.environ.get('NEIGHBOUR', 'mix')      # mix | attn | stream | gemm | ln : what stream B runs
+bad_f = bad_b = rows_f = rows_b = 0
+first = None
+datt = torch.randn(192 * 31, 768, generator=g).to(BF16).to(dev)
+xa = torch.randn(5952, H, generator=g).to(BF16).to(dev)
+ya, xa2 = torch.zeros_like(xa), torch.zeros_like(xa)
+mean_a, rstd_a = torch.zeros(5952, device=dev), torch.zeros(5952, device=dev)
+dq, dl = torch.zeros_like(qkv), torch.zeros(192 * 12 * 31, device=dev)
+for rep in range(REPS):
+    with torch.cuda.stream(sb):
+        for _ in range(12):
+            if mode in ('mix', 'gemm'):
+                ops.gemm(a, w1, h, transB=True)
+            if mode in ('mix', 'attn'):
+                ops.attention_fwd(qkv, None, ao, lse, 192, 31, 12)
+                ops.attention_bwd(qkv, None, ao, datt, lse, dl, dq, None, 192, 31, 12)
+            if mode in ('mix', 'stream'):
+                big.add_(1.0)
+            if mode in ('mix', 'ln'):            # another LayerNorm launch (the audio tower's rows) -- the same kernel from a second queue
+                ops.layernorm_fwd(xa, gam, bet, ya, mean_a, rstd_a)
+                ops.layernorm_fwd(ya, gam, bet, xa2, mean_a, rstd_a)
+    with torch.cuda.stream(sa):
+        for i in range(NL):
+            if os.environ.get('CHAIN') == '1':           # the step's opening: pre_ln then layer 0's ln1, back to back (the second reads what the first wrote)
+                ops.layernorm_fwd(x, gam, bet, ytmp, mean, rstd)
+                ops.layernorm_fwd(ytmp, gam, bet, ys[i], mean2, rstd2)
+                continue
+            ops.layernorm_fwd(x, gam, bet, ys[i], mean, rstd)
+            ops.layernorm_bwd(dy, x, gam, mean, rstd, dxs[i], dg, db, ws, dx_add=add)
+    torch.cuda.synchronize()
+    for i in range(NL):
+        df, dbw = (ys[i] != y_ref).any(1), (dxs[i] != dx_ref).any(1)
+        if bool(df.any()):
+            bad_f += 1; rows_f += int(df.sum())
+            if first is None:
+                r = int(df.nonzero()[0]); c = (ys[i][r] != y_ref[r]).nonzero().flatten().tolist()
+                first = f'ln_fwd row {r} cols {c[:8]}: got {ys[i][r, c[0]].item()} want {y_ref[r, c[0]].item()} input x {x[r, c[0]].item()}'
+        if bool(dbw.any()):
+            bad_b += 1; rows_b += int(dbw.sum())
+print(f'library {os.environ.get("MR_LIB", "shipped")}, neighbour {mode}: {REPS * NL} launches beside a busy second stream -- ln_fwd differed from the lone launch in '
+      f'{bad_f} launches ({rows_f} rows in all), ln_bwd in {bad_b} ({rows_b} rows)' + (f'; first: {first}' if first else ''), flush=True)
