@@ -37,11 +37,13 @@ sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 REPS = int(os.environ.get('REPS', '60'))
 NL = 16                                        # LayerNorm launches per repetition, each into its own buffer, all beside stream B's loop
 ys, dxs = [torch.zeros_like(x) for _ in range(NL)], [torch.zeros_like(x) for _ in range(NL)]
-mode = os.environ.get('NEIGHBOUR', 'mix')      # mix | attn | stream | gemm | ln : what stream B runs
+mode = os.environ.get('NEIGHBOUR', 'mix')      # mix | attn | stream | gemm | ln | smallgemm : what stream B runs
 bad_f = bad_b = rows_f = rows_b = 0
 first = None
 datt = torch.randn(192 * 31, 768, generator=g).to(BF16).to(dev)
 xa = torch.randn(5952, H, generator=g).to(BF16).to(dev)
+emb_in, emb_w, emb_out = torch.randn(5760, 136, generator=g).to(BF16).to(dev), (torch.randn(136, 768, generator=g) * 0.1).to(BF16).to(dev), torch.zeros(5760, 768, dtype=BF16, device=dev)
+sm_a, sm_o = torch.randn(192, 768, generator=g).to(BF16).to(dev), torch.zeros(192, 768, dtype=BF16, device=dev)
 ya, xa2 = torch.zeros_like(xa), torch.zeros_like(xa)
 mean_a, rstd_a = torch.zeros(5952, device=dev), torch.zeros(5952, device=dev)
 dq, dl = torch.zeros_like(qkv), torch.zeros(192 * 12 * 31, device=dev)
@@ -55,6 +57,10 @@ for rep in range(REPS):
                 ops.attention_bwd(qkv, None, ao, datt, lse, dl, dq, None, 192, 31, 12)
             if mode in ('mix', 'stream'):
                 big.add_(1.0)
+            if mode in ('mix', 'smallgemm'):     # the 128 x 128 MFMA kernel (few small workgroups: they share CUs -- and SIMDs -- with the LayerNorm waves)
+                for _ in range(4):
+                    ops.gemm(emb_in, emb_w, emb_out)
+                    ops.gemm(sm_a, w2[:, :768], sm_o, transB=True)
             if mode in ('mix', 'ln'):            # another LayerNorm launch (the audio tower's rows) -- the same kernel from a second queue
                 ops.layernorm_fwd(xa, gam, bet, ya, mean_a, rstd_a)
                 ops.layernorm_fwd(ya, gam, bet, xa2, mean_a, rstd_a)
@@ -74,7 +80,7 @@ for rep in range(REPS):
             if first is None:
                 r = int(df.nonzero()[0]); c = (ys[i][r] != y_ref[r]).nonzero().flatten().tolist()
                 first = f'ln_fwd row {r} cols {c[:8]}: got {ys[i][r, c[0]].item()} want {y_ref[r, c[0]].item()} input x {x[r, c[0]].item()}'
-        if bool(dbw.any()):
+        if bool(dbw.any()) and os.environ.get('CHAIN') != '1':       # (chained mode overwrites the statistics ln_bwd reads: not compared)
             bad_b += 1; rows_b += int(dbw.sum())
 print(f'library {os.environ.get("MR_LIB", "shipped")}, neighbour {mode}: {REPS * NL} launches beside a busy second stream -- ln_fwd differed from the lone launch in '
       f'{bad_f} launches ({rows_f} rows in all), ln_bwd in {bad_b} ({rows_b} rows)' + (f'; first: {first}' if first else ''), flush=True)
