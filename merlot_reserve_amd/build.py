@@ -21,6 +21,12 @@ LIB = os.path.join(HERE, 'libmreserve_hip.so')
 # scalar as well; the bf16 GEMM files keep their packed epilogues (3.2 ms of the step) and are held to bit-stability under that neighbour by the test.
 EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'layernorm.hip': ['-fno-slp-vectorize'], 'rowops.hip': ['-fno-slp-vectorize'],
                'adam.hip': ['-fno-slp-vectorize', '-ffp-contract=off'], 'f32bwd.hip': ['-fno-slp-vectorize'], 'f32path.hip': ['-fno-slp-vectorize']}
+# The hazard at instruction level (scripts/micro/pk_probe.hip, scripts/pk_probe.py): v_pk_add_f32 / v_pk_fma_f32 (any packed fp32 arithmetic) with an
+# `op_sel:[..1..]` source -- the LOW result element reading the HIGH register of a source pair -- returns wrong values in lanes 48-63 of a wave
+# while another kernel's MFMA waves are resident on its SIMD (0 mismatches alone; op_sel_hi, neg_lo / neg_hi, v_pk_mov_b32 op_sel are unaffected).
+# The files that keep the SLP pass are therefore SCANNED: build() also emits their device assembly and fails if such an instruction appears.
+SLP_FILES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip']
+HAZARD_RE = r'^\s*v_pk_(add|mul|fma|min|max)_f32\b.*\bop_sel:\['
 SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'f32bwd.hip', 'mr_error.cpp', 'comm.cpp']
 
 
@@ -30,6 +36,21 @@ def _needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'mreserve_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def scan_packed_op_sel():
+    """[(file, count, example)] of hazardous packed-fp32 instructions in the device assembly build() left under build/ (see HAZARD_RE)."""
+    import re
+    out = []
+    rx = re.compile(HAZARD_RE, re.M)
+    for src in SLP_FILES:
+        asm = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.s')
+        if not os.path.exists(asm):
+            raise FileNotFoundError(f'{asm}: run merlot_reserve_amd.build.build(force=True)')
+        hits = [m.group(0).strip() for m in rx.finditer(open(asm).read())]
+        if hits:
+            out.append((src, len(hits), hits[0]))
+    return out
 
 
 def build(force=False, verbose=True):
@@ -47,10 +68,23 @@ def build(force=False, verbose=True):
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + debug + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
+    asm_procs = []
+    for src in SLP_FILES:             # device assembly of the packed-code files, for the hazard scan (same flags as the object)
+        asm = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.s')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + debug + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '--cuda-device-only', '-S', os.path.join(CSRC, src), '-o', asm]
+        asm_procs.append((src, asm, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
+    for src, asm, p in asm_procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc -S failed on {src}:\n{out.decode()}')
+    bad = scan_packed_op_sel()
+    if bad:
+        raise RuntimeError('packed fp32 instructions with an op_sel source (wrong in lanes 48-63 beside MFMA waves, see build.py) in:\n' +
+                           '\n'.join(f'{f}: {n} e.g. {ex}' for f, n, ex in bad) + '\ncompile that file with -fno-slp-vectorize or restructure the code')
     # -z defs: an undefined kernel stub (a template the host pass silently failed to emit) fails the build instead of the first launch
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
