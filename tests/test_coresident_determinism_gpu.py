@@ -114,3 +114,46 @@ def test_gemm_epilogues_beside_mfma_waves(dev, kernel):
         for k, v in prev.items():
             ops.set_option(k, v)
         ops.set_option('gemm_trace', 0)
+
+
+def test_attention_and_row_kernels_beside_mfma_waves(dev):
+    """The kernels whose small workgroups share CUs with other queues in the real step -- short-sequence attention forward / backward, attention pooling,
+    gathers, unit-norm, the fused Adam -- each against its lone launch under the same neighbour."""
+    from merlot_reserve_amd import ops
+    g = torch.Generator().manual_seed(2)
+    nseq, S, nh = 192, 31, 12
+    H = nh * 64
+    qkv = torch.randn(nseq * S, 3 * H, generator=g).to(BF16).to(dev)
+    dout = torch.randn(nseq * S, H, generator=g).to(BF16).to(dev)
+    tab = (torch.rand(S, 32, generator=g) * 2 - 1).to(dev)
+    Gp = nseq * 6
+    rows = (torch.arange(nseq)[:, None, None] * S + 1 + torch.arange(6)[None, :, None] * 5 + torch.arange(5)[None, None]).reshape(Gp, 5).to(torch.int32).to(dev)
+    q = torch.randn(Gp, H, generator=g).to(BF16).to(dev)
+    idxp = torch.arange(0, nseq * S + 1, dtype=torch.int32, device=dev)
+    idx = torch.randperm(nseq * S, generator=g).to(torch.int32).to(dev)
+    npar = 8 * 2048 * 64
+    master0 = torch.randn(npar, generator=g).to(dev)
+    grad = (torch.randn(npar, generator=g) * 1e-2).to(BF16).to(dev)
+    flags = torch.ones(npar // 2048, dtype=torch.uint8, device=dev)
+    hyper = torch.tensor([1.0, -1e-3, 1.0, 1.0], device=dev)
+    n = 8
+
+    def bufs():
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        f = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        return dict(out=z(nseq * S, H), lse=f(nseq * nh * S), delta=f(nseq * nh * S), dqkv=z(nseq * S, 3 * H), po=z(Gp, H), probs=f(Gp, nh, 5),
+                    gath=z(nseq * S, H), un=z(nseq * S, H), inv=f(nseq * S), master=master0.clone(), work=z(npar), mu=z(npar), nu=z(npar))
+    B = [bufs() for _ in range(n)]
+    ls = torch.tensor([0.3], dtype=BF16, device=dev)
+
+    def launch(i):
+        b = B[i]
+        ops.attention_fwd(qkv, None, b['out'], b['lse'], nseq, S, nh)
+        ops.attention_bwd(qkv, None, b['out'], dout, b['lse'], b['delta'], b['dqkv'], tab, nseq, S, nh)
+        ops.poolattn_fwd(q, qkv[:, H:2 * H], qkv[:, 2 * H:], rows, b['po'], b['probs'], nh)
+        ops.segment_sum([dout], idxp, idx, b['gath'])
+        ops.unit_norm_scale_fwd(dout, ls, b['un'], b['inv'])
+        b['master'].copy_(master0); b['mu'].zero_(); b['nu'].zero_()
+        ops.adam_bf16_update_dev(b['master'], b['work'], grad, b['mu'], b['nu'], None, flags, 0.9, 0.98, 1e-6, 0.1, hyper)
+    outs = [tuple(B[i][k] for k in ('out', 'lse', 'dqkv', 'po', 'probs', 'gath', 'un', 'inv', 'master', 'work', 'mu', 'nu')) for i in range(n)]
+    assert _hold(dev, launch, outs, reps=8) == 0
