@@ -24,27 +24,69 @@ EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'layernorm.hip': ['-fno-
 # The hazard at instruction level (scripts/micro/pk_probe.hip, scripts/pk_probe.py): v_pk_add_f32 / v_pk_fma_f32 (any packed fp32 arithmetic) with an
 # `op_sel:[..1..]` source -- the LOW result element reading the HIGH register of a source pair -- returns wrong values in lanes 48-63 of a wave
 # while another kernel's MFMA waves are resident on its SIMD (0 mismatches alone; op_sel_hi, neg_lo / neg_hi, v_pk_mov_b32 op_sel are unaffected).
-# The files that keep the SLP pass are therefore SCANNED: build() also emits their device assembly and fails if such an instruction appears.
-SLP_FILES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip']
+# EVERY .hip file is scanned (round 5: the files built without the SLP pass still contain packed fp32 arithmetic from explicit vector
+# expressions -- attention.hip 272 instructions -- so "built scalar" alone does not exclude the form): the device assembly of each
+# object is kept under build/ (a by-product of the object's own compile, --save-temps) and build() fails if such an instruction appears.
+SLP_FILES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip']        # the files that keep the SLP vectoriser (packed epilogues)
 HAZARD_RE = r'^\s*v_pk_(add|mul|fma|min|max)_f32\b.*\bop_sel:\['
 SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'f32bwd.hip', 'mr_error.cpp', 'comm.cpp']
+HIP_FILES = [f for f in SOURCES if f.endswith('.hip')]
+# Register spills (metadata .vgpr_spill_count / .sgpr_spill_count of every kernel in the device assembly): a spill inside a k-loop costs more than any
+# schedule gains (gemm4<256,0> with 183 spilled registers: 299 vs 91 us), so build() FAILS on a kernel with spilled vector registers unless it is
+# listed here with the number it is known to carry and the reason it is tolerated.  {regex on the demangled-ish symbol: (max spilled VGPRs, why)}
+# Round 5 state (scripts/spill_sites.py prints, per kernel, the basic blocks with scratch traffic and whether they lie in the k-loop; its output is
+# committed as profiles/r05_spill_sites.txt): removed -- gemm4<256,0> (183, reloads in the k-loop: the 256-wide bias mode stays on the ping-pong
+# kernel), gemm3<256,4,1> (20, one reload in the k-loop's MFMA block: that mode always runs two-phase), gemm_bf16_kernel / gemm_bf16_grouped_kernel
+# (22-42: address arithmetic hoisted over the epilogue's staging loop, now pinned behind an opaque move).  Tolerated, all COLD (per-tile epilogue /
+# item-switch / prologue code of persistent kernels; `hot_spill_blocks()` = scratch instructions in a basic block that also holds MFMAs, which
+# tests/test_build_isa_guard.py holds to the three kernels marked HOT below):
+SPILL_ALLOWED = {
+    r'gemm4_kernelILi256ELi[35]E': (5, 'epilogue: two row-offset registers and three fragment registers of the next tile held across the store section; k-loop block clean'),
+    r'gemm256_kernelILi256E': (24, 'DMA source offsets of the tile pieces, reloaded in the per-item setup (also where the cursor switches items inside the unrolled k-loop, under its uniform branch) and epilogue prefetch registers; no MFMA block touches scratch'),
+    r'gemm256_kernelILi192E': (5, 'as the 256-wide instance'),
+    r'gemm5_kernelILi[012]ELi4ELi256ELi3E': (11, 'per-tile item decode + epilogue offsets of the two-per-CU geometry (<= 128 registers per wave by design); no MFMA block touches scratch'),
+    r'gemm5_kernelILi4ELi4ELi256ELi3E': (20, 'HOT (4 stores in an MFMA block).  aux mode of the two-per-CU geometry: NOT dispatched by the default policy (aux arrives with column sums, which it refuses); option gemm5=1 only'),
+    r'attn_bwd_dq_kernelILi2ELb1E': (14, 'HOT (3 reloads in an MFMA block).  held to three waves per SIMD on purpose: 168 registers + 14 spilled is faster than 184 at two waves (joint backward 181 -> 175 us, round 2)'),
+    r'attn_bwd1_kernelILb1E': (3, 'HOT (1 store in an MFMA block, outside the tile loop).  masked one-pass backward (no stock tower routes to it)'),
+}
+STAMP = os.path.join(HERE, 'build', 'flags.txt')
+JOBS = max(1, min(8, (os.cpu_count() or 2)))
+
+
+def _flag_stamp():
+    """What the objects under build/ were compiled with: a rebuild is needed when it differs (e.g. MR_DEBUG_ENV toggled), not only when a source is newer."""
+    debug = os.environ.get('MR_DEBUG_ENV') == '1'
+    return 'debug_env=%d\n' % debug + ''.join(f'{k}: {" ".join(v)}\n' for k, v in sorted(EXTRA_FLAGS.items()))
+
+
+def _asm_path(src):
+    return os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.s')
 
 
 def _needs_build():
     if not os.path.exists(LIB):
+        return True
+    if not os.path.exists(STAMP):
+        # a library that travelled without its build/ directory (the GPU box's snapshot carries both; a bare copy does not): trust the mtimes
+        pass
+    elif open(STAMP).read() != _flag_stamp():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'mreserve_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def scan_packed_op_sel():
-    """[(file, count, example)] of hazardous packed-fp32 instructions in the device assembly build() left under build/ (see HAZARD_RE)."""
+def _asm_stale():
+    return any(not os.path.exists(_asm_path(f)) or os.path.getmtime(_asm_path(f)) < os.path.getmtime(os.path.join(CSRC, f)) for f in HIP_FILES)
+
+
+def scan_packed_op_sel(files=None):
+    """[(file, count, example)] of hazardous packed-fp32 instructions in the device assembly build() left under build/ (see HAZARD_RE), every .hip file."""
     import re
     out = []
     rx = re.compile(HAZARD_RE, re.M)
-    for src in SLP_FILES:
-        asm = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.s')
+    for src in (files or HIP_FILES):
+        asm = _asm_path(src)
         if not os.path.exists(asm):
             raise FileNotFoundError(f'{asm}: run merlot_reserve_amd.build.build(force=True)')
         hits = [m.group(0).strip() for m in rx.finditer(open(asm).read())]
@@ -53,41 +95,132 @@ def scan_packed_op_sel():
     return out
 
 
+def kernel_resources(files=None):
+    """{file: {kernel symbol: {'vgpr', 'agpr', 'sgpr', 'vgpr_spill', 'sgpr_spill', 'lds', 'scratch'}}} from the amdhsa.kernels metadata of the device assembly."""
+    import re
+    res = {}
+    key = {'.vgpr_count': 'vgpr', '.agpr_count': 'agpr', '.sgpr_count': 'sgpr', '.vgpr_spill_count': 'vgpr_spill', '.sgpr_spill_count': 'sgpr_spill',
+           '.group_segment_fixed_size': 'lds', '.private_segment_fixed_size': 'scratch'}
+    for src in (files or HIP_FILES):
+        text = open(_asm_path(src)).read()
+        i = text.find('amdhsa.kernels:')
+        if i < 0:
+            res[src] = {}
+            continue
+        j = text.find('amdhsa.target:', i)
+        ks = {}
+        for block in re.split(r'\n  - ', text[i:j if j > 0 else len(text)])[1:]:
+            ent = {}
+            name = None
+            for line in block.splitlines():
+                m = re.match(r'\s*(\.[a-z_]+):\s*(\S+)\s*$', line)
+                if not m:
+                    continue
+                if m.group(1) == '.name':
+                    name = m.group(2).strip("'\"")
+                elif m.group(1) in key:
+                    ent[key[m.group(1)]] = int(m.group(2))
+            if name:
+                ks[name] = ent
+        res[src] = ks
+    return res
+
+
+def hot_spill_blocks(files=None):
+    """[(file, kernel, block label, MFMAs, scratch stores, scratch loads)]: basic blocks of the device assembly that hold both MFMAs and scratch traffic."""
+    import re
+    out = []
+    for src in (files or HIP_FILES):
+        name, blk = None, None
+        for line in open(_asm_path(src)):
+            m = re.match(r'^(_Z\w+):', line)
+            if m:
+                name, blk = m.group(1), ['<entry>', 0, 0, 0]
+                continue
+            if name is None:
+                continue
+            if line.startswith('.Lfunc_end') or re.match(r'^\.LBB\d+_\d+:', line):
+                if blk[1] and (blk[2] or blk[3]):
+                    out.append((src, name, *blk))
+                blk = [line.split(':')[0], 0, 0, 0]
+                if line.startswith('.Lfunc_end'):
+                    name = None
+                continue
+            t = line.strip()
+            if t.startswith('v_mfma'):
+                blk[1] += 1
+            elif t.startswith('scratch_store'):
+                blk[2] += 1
+            elif t.startswith('scratch_load'):
+                blk[3] += 1
+    return out
+
+
+def scan_spills(files=None):
+    """[(file, kernel, spilled VGPRs)] of kernels with spilled vector registers that SPILL_ALLOWED does not cover."""
+    import re
+    bad = []
+    for src, ks in kernel_resources(files).items():
+        for name, ent in ks.items():
+            n = ent.get('vgpr_spill', 0)
+            if n <= 0:
+                continue
+            cap = max([c for rx, (c, _why) in SPILL_ALLOWED.items() if re.search(rx, name)], default=0)
+            if n > cap:
+                bad.append((src, name, n))
+    return bad
+
+
 def build(force=False, verbose=True):
     if not force and not _needs_build():
         return LIB
+    import json
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # MR_DEBUG_ENV=1: a DEBUG build whose kernels' dispatch reads the experiment scripts' environment knobs (MR_GEMM3, MR_G3_PH, ...:
     # csrc/mr_options.h mr_env_int); the product build ignores the environment
     debug = ['-DMR_DEBUG_ENV'] if os.environ.get('MR_DEBUG_ENV') == '1' else []
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    bdir = os.path.join(HERE, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    objs, queue, running, failed = [], [], [], []
     for src in SOURCES:
-        obj = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.o')
+        stem = src.rsplit('.', 1)[0]
+        obj = os.path.join(bdir, stem + '.o')
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + debug + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        if src.endswith('.hip'):
+            cmd.append('--save-temps=obj')          # leaves <stem>-hip-amdgcn-amd-amdhsa-gfx950.s: the device assembly OF THIS OBJECT, for the scans
+        queue.append((src, cmd))
         objs.append(obj)
-    asm_procs = []
-    for src in SLP_FILES:             # device assembly of the packed-code files, for the hazard scan (same flags as the object)
-        asm = os.path.join(HERE, 'build', src.rsplit('.', 1)[0] + '.s')
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17'] + debug + EXTRA_FLAGS.get(src, []) + ['-x', 'hip', '--cuda-device-only', '-S', os.path.join(CSRC, src), '-o', asm]
-        asm_procs.append((src, asm, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+    while queue or running:
+        while queue and len(running) < JOBS:
+            src, cmd = queue.pop(0)
+            running.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=bdir)))
+        src, p = running.pop(0)
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
-    for src, asm, p in asm_procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError(f'hipcc -S failed on {src}:\n{out.decode()}')
+            failed.append(f'hipcc failed on {src}:\n{out.decode()}')
+    if failed:
+        raise RuntimeError('\n'.join(failed))
+    for src in HIP_FILES:
+        stem = src.rsplit('.', 1)[0]
+        os.replace(os.path.join(bdir, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'), _asm_path(src))
+        for f in os.listdir(bdir):                  # the other intermediates (preprocessed sources, bitcode, host assembly) are not needed
+            if f.startswith(stem + '-h') or f.startswith(stem + '.hip-hip-'):
+                os.remove(os.path.join(bdir, f))
     bad = scan_packed_op_sel()
     if bad:
         raise RuntimeError('packed fp32 instructions with an op_sel source (wrong in lanes 48-63 beside MFMA waves, see build.py) in:\n' +
-                           '\n'.join(f'{f}: {n} e.g. {ex}' for f, n, ex in bad) + '\ncompile that file with -fno-slp-vectorize or restructure the code')
+                           '\n'.join(f'{f}: {n} e.g. {ex}' for f, n, ex in bad) + '\nrestructure the code (SLP files: or compile with -fno-slp-vectorize)')
+    with open(os.path.join(bdir, 'resources.json'), 'w') as f:
+        json.dump(kernel_resources(), f, indent=1, sort_keys=True)
+    spills = scan_spills()
+    if spills:
+        raise RuntimeError('kernels with spilled vector registers (build.py SPILL_ALLOWED lists the tolerated ones):\n' +
+                           '\n'.join(f'{f}: {k}: {n} VGPRs' for f, k, n in spills))
     # -z defs: an undefined kernel stub (a template the host pass silently failed to emit) fails the build instead of the first launch
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(_flag_stamp())
     if verbose:
         print(f'built {LIB}', file=sys.stderr)
     return LIB

@@ -188,14 +188,17 @@ __device__ __forceinline__ void gemm_bf16_tile(const mr_gemm_args& p, __bf16* sm
 
     if (p.c_dtype == MR_DT_F32) {
         float* C = static_cast<float*>(p.C);
+        int li_here, g_here;              // (opaque copies: keeps this path's address arithmetic out of the common path, see phase 2 below)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(li_here) : "v"(li));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(g_here) : "v"(g));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t n = n0 + wn * 64 + j * 16 + li;
+                const int64_t n = n0 + wn * 64 + j * 16 + li_here;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t m = m0 + wm * 64 + i * 16 + g * 4 + r;
+                    const int64_t m = m0 + wm * 64 + i * 16 + g_here * 4 + r;
                     if (m < p.M && n < p.N) C[m * p.ldc + n] = acc[i][j][r];
                 }
             }
@@ -225,9 +228,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const mr_gemm_args& p, __bf16* sm
         __bf16* Cout = static_cast<__bf16*>(final_pass ? p.C : p.c2);
         const __bf16* R = final_pass ? static_cast<const __bf16*>(p.residual) : nullptr;
         const __bf16* X = final_pass ? static_cast<const __bf16*>(p.aux) : nullptr;
+        // the row / column / address arithmetic below depends only on the thread and the arguments, so the optimiser computed all of it ahead of the
+        // staging loop above and spilled it across that loop (22-42 registers): an opaque zero added to the thread index pins it here
+        int tid_here;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(tid_here) : "v"(tid));
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int c = tid + 256 * it;
+            const int c = tid_here + 256 * it;
             const int row = c >> 4, ch = c & 15;
             const int64_t gm = m0 + row, gn = n0 + 8 * ch;
             if (gm < p.M && gn < p.N) {

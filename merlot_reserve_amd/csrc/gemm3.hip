@@ -704,7 +704,9 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
         static int g4_env = -1;
         if (g4_env < 0) g4_env = mr_env_int("MR_GEMM4", 1);
         const int g4 = g_mr_opt_gemm4 >= 0 ? g_mr_opt_gemm4 : g4_env;
-        if (g4 && mr_gemm4_takes(a)) return mr_gemm4_launch(a, bn, ga, gsz, s);
+        // (not the 256-wide bias mode: 256 accumulators + the bias rows overflow the wave's 512 registers -- 183 spilled, reloads inside
+        // the k-loop, 299 vs 91 us -- so that combination stays on the ping-pong kernel and gemm4<256,0> is not instantiated)
+        if (g4 && mr_gemm4_takes(a) && !(bn == 256 && a->bias && !a->residual)) return mr_gemm4_launch(a, bn, ga, gsz, s);
     }
     dim3 grid((unsigned)gsz), block(512);
     int mode = 0;
@@ -718,11 +720,12 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
     // epilogue (its prefetch registers + the one-phase schedule's spill: 94 vs 86 us on the fc1 dgrad) and very long k-loops, where B
     // requested one phase ahead by ONE group lands later than the two-phase schedule's (8192^3: 745 vs 729 us)
     const int ph_auto = ((mode == 4 && bn == 256) || a->K >= 8192) ? 2 : 1;
-    const int ph = g_mr_opt_gemm3_ph ? g_mr_opt_gemm3_ph : ph_env ? ph_env : ph_auto;
+    int ph = g_mr_opt_gemm3_ph ? g_mr_opt_gemm3_ph : ph_env ? ph_env : ph_auto;
+    if (mode == 4 && bn == 256) ph = 2;      // <256,4,1> is not built: 20 spilled registers with a reload inside the k-loop's MFMA block
 #define G3_LAUNCH(MODE)                                                                               \
     do {                                                                                              \
         if (ph == 1) {                                                                                \
-            if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE, 1>), grid, block, 0, s, ga);   \
+            if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE, (MODE == 4 ? 2 : 1)>), grid, block, 0, s, ga);   \
             else hipLaunchKernelGGL((g3::gemm3_kernel<192, MODE, 1>), grid, block, 0, s, ga);             \
         } else {                                                                                      \
             if (bn == 256) hipLaunchKernelGGL((g3::gemm3_kernel<256, MODE, 2>), grid, block, 0, s, ga);   \

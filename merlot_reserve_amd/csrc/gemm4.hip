@@ -284,6 +284,7 @@ bool mr_gemm4_takes(const mr_gemm_args* a) { return !a->c2 && !a->rot_tab && !a-
 // Same eligibility and tile plan as the ping-pong kernel: the caller (mr_gemm3_launch) has built `ga` and checked mr_gemm4_takes(a).
 int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int64_t gsz, hipStream_t s) {
     const int mode = a->residual ? 3 : a->bias ? 0 : 5;
+    MR_CHECK_ARG(!(bn == 256 && mode == 0), "mr_gemm (gemm4): the 256-wide bias mode is not built (register budget); route it to the ping-pong kernel");
     dim3 grid((unsigned)gsz), block(256);
 #define G4_LAUNCH(MODE)                                                                               \
     do {                                                                                              \
@@ -291,7 +292,7 @@ int mr_gemm4_launch(const mr_gemm_args* a, int bn, const g256::G256Args& ga, int
         else hipLaunchKernelGGL((g4::gemm4_kernel<192, MODE>), grid, block, 0, s, ga);                \
     } while (0)
     switch (mode) {
-        case 0: G4_LAUNCH(0); break;
+        case 0: hipLaunchKernelGGL((g4::gemm4_kernel<192, 0>), grid, block, 0, s, ga); break;
         case 3: G4_LAUNCH(3); break;
         default: G4_LAUNCH(5); break;
     }

@@ -433,29 +433,46 @@ __global__ __launch_bounds__(256) void contrastive_reduce_kernel(const float* __
 
 // ---------------------------------------------------------------------------------------------- softmax cross-entropy
 // finetune/vcr/qa_qar_joint_finetune.py:188-195: loss = -mean_r log_softmax(logits[r])[label[r]], is_right = mean(argmax == label);
-// one lane per row (C <= 64 classes); dlogits = coef * (softmax - onehot) written as bf16 at the same strides.
-__global__ void softmax_xent_kernel(const float* __restrict__ logits, int64_t row_stride, int64_t class_stride,
+// one lane per row (C <= 64 classes); dlogits = coef * (softmax - onehot) written as bf16 at the same strides.  ONE workgroup walks the
+// rows (thread t: rows t, t + 256, ...) and the two sums leave it through a fixed-order LDS tree: no float atomics, bitwise reproducible.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, int64_t row_stride, int64_t class_stride,
                                     const int32_t* __restrict__ labels, int64_t rows, int C, float coef,
                                     float* __restrict__ loss_out, float* __restrict__ correct_out, __bf16* __restrict__ dlogits) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float* x = logits + r * row_stride;
-    float mx = -INFINITY;
-    int arg = 0;
-    for (int c = 0; c < C; ++c) {
-        const float v = x[c * class_stride];
-        if (v > mx) { mx = v; arg = c; }          // first maximum, like argmax
+    __shared__ float red[2][256];
+    float lsum = 0.f, csum = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) {
+        const float* x = logits + r * row_stride;
+        float mx = -INFINITY;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) {
+            const float v = x[c * class_stride];
+            if (v > mx) { mx = v; arg = c; }          // first maximum, like argmax
+        }
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += expf(x[c * class_stride] - mx);
+        const int lab = labels[r];
+        const float logp = x[lab * class_stride] - mx - logf(den);
+        lsum += -coef * logp;
+        csum += coef * (arg == lab ? 1.0f : 0.0f);
+        if (dlogits != nullptr) {
+            const float inv = 1.0f / den;
+            for (int c = 0; c < C; ++c)
+                dlogits[r * row_stride + c * class_stride] = (__bf16)(coef * (expf(x[c * class_stride] - mx) * inv - (c == lab ? 1.0f : 0.0f)));
+        }
     }
-    float den = 0.f;
-    for (int c = 0; c < C; ++c) den += expf(x[c * class_stride] - mx);
-    const int lab = labels[r];
-    const float logp = x[lab * class_stride] - mx - logf(den);
-    atomicAdd(loss_out, -coef * logp);
-    if (correct_out != nullptr) atomicAdd(correct_out, coef * (arg == lab ? 1.0f : 0.0f));
-    if (dlogits != nullptr) {
-        const float inv = 1.0f / den;
-        for (int c = 0; c < C; ++c)
-            dlogits[r * row_stride + c * class_stride] = (__bf16)(coef * (expf(x[c * class_stride] - mx) * inv - (c == lab ? 1.0f : 0.0f)));
+    red[0][threadIdx.x] = lsum;
+    red[1][threadIdx.x] = csum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] += red[0][0];
+        if (correct_out != nullptr) correct_out[0] += red[1][0];
     }
 }
 
@@ -464,7 +481,7 @@ __global__ void softmax_xent_kernel(const float* __restrict__ logits, int64_t ro
 extern "C" int mr_softmax_xent(const float* logits, int64_t row_stride, int64_t class_stride, const int32_t* labels, int64_t rows,
                                int64_t C, float coef, float* loss_out, float* correct_out, void* dlogits_bf16, void* stream) {
     MR_CHECK_ARG(logits && labels && loss_out && rows > 0 && C > 0 && C <= 64, "mr_softmax_xent: bad args (C <= 64)");
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), logits,
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
                        row_stride, class_stride, labels, rows, (int)C, coef, loss_out, correct_out, static_cast<__bf16*>(dlogits_bf16));
     MR_CHECK_LAUNCH("mr_softmax_xent");
     return MR_OK;
