@@ -178,6 +178,13 @@ def gemm_args(a, b, out, transA=False, transB=False, bias=None, rot_tab=None, ro
     return g
 
 
+def gemm_bytes(g):
+    """Algorithmic HBM bytes of one GEMM launch as issued: both operands once, the output once, every epilogue operand / second output once."""
+    mn = g.M * g.N
+    return (2 * (g.M * g.K + g.N * g.K) + (4 if g.c_dtype == MR_DT_F32 else 2) * mn + (2 * mn if g.c2 else 0) + (2 * mn if g.residual else 0) +
+            (2 * mn if g.aux else 0) + (2 * g.N if g.bias else 0))
+
+
 @_timed('gemm')
 def gemm(a, b, out, **kw):
     """out[M,N] = op(a) @ op(b) with the fused epilogue of mr_gemm.  a: [M,K] (or [K,M] if transA); b: [K,N]
@@ -194,7 +201,7 @@ def gemm(a, b, out, **kw):
         check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
         e1.record()
         GEMM_PROFILE.append((e0, e1, 2.0 * g.M * g.N * g.K, (g.M, g.N, g.K, g.transA, g.transB, bool(g.bias), bool(g.rot_tab), bool(g.c2), g.act, bool(g.residual), bool(g.aux)),
-                             lib.mr_last_gemm_kernel().decode()))
+                             lib.mr_last_gemm_kernel().decode(), gemm_bytes(g)))
         return out
     check(lib.mr_gemm(C.byref(g), _stream()), 'mr_gemm')
     return out
@@ -215,7 +222,8 @@ def gemm_grouped(arg_list):
         e0.record()
         check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list), ('grouped', len(arg_list), arg_list[0].K), lib.mr_last_gemm_kernel().decode()))
+        GEMM_PROFILE.append((e0, e1, sum(2.0 * g.M * g.N * g.K for g in arg_list), ('grouped', len(arg_list), arg_list[0].K), lib.mr_last_gemm_kernel().decode(),
+                             sum(gemm_bytes(g) for g in arg_list)))
         return
     check(lib.mr_gemm_grouped(arr, len(arg_list), _stream()), 'mr_gemm_grouped')
 

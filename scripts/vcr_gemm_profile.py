@@ -26,7 +26,7 @@ for _ in range(3):
     F.finetune_train_step(state, batch)
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for e0, e1, fl, shape, kern in ops.GEMM_PROFILE:
+for e0, e1, fl, shape, kern, _bytes in ops.GEMM_PROFILE:
     k = (kern, shape)
     a = agg.setdefault(k, [0, 0.0, fl])
     a[0] += 1

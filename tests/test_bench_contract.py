@@ -45,3 +45,13 @@ def test_algorithmic_work_per_video_segment():
     assert abs(base / fwd - 3.0) < 1e-9
     large = bench.algorithmic_flops_per_record(load_config('large')) / 2
     assert 3.0 < large / base < 3.5           # 24 layers x 1024 wide against 12 x 768
+
+
+def test_gemm_algorithmic_bytes():
+    """ops.gemm_bytes: every operand, output and epilogue operand once (the roofline's algorithmic_bytes_per_step)."""
+    import types
+    from merlot_reserve_amd import ops
+    g = types.SimpleNamespace(M=256, N=512, K=128, c_dtype=ops.MR_DT_BF16, c2=None, residual=None, aux=None, bias=None)
+    assert ops.gemm_bytes(g) == 2 * (256 * 128 + 512 * 128) + 2 * 256 * 512
+    g = types.SimpleNamespace(M=256, N=512, K=128, c_dtype=ops.MR_DT_F32, c2=1, residual=1, aux=None, bias=1)
+    assert ops.gemm_bytes(g) == 2 * (256 * 128 + 512 * 128) + 4 * 256 * 512 + 2 * 2 * 256 * 512 + 2 * 512

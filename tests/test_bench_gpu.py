@@ -28,6 +28,11 @@ def test_bench_line_contract(dev):
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
     assert 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0
+    # round 5: the GEMM launches' algorithmic bytes beside the PMC total, a calibration figure around the timed region, graph == eager
+    assert 20e9 < r['algorithmic_bytes_per_step'] < 80e9 and (r['traffic_ratio'] is None or 0.8 < r['traffic_ratio'] < 3.0)
+    cal = d['config']['calibration_tflops']
+    assert len(cal) == 2 and all(500.0 < c_ < 2500.0 for c_ in cal)
+    assert d['config']['graph_equals_eager'] is True
     b = d['breakdown']
     assert set(b['ms_per_step']) >= {'gemm', 'attention', 'layernorm+reductions', 'optimizer'} and b['sum_ms'] > 0
     assert 'degraded' not in d
@@ -58,3 +63,5 @@ def test_bench_multi_rank_code_path_with_one_rank(dev):
     assert len(c['rccl']['allreduce_bucket_mbytes']) == 5 and c['rccl']['version'] and 'NCCL_ALGO' in c['rccl']
     assert len(c['gradient_buckets']) == 5 and 0.0 < c['exposed_gradient_fraction'] < 0.2
     assert d['value'] > 0 and d['n_gpus'] == 1
+    assert c['graph_equals_eager'] is True, 'the one-shot check of the captured multi-rank program against the eager step'
+
