@@ -68,6 +68,9 @@ const char* mr_last_error(void);
  *                   start phase of two workgroups sharing a CU
  *   "attn_onepass"  -1 = default: mr_attention_bwd runs its one-pass kernel (dQ, dK, dV from one sweep, one workgroup per (sequence,
  *                   head)) for 128 < S <= 256 | 0 = never (the dQ + dK / dV kernel pair) | 1 = whenever S <= 256 (tests, A/B)
+ *   "attn_tile_modes" 1 = default: the masked attention kernels classify every (wave, 64-position tile) pair by the position codes -- all pairs
+ *                   allowed: the unmasked instruction sequence; none allowed and every query valid: the tile is skipped; otherwise the general
+ *                   path -- bit-identical results | 0 = the general path everywhere (tests, A/B)
  *   "gemm_trace"    1 = every GEMM launch records the kernel it was routed to (mr_last_gemm_kernel; bench.py's per-kernel table)
  * Environment variables (MR_GEMM3, MR_G3_PH, ...: experiment scripts) are read only by a library built with -DMR_DEBUG_ENV
  * (MR_DEBUG_ENV=1 python -m merlot_reserve_amd.build); the product build ignores the environment.
@@ -174,7 +177,7 @@ int mr_attention_fwd(const void* qkv, const int32_t* code, void* out, float* lse
                      int64_t nseq, int64_t S, int64_t nh, void* stream);
 /* dqkv [nseq*S, 3H] bf16 = gradient wrt the PRE-"rotary" qkv when rot_tab != NULL (the diagonal
  * scaling is applied to dq, dk on the way out), else wrt qkv as given.  delta: fp32 [nseq, nh, S] workspace (rowsum(dO * O),
- * computed by the dQ kernel).  colsum (optional): fp32 [mr_attention_bwd_colsum_rows(nseq, S), 3H] -- per (sequence, 64- or
+ * computed by the dQ kernel for the dK / dV kernel; a row whose dO is entirely zero is marked -0.0 there -- an internal hand-off, not an output).  colsum (optional): fp32 [mr_attention_bwd_colsum_rows(nseq, S), 3H] -- per (sequence, 64- or
  * 128-position block) column sums of the stored dqkv, i.e. partial rows of the qkv bias gradient (M:228) to be summed in a
  * fixed order by mr_reduce_partials; every element is written. */
 int mr_attention_bwd(const void* qkv, const int32_t* code, const void* out, const void* dout, const float* lse,

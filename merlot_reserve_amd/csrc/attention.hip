@@ -81,6 +81,30 @@ constexpr float NEG_BIAS = -8589934592.0f;         // -2^33: stands in for the r
 constexpr float PAD_LSE = 0.25f * NEG_BIAS;        // an LSE below this marks a row with no allowed key
 constexpr int CODE_NONE = -2;                      // key beyond the sequence
 constexpr int CODE_PADQ = -3;                      // query with no allowed key (PAD, or beyond the sequence): matches no key code
+constexpr int CODE_MIXED = INT32_MIN;              // a 64-position tile (a wave's positions) without ONE common code: the general path
+constexpr int CODE_DEAD = INT32_MIN + 1;           // backward: a query tile whose rows all have a zero upstream gradient: skipped by every wave
+// ---- block-structured masks (round 5).  The mask is code[i] == code[j] && code[i] >= 0 and real sequences carry their codes in RUNS (one video
+// source after the other, a PAD tail or gap), so most (wave, 64-position tile) pairs are UNIFORM: every pair allowed -- then the per-score
+// compare / select / add of the bias is dead weight and the tile runs the unmasked instruction sequence (bit-identical: the bias is exactly 0) --
+// or every pair disallowed while every query of the wave is a valid one (so each has an allowed key: itself): then every weight of the
+// tile is exactly 0 (forward: exp2 of -1e10 log2 e below a finite maximum; or, before the row's first allowed key, wiped by the rescale factor
+// exp2(-1e10..) = 0 at that key) and the tile is SKIPPED, bit-identically.  Classification: the staging wave votes on the tile's codes
+// (one ballot) and leaves its class in LDS beside the codes; each wave votes once on its own positions; PAD queries (uniform rows over all
+// S keys), ragged last tiles and mixed tiles take the general path.  Forward, a wave whose queries are ALL PAD (TILE_UNIFORM): every score of
+// a tile inside the sequence rounds to the same -1e10 log2 e, so m = that constant, every weight is exp2(0) = 1 and each lane's row sum
+// grows by its 16 keys: the Q K^T product and the softmax arithmetic are skipped and the P V product runs on a fragment of ones -- the same
+// MFMA sequence on the same operands as the general path, bit-identical.
+enum : int { TILE_GENERAL = 0, TILE_FAST = 1, TILE_SKIP = 2, TILE_UNIFORM = 3 };
+__device__ __forceinline__ int tile_mode(bool wave_uniform, int wave_code, int tile_code) {
+    if (!wave_uniform || tile_code == CODE_MIXED) return TILE_GENERAL;
+    return tile_code == wave_code ? TILE_FAST : TILE_SKIP;
+}
+// class of the 64 positions the staging wave (all 64 lanes active) holds one code each of: their common code, CODE_MIXED otherwise or when
+// the tile reaches beyond the sequence
+__device__ __forceinline__ int tile_class(int c, bool tile_inside) {
+    const int c0 = __builtin_amdgcn_readfirstlane(c);
+    return (tile_inside && !__any(c != c0)) ? c0 : CODE_MIXED;
+}
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -200,11 +224,12 @@ constexpr float NEG_BIG2 = -1e10f * LOG2E;         // the reference's -1e10 bias
 template <int QB, bool MASKED>
 __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
                                                           __bf16* __restrict__ out, float* __restrict__ lse,
-                                                          int64_t S, int64_t nh) {
+                                                          int64_t S, int64_t nh, const int tile_modes) {
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];          // LDS-DMA images (see dma_src)
     __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];          // masked: key codes
     __shared__ __attribute__((aligned(16))) float Ns[2][TK];            // additive key bias, exp2 domain (see key_meta2)
+    __shared__ int32_t Ku[2];                                           // masked: class of the key tile (tile_class)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
@@ -227,6 +252,20 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         }
         cq[qb] = (MASKED && qi[qb] < S) ? code[seq * S + qi[qb]] : 0;
         if (MASKED && cq[qb] < 0) cq[qb] = CODE_PADQ;            // a PAD query matches no key code (a PAD key's is -1)
+    }
+    // this wave's queries: one common valid code?  (queries beyond the sequence are never stored: wildcards; a wave without any query inside
+    // the sequence skips every tile)
+    bool wq_uniform = false, wq_allpad = false;
+    int wq_code = 0;
+    if constexpr (MASKED) {
+        wq_code = __builtin_amdgcn_readfirstlane(cq[0]);        // lane 0 = the wave's first query
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) ok = ok && (qi[qb] >= S || cq[qb] == wq_code);
+        const bool first_inside = q0 + wave * QB * 16 < S;
+        wq_uniform = tile_modes != 0 && (!first_inside || (wq_code >= 0 && !__any(!ok)));
+        wq_allpad = tile_modes != 0 && first_inside && wq_code == CODE_PADQ && !__any(!ok);
+        if (!first_inside) wq_code = CODE_PADQ - 1;             // equals no tile class: every tile is skipped
     }
 
     float m[QB], l[QB];
@@ -266,22 +305,50 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
     };
 
-    int cr = 0;
+    int cr = 0, kur = 0;
     float nr = 0.f;
     stage(0, 0);
-    if (tid < TK) { key_meta2(tid, cr, nr); if (MASKED) Cs[0][tid] = cr; Ns[0][tid] = nr; }
+    if (tid < TK) {
+        key_meta2(tid, cr, nr);
+        if (MASKED) { Cs[0][tid] = cr; kur = tile_class(cr, TK <= S); if (tid == 0) Ku[0] = kur; }
+        Ns[0][tid] = nr;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
+    // one key tile's scores, softmax update and P V product; FAST (masked kernels only): every (query, key) pair of this wave and tile is
+    // allowed, the bias is 0 for all of them
+    // (staging and the end-of-tile wait stay inside the lambda: split off, the same statements cost registers -- see the dQ kernel)
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
+        // masked kernels: one body, wave-uniform branches around the bias section (TILE_FAST) / the whole compute section (TILE_SKIP) --
+        // three instantiated bodies cost this kernel its third wave per SIMD (206 registers)
+        int mode = TILE_GENERAL;
+        if constexpr (MASKED) {
+            mode = tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[b]));
+            if (wq_allpad && (int64_t)(t + 1) * TK <= S) mode = TILE_UNIFORM;
+        }
         MR_ASTAMP(0);
         if (t + 1 < nt) {      // next tile: straight into the other buffer (last read one iteration ago, behind that iteration's barrier)
             stage(t + 1, b ^ 1);
-            if (tid < TK) key_meta2((int64_t)(t + 1) * TK + tid, cr, nr);
+            if (tid < TK) {
+                key_meta2((int64_t)(t + 1) * TK + tid, cr, nr);
+                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);
+            }
         }
         MR_ASTAMP(1);
+        if (!MASKED || mode != TILE_SKIP) {
+        bf16x8 pf[QB][2];
+        constexpr bool V_EARLY = !MASKED;
+        s16x4 vlo[2][4], vhi[2][4];
+        if (MASKED && mode == TILE_UNIFORM) {
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) { m[qb] = NEG_BIG2; l[qb] += 16.f; pf[qb][0] = ones; pf[qb][1] = ones; }
+        } else {
         f32x4 st[QB][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -296,8 +363,6 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         // the V fragments do not depend on the softmax: the first half (keys 0-31) is requested now and lands while it runs; the
         // second half after it (its registers are the softmax's), landing under the first half's MFMAs
         // (the masked variant holds the codes as well and would lose its third wave per SIMD to these 16 registers: it asks late)
-        constexpr bool V_EARLY = !MASKED;
-        s16x4 vlo[2][4], vhi[2][4];
         if constexpr (V_EARLY) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) tr_frag_d_issue(Vs[b], 0, 16 * db, lane, vlo[0][db], vhi[0][db]);
@@ -305,22 +370,34 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         float tmx[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) tmx[qb] = -INFINITY;
+        if (MASKED && mode == TILE_FAST) {       // every pair allowed: the bias is 0, s = fma(raw, SCALE2, 0)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {         // the staged vectors of one 16-key block at a time: 8 registers live, not 32
-            const f32x4 nbv = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
-            i32x4 ckv = {0, 0, 0, 0};
-            if (MASKED) ckv = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
+                for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float bias = MASKED ? ((ckv[r] == cq[qb]) ? 0.f : nbv[r]) : nbv[r];
-                    const float s = __builtin_fmaf(st[qb][kb][r], SCALE2, bias);
-                    st[qb][kb][r] = s;
-                    tmx[qb] = fmaxf(tmx[qb], s);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float s = st[qb][kb][r] * SCALE2;
+                        st[qb][kb][r] = s;
+                        tmx[qb] = fmaxf(tmx[qb], s);
+                    }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {         // the staged vectors of one 16-key block at a time: 8 registers live, not 32
+                const f32x4 nbv = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
+                i32x4 ckv = {0, 0, 0, 0};
+                if (MASKED) ckv = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bias = MASKED ? ((ckv[r] == cq[qb]) ? 0.f : nbv[r]) : nbv[r];
+                        const float s = __builtin_fmaf(st[qb][kb][r], SCALE2, bias);
+                        st[qb][kb][r] = s;
+                        tmx[qb] = fmaxf(tmx[qb], s);
+                    }
+            }
         }
-        bf16x8 pf[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float tmax = tmx[qb];
@@ -343,6 +420,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
             pf[qb][0] = pack_acc_pair(st[qb][0], st[qb][1]);
             pf[qb][1] = pack_acc_pair(st[qb][2], st[qb][3]);
+        }
         }
         MR_ASTAMP(3);
         __builtin_amdgcn_sched_barrier(0);
@@ -370,7 +448,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             }
         }
         MR_ASTAMP(4);
-        if (t + 1 < nt && tid < TK) { if (MASKED) Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
+        }
+        if (t + 1 < nt && tid < TK) { if (MASKED) { Cs[b ^ 1][tid] = cr; if (tid == 0) Ku[b ^ 1] = kur; } Ns[b ^ 1][tid] = nr; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         MR_ASTAMP(5);
         __syncthreads();
@@ -403,12 +482,13 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
                                                              const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, float* __restrict__ delta,
                                                              __bf16* __restrict__ dqkv, const float* __restrict__ rot_tab,
-                                                             int64_t rot_rows, float* __restrict__ colsum, int64_t S, int64_t nh) {
+                                                             int64_t rot_rows, float* __restrict__ colsum, int64_t S, int64_t nh, const int tile_modes) {
     __shared__ __attribute__((aligned(16))) float red[4][64];
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];       // LDS-DMA images: row reads (S^T) and tr reads (dQ^T)
     __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];       // row reads (dP^T)
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     __shared__ __attribute__((aligned(16))) float Ns[2][TK];
+    __shared__ int32_t Ku[2];                                         // masked: class of the key tile (tile_class)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
@@ -423,12 +503,13 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     int cq[QB];
     float nlse2[QB], del[QB];
     bool padq[QB];
-    bool any_pad = false;
+    bool any_pad = false, any_nz = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         qi[qb] = (int)q0 + (wave * QB + qb) * 16 + i;
         const bool ok = qi[qb] < S;
         float dsum = 0.f;
+        unsigned nz = 0u;                             // any non-zero bit pattern (other than -0) in this lane's part of the dO row
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
             u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u}, x = {0u, 0u, 0u, 0u};
@@ -437,6 +518,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
                 w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
                 x = *reinterpret_cast<const u32x4*>(o + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
             }
+            nz |= (w[0] | w[1] | w[2] | w[3]) & 0x7fff7fffu;
             qf[qb][dd] = scale_eighth(v);             // the TRUE q also for PAD rows: the reference differentiates through them
             dof[qb][dd] = __builtin_bit_cast(bf16x8, w);
             float a[8], bb[8];
@@ -447,8 +529,14 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         }
         dsum += __shfl_xor(dsum, 16, 64);             // the 4 lanes of a query hold 16 of its 64 dims each
         dsum += __shfl_xor(dsum, 32, 64);
+        nz |= __shfl_xor(nz, 16, 64);
+        nz |= __shfl_xor(nz, 32, 64);
+        any_nz = any_nz || nz != 0u;
         del[qb] = dsum;
-        if (ok && g == 0) delta[(seq * nh + h) * S + qi[qb]] = dsum;        // for the dK / dV kernel, launched behind this one
+        // for the dK / dV kernel, launched behind this one.  A row whose upstream gradient is ENTIRELY zero (the PAD rows of a training step: nothing
+        // reads their outputs) contributes exactly nothing to dQ, dK or dV (dS = P (0 - 0), dV += P^T 0) whatever its weights are: it is
+        // marked with delta = -0.0 (its delta is +0.0 by arithmetic), so that the dK / dV kernel can skip query tiles made of such rows
+        if (ok && g == 0) delta[(seq * nh + h) * S + qi[qb]] = (tile_modes != 0 && nz == 0u) ? -0.0f : dsum;
         int c = ok ? (MASKED ? code_seq[qi[qb]] : 0) : CODE_PADQ;
         if (c < 0) c = CODE_PADQ;
         cq[qb] = c;
@@ -460,6 +548,20 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         nlse2[qb] = -L * LOG2E;
     }
     const bool wave_pad = MASKED && __any(any_pad);
+    // every row of this wave has a zero upstream gradient (rows beyond the sequence count as such): dQ = 0, no tile is computed
+    const bool wave_dead = tile_modes != 0 && !__any(any_nz);
+    // this wave's queries: one common valid code (see tile_mode)?  Rows beyond the sequence are wildcards (their P is exp2(-inf) = 0)
+    bool wq_uniform = false;
+    int wq_code = 0;
+    if constexpr (MASKED) {
+        wq_code = __builtin_amdgcn_readfirstlane(cq[0]);
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) ok = ok && (qi[qb] >= S || cq[qb] == wq_code);
+        const bool first_inside = q0 + wave * QB * 16 < S;
+        wq_uniform = tile_modes != 0 && (!first_inside || (wq_code >= 0 && !__any(!ok)));
+        if (!first_inside) wq_code = CODE_PADQ - 1;
+    }
     f32x4 dq[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -482,25 +584,39 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
     };
-    int cr = 0;
+    int cr = 0, kur = 0;
     float nr = 0.f;
     stage(0, 0);
-    if (tid < TK) { key_meta(tid, S, code_seq, MASKED, cr, nr); Cs[0][tid] = cr; Ns[0][tid] = nr; }
+    if (tid < TK) {
+        key_meta(tid, S, code_seq, MASKED, cr, nr);
+        Cs[0][tid] = cr; Ns[0][tid] = nr;
+        if (MASKED) { kur = tile_class(cr, TK <= S); if (tid == 0) Ku[0] = kur; }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
     const bool ragged = (S & (TK - 1)) != 0;
-    // one key tile; NB (compile time) = the scores of this tile need the per-key bias: always when masked, otherwise only in a ragged
-    // LAST tile (keys beyond the sequence) -- which is peeled below so that the hot loop of the unmasked towers carries neither the
-    // test nor the addresses of the staged codes (as one loop with a run-time flag the kernel needed 190 registers)
-    auto tile_body = [&](int t, auto nb_c) {
-        constexpr bool need_bias = decltype(nb_c)::value;
+    // one key tile; NB (compile time) = the scores of this tile need the per-key bias: when masked unless the tile is uniformly allowed
+    // for this wave (tile_mode), otherwise only in a ragged LAST tile (keys beyond the sequence) -- which is peeled below so that the hot
+    // loop of the unmasked towers carries neither the test nor the addresses of the staged codes (as one loop with a run-time flag the
+    // kernel needed 190 registers)
+    // (staging and the end-of-tile wait stay INSIDE this lambda: as three lambdas -- top / compute / end -- the same statements compiled to
+    // 168 registers + 31 spilled for the unmasked instance instead of 154 + 0)
+    // masked kernels: ONE body with wave-uniform branches on the tile's mode (three instantiated bodies cost registers: 230 -> 256 + 20 spilled in
+    // the dK / dV kernel, 168 -> 206 in the forward kernel)
+    auto tile_body = [&](int t, auto nb_c, const int mode) {
+        const bool need_bias = MASKED ? (mode == TILE_GENERAL) : decltype(nb_c)::value;
+        const bool skip = MASKED && mode == TILE_SKIP;       // stage, wait and synchronise only: every weight of the tile is 0 for this wave
         const int b = t & 1;
         if (t + 1 < nt) {
             stage(t + 1, b ^ 1);
-            if (tid < TK) key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
+            if (tid < TK) {
+                key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
+                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);
+            }
         }
+        if (!skip) {
         f32x4 ds[QB][2];
         bf16x8 dsf[QB][2];
 #pragma unroll
@@ -523,7 +639,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
                 f32x4 pv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, nlse2[qb]));
-                if (wave_pad) {
+                if (need_bias && wave_pad) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pv[r] = padq[qb] ? ((ck[r] == CODE_NONE) ? 0.f : inv_S) : pv[r];
                 }
@@ -550,16 +666,18 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
                     dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[qb][t2], dq[qb][db], 0, 0, 0);
             }
         }
-        if (t + 1 < nt && tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; }
+        }
+        if (t + 1 < nt && tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; if (MASKED && tid == 0) Ku[b ^ 1] = kur; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     };
     if constexpr (MASKED) {
-        for (int t = 0; t < nt; ++t) tile_body(t, std::integral_constant<bool, true>{});
+        for (int t = 0; t < nt; ++t)
+            tile_body(t, std::true_type{}, wave_dead ? (int)TILE_SKIP : tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[t & 1])));
     } else {
-        for (int t = 0; t < nt - 1; ++t) tile_body(t, std::integral_constant<bool, false>{});
-        if (ragged) tile_body(nt - 1, std::integral_constant<bool, true>{});
-        else tile_body(nt - 1, std::integral_constant<bool, false>{});
+        for (int t = 0; t < nt - 1; ++t) tile_body(t, std::false_type{}, TILE_GENERAL);
+        if (ragged) tile_body(nt - 1, std::true_type{}, TILE_GENERAL);
+        else tile_body(nt - 1, std::false_type{}, TILE_GENERAL);
     }
     f32x4 cs[4];
 #pragma unroll
@@ -593,13 +711,14 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                                                               const __bf16* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, __bf16* __restrict__ dqkv,
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
-                                                              float* __restrict__ colsum, int64_t S, int64_t nh) {
+                                                              float* __restrict__ colsum, int64_t S, int64_t nh, const int tile_modes) {
     __shared__ __attribute__((aligned(16))) float red[4][64];
     __shared__ __attribute__((aligned(16))) char Qs[2][TILE_B];        // LDS-DMA images: row reads (S) and tr reads (dK^T)
     __shared__ __attribute__((aligned(16))) char Ds[2][TILE_B];        // dO: row reads (dP) and tr reads (dV^T)
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     __shared__ int32_t Fs[2];                                          // tile has a row without allowed key
+    __shared__ int32_t Qu[2];                                          // masked: the query tile's common valid code, or CODE_MIXED (tile_class)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
@@ -631,6 +750,16 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         nkl[kb] = ok ? NEG_BIAS : -INFINITY;
         unil[kb] = ok ? 1.0f : 0.0f;
     }
+    // this wave's keys: all inside the sequence with one common code (a valid one, or -1: PAD keys, which no valid query may see)?
+    bool wk_uniform = false;
+    int wk_code = 0;
+    if constexpr (MASKED) {
+        wk_code = __builtin_amdgcn_readfirstlane(ck[0]);
+        bool ok = true;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) ok = ok && ck[kb] == wk_code;
+        wk_uniform = tile_modes != 0 && wk_code != CODE_NONE && !__any(!ok);
+    }
     f32x4 dk[KB][4], dv[KB][4];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
@@ -655,7 +784,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_ + 1024), 16, sd1, (unsigned)t * d_step, 0, 0);
     };
     float lr = 0.f, er = 0.f, ur = 0.f;
-    int cr = 0, fr = 0;
+    int cr = 0, fr = 0, qur = 0;
     auto side_load = [&](int64_t q0) {        // wave 0 (tid < TK) stages the 64 queries' scalars
         if (tid < TK) {
             const bool ok = q0 + tid < S;
@@ -667,22 +796,39 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
             cr = (c < 0) ? CODE_PADQ : c;
             ur = pad ? inv_S : 0.f;
             fr = MASKED ? (int)__any(pad) : 0;
+            if (MASKED) {                     // a tile with a PAD (or missing) query is never uniform: PAD rows weigh EVERY key
+                qur = tile_class(cr, true);
+                if (qur < 0) qur = CODE_MIXED;
+                // ... unless every row of the tile is beyond the sequence or marked by the dQ kernel as having a zero upstream gradient
+                // (delta = -0.0): such a tile contributes exactly nothing to dK / dV and is skipped by every wave
+                if (tile_modes != 0 && !__any(ok && __float_as_uint(er) != 0x80000000u)) qur = CODE_DEAD;
+            }
         }
     };
     stage(0, 0);
     side_load(0);
-    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; Us[0][tid] = ur; if (tid == 0) Fs[0] = fr; }
+    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; Us[0][tid] = ur; if (tid == 0) { Fs[0] = fr; Qu[0] = qur; } }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nt = (int)((S + TK - 1) / TK);
+    // one query tile; FAST (masked kernels only): every (query, key) pair of the tile and this wave's keys is allowed
+    // (staging and the end-of-tile wait stay inside the lambda: split off, the same statements cost registers -- see the dQ kernel)
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
+        // masked kernels: wave-uniform branches on the tile's mode inside ONE body (see the dQ kernel)
+        int mode = TILE_GENERAL;
+        if constexpr (MASKED) {
+            const int qc = __builtin_amdgcn_readfirstlane(Qu[b]);
+            mode = qc == CODE_DEAD ? (int)TILE_SKIP : tile_mode(wk_uniform, wk_code, qc);
+        }
+        const bool FAST = MASKED && mode == TILE_FAST;
         if (t + 1 < nt) {
             stage(t + 1, b ^ 1);
             side_load((int64_t)(t + 1) * TK);
         }
-        const bool tile_pad = MASKED && Fs[b] != 0;
+        if (!MASKED || mode != TILE_SKIP) {
+        const bool tile_pad = MASKED && !FAST && Fs[b] != 0;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             f32x4 pp[KB][2], ds[KB][2];
@@ -694,7 +840,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
                 i32x4 c4 = {0, 0, 0, 0};
-                if (MASKED) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+                if (MASKED && !FAST) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);       // (wave-uniform branch)
                 f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
                 if (tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
 #pragma unroll
@@ -704,12 +850,17 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                     f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
                     f32x4 pv;
+                    if (FAST) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // allowed = same code (a PAD key's -1 and a missing key's -2 equal no query code; unmasked: codes are 0,
-                        // missing keys -2, missing queries have l4 = -inf)
-                        const float s = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
-                        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E, l4[r]));
+                        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, l4[r]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // allowed = same code (a PAD key's -1 and a missing key's -2 equal no query code; unmasked: codes are 0,
+                            // missing keys -2, missing queries have l4 = -inf)
+                            const float s = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                            pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E, l4[r]));
+                        }
                     }
                     if (tile_pad) {       // rows without allowed key: uniform over the existing keys
 #pragma unroll
@@ -753,7 +904,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                 }
             }
         }
-        if (t + 1 < nt && tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) Fs[b ^ 1] = fr; }
+        }
+        if (t + 1 < nt && tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) { Fs[b ^ 1] = fr; Qu[b ^ 1] = qur; } }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     }
@@ -911,6 +1063,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    const bool keys_inside = !MASKED && 32 * wave + 32 <= S;
     // dQ^T of one tile: wave (db = wave & 3, query half wave >> 2) over all 256 keys
     const int qdb = wave & 3, qh = wave >> 2;
     f32x4 csq = {0.f, 0.f, 0.f, 0.f};
@@ -986,10 +1139,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
                     f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
                     f32x4 pv;
+                    if (keys_inside) {    // (wave-uniform) unmasked, every key of this wave inside the sequence: every pair is allowed (a query beyond the sequence has l4 = -inf: p = 0)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sc = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
-                        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, LOG2E, l4[r]));
+                        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, l4[r]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sc = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                            pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, LOG2E, l4[r]));
+                        }
                     }
                     if (MASKED) {         // (always, no wave-uniform shortcut: this variant only runs masked towers of <= 256 positions)
 #pragma unroll
@@ -1119,11 +1277,12 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const __bf16* q = static_cast<const __bf16*>(qkv);
     __bf16* o = static_cast<__bf16*>(out);
+    const int tm = mr_opts().attn_tile_modes;
     const bool two = S > attn_qb_threshold();        // short sequences (audio 31, span 16): one 16-query block per wave
-    if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
-    else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
-    else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
-    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh);
+    if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
+    else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
+    else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
     MR_CHECK_LAUNCH("mr_attention_fwd");
     return MR_OK;
 }
@@ -1162,12 +1321,13 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
         return MR_OK;
     }
     const bool two = S > attn_qb_threshold();
+    const int tm = mr_opts().attn_tile_modes;
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, oo, d, lse, delta, g, \
-                           rot_tab, rot_rows, colsum, S, nh);                                                                 \
+                           rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
-                           rot_tab, rot_rows, colsum, S, nh);                                                                 \
+                           rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
     } while (0)
     if (two && code) MR_LAUNCH_BWD(2, true);
     else if (two) MR_LAUNCH_BWD(2, false);

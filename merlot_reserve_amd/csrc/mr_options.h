@@ -15,6 +15,7 @@ struct MrOptions {
     int gemm5 = -1;            // "gemm5"
     int gemm5_stagger = -1;    // "gemm5_stagger"
     int attn_onepass = -1;     // "attn_onepass"
+    int attn_tile_modes = 1;   // "attn_tile_modes"
     int trace = 0;             // "gemm_trace": record the kernel every GEMM launch is routed to (mr_last_gemm_kernel)
 };
 

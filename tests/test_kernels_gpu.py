@@ -287,6 +287,68 @@ def test_attention_fwd_bwd(dev, case, onepass, attn_path):
     assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
 
 
+def _run_codes(S, runs):
+    c = []
+    for code, n in runs:
+        c += [code] * n
+    assert len(c) == S, (len(c), S)
+    return c
+
+
+# position codes in RUNS, as real sequences carry them (video sources one after the other, PAD gaps / tails; planner.joint_code of the
+# bench batch: [(0,108),(-1,52),(0,480)] / [(0,527),(-1,113)]): boundaries off and on the 64-position tile grid, several sources, an all-valid
+# and an entirely empty sequence -- the (wave, tile) classes of csrc/attention.hip (fast / skip / general) all occur
+RUN_MASKS = {
+    640: [[(0, 108), (-1, 52), (0, 480)], [(0, 527), (-1, 113)], [(0, 200), (1, 250), (-1, 62), (2, 128)], [(0, 640)], [(-1, 640)],
+          [(0, 128), (-1, 64), (1, 256), (-1, 192)]],
+    200: [[(0, 70), (-1, 30), (0, 100)], [(1, 64), (2, 64), (-1, 72)]],
+    130: [[(0, 128), (-1, 2)], [(-1, 3), (5, 127)]],
+    1312: [[(0, 1000), (-1, 312)], [(0, 400), (1, 400), (2, 400), (-1, 112)]],
+}
+
+
+@pytest.mark.parametrize('zero_pad_dout', [False, True])
+@pytest.mark.parametrize('S,nh,onepass', [(640, 3, -1), (200, 2, 0), (200, 2, 1), (130, 2, -1), (130, 2, 0), (1312, 2, -1)])
+def test_attention_run_structured_masks(dev, S, nh, onepass, zero_pad_dout, attn_path):
+    """Masks made of runs: against the fp32 torch reference (PAD rows get a non-zero upstream gradient too), and BIT FOR BIT against the same
+    kernels with the tile classification switched off (option attn_tile_modes = 0: the general path everywhere).  zero_pad_dout: the upstream
+    gradient of the PAD rows is zero, which the dQ kernel detects per row (delta = -0.0) and both backward kernels use to skip dead waves / tiles."""
+    from merlot_reserve_amd import ops
+    attn_path(onepass)
+    runs = RUN_MASKS[S]
+    nseq, H = len(runs), nh * 64
+    qkv = rnd((nseq * S, 3 * H), dev, seed=11)
+    code = torch.tensor([_run_codes(S, r) for r in runs], dtype=torch.int32).reshape(-1).to(dev)
+    dout = rnd((nseq * S, H), dev, seed=12)
+    if zero_pad_dout:      # as in a training step: nothing reads the PAD rows' outputs (the backward kernels skip waves / tiles made of such rows)
+        dout = dout * (code >= 0).reshape(-1, 1).to(BF16)
+    res = {}
+    try:
+        for modes in (1, 0):
+            ops.set_option('attn_tile_modes', modes)
+            out = torch.zeros(nseq * S, H, dtype=BF16, device=dev)
+            lse = torch.zeros(nseq, nh, S, device=dev)
+            ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
+            dqkv = torch.full_like(qkv, float('nan'))
+            delta = torch.zeros(nseq, nh, S, device=dev)
+            ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+            res[modes] = (out, lse, dqkv)
+    finally:
+        ops.set_option('attn_tile_modes', 1)
+    for a, b, name in zip(res[1], res[0], ('out', 'lse', 'dqkv')):
+        assert torch.equal(a, b), f'{name}: the classified tiles must reproduce the general path bit for bit'
+    out, lse, dqkv = res[1]
+    qr = qkv.float().clone().requires_grad_(True)
+    ref_o, ref_lse = ref_attention(qr, code, nseq, S, nh)
+    assert_close(out, ref_o, 4e-3, 'attn out (run masks)')
+    valid = (code.reshape(nseq, S) >= 0)[:, None, :].expand(nseq, nh, S)
+    assert relerr(lse[valid], ref_lse[valid]) < 1e-3
+    ref_o.backward(dout.float())
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
+        assert_close(dqkv[:, sl], qr.grad[:, sl], 1.5e-2, f'attn {name} (run masks)')
+
+
 @pytest.mark.parametrize('onepass', [-1, 1])
 @pytest.mark.parametrize('nseq,S,nh,masked', [(2, 241, 2, False), (1, 100, 2, True), (3, 31, 2, False)])
 def test_attention_reads_nothing_past_the_sequence(dev, nseq, S, nh, masked, onepass, attn_path):
