@@ -65,7 +65,7 @@ def cpu_baseline(config, threads=None):
     forward + backward of ONE record (2 video-segment groups) of the full-depth base model (or, for larger models,
     every tower at 1/`depth_div` of its depth, scaled back by the ratio of algorithmic FLOPs), the same
     widths, sequence lengths and batch structure; reported in the metric's unit.  Protocol (round 5): the warm-up IS a sweep of the
-    thread count over {16, 32, 64, physical cores} (one run each, capped at the CPUs available), then the median of 3 runs at the
+    thread count over {8, 16, 32, 64, physical cores} (one run each, capped at the CPUs available), then the median of 3 runs at the
     FASTEST count -- the baseline is the best CPU figure, not an artefact of one-thread-per-core on a 128-core host (round 4: 0.082
     vseg/s at 128 threads against 0.184 at 32).  CPU model, core counts, the sweep and every run are in the record."""
     import copy
@@ -95,7 +95,7 @@ def cpu_baseline(config, threads=None):
         R.loss_and_grads(params, small, ob, osp, oz)
         return time.time() - t0
 
-    cand = [threads] if threads else sorted({min(c, logical) for c in (16, 32, 64, phys)})
+    cand = [threads] if threads else sorted({min(c, logical) for c in (8, 16, 32, 64, phys)})
     sweep = {}
     one(cand[0]) if len(cand) > 1 else None          # allocator / first touch of the activations: not charged to the first candidate
     for c in cand:

@@ -196,6 +196,16 @@ __device__ __forceinline__ void block_colsum_store(f32x4 (&cs)[4], float (*red)[
     if (tid < 64) dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
+// Row of the "rotary" scale table for position `pos` (< S) of a sequence whose first row is seq_rot0 = (seq * S) % rot_rows: the table has rot_rows
+// rows and repeats (one row per position of a sequence: rot_rows = S; or one per position of the batch).  32-bit, and without a division when the
+// table is at least a sequence long -- as (seq * S + pos) % rot_rows in 64 bits this was ~60 vector instructions per use, twice per query tile in
+// the one-pass backward kernel's loop.
+__device__ __forceinline__ int rot_row_index(int seq_rot0, int pos, int rot_rows, bool table_shorter_than_seq) {
+    int r = seq_rot0 + pos;
+    if (table_shorter_than_seq) return r % rot_rows;
+    return r >= rot_rows ? r - rot_rows : r;
+}
+
 // XCD-aware block order.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, so with the plain
 // (block, head, sequence) grid the query blocks of ONE (sequence, head) -- which all stream the same K / V rows -- landed
 // on different XCDs and every XCD's L2 fetched those rows for itself (rocprofv3 FETCH_SIZE: 3.7x the algorithmic bytes
@@ -497,6 +507,8 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
+    const bool rot_short = rot_rows < S;
 
     bf16x8 qf[QB][2], dof[QB][2];
     int qi[QB];      // (32-bit: S < 2^31; address arithmetic widens at the use)
@@ -540,10 +552,13 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         int c = ok ? (MASKED ? code_seq[qi[qb]] : 0) : CODE_PADQ;
         if (c < 0) c = CODE_PADQ;
         cq[qb] = c;
-        const float L = ok ? lse[(seq * nh + h) * S + qi[qb]] : INFINITY;   // beyond the sequence: p = exp2(-inf) = 0
+        float L = ok ? lse[(seq * nh + h) * S + qi[qb]] : INFINITY;   // beyond the sequence: p = exp2(-inf) = 0
         // a query row with no allowed key (PAD): the softmax is uniform over the S keys and its LSE is not representable:
-        // take P = 1/S instead of exp(s - lse)
-        padq[qb] = MASKED && ok && L < PAD_LSE;
+        // take P = 1/S instead of exp(s - lse) -- unless its upstream gradient is zero (every PAD row of a training step): then
+        // dS = P (0 - 0) = 0 whatever P is, and the row is treated like one beyond the sequence (p = 0) instead of costing its wave the uniform-row selects
+        const bool pad = MASKED && ok && L < PAD_LSE;
+        if (pad && tile_modes != 0 && nz == 0u) L = INFINITY;
+        padq[qb] = pad && L != INFINITY;
         any_pad = any_pad || padq[qb];
         nlse2[qb] = -L * LOG2E;
     }
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     // masked kernels: ONE body with wave-uniform branches on the tile's mode (three instantiated bodies cost registers: 230 -> 256 + 20 spilled in
     // the dK / dV kernel, 168 -> 206 in the forward kernel)
     auto tile_body = [&](int t, auto nb_c, const int mode) {
-        const bool need_bias = MASKED ? (mode == TILE_GENERAL) : decltype(nb_c)::value;
+        const bool need_bias = mode == TILE_GENERAL;         // (masked kernels; the unmasked ones take nb_c)
         const bool skip = MASKED && mode == TILE_SKIP;       // stage, wait and synchronise only: every weight of the tile is 0 for this wave
         const int b = t & 1;
         if (t + 1 < nt) {
@@ -617,36 +632,48 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
             }
         }
         if (!skip) {
-        f32x4 ds[QB][2];
         bf16x8 dsf[QB][2];
+        // scores, P, dS of the tile (the first two products + the per-score arithmetic).  Masked kernels: instantiated twice under ONE wave-uniform
+        // branch per tile -- with the bias arithmetic (general) and without (every pair allowed); a branch per (key block, query block) site instead cost
+        // 8 scalar branches and ~40 register moves at their joins per tile, more than the bias instructions it skipped
+        auto scores = [&](auto nbs_c) {
+            constexpr bool NB = decltype(nbs_c)::value;
+            f32x4 ds[QB][2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const bf16x8 k0 = row_frag_d(Ks[b], kb * 16, 0, lane), k1 = row_frag_d(Ks[b], kb * 16, 1, lane);
-            const bf16x8 v0 = row_frag_d(Vs[b], kb * 16, 0, lane), v1 = row_frag_d(Vs[b], kb * 16, 1, lane);
-            i32x4 ck = {0, 0, 0, 0};
-            f32x4 nk = {0.f, 0.f, 0.f, 0.f};
-            if (need_bias) {
-                ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
-                nk = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
-            }
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], st, 0, 0, 0);
-                f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp, 0, 0, 0);
-                if (need_bias) add_bias(st, ck, nk, cq[qb]);
-                f32x4 pv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, nlse2[qb]));
-                if (need_bias && wave_pad) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[r] = padq[qb] ? ((ck[r] == CODE_NONE) ? 0.f : inv_S) : pv[r];
+            for (int kb = 0; kb < 4; ++kb) {
+                const bf16x8 k0 = row_frag_d(Ks[b], kb * 16, 0, lane), k1 = row_frag_d(Ks[b], kb * 16, 1, lane);
+                const bf16x8 v0 = row_frag_d(Vs[b], kb * 16, 0, lane), v1 = row_frag_d(Vs[b], kb * 16, 1, lane);
+                i32x4 ck = {0, 0, 0, 0};
+                f32x4 nk = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (NB) {
+                    ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+                    nk = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[qb][kb & 1][r] = pv[r] * (dp[r] - del[qb]);
-                if (kb & 1) dsf[qb][kb >> 1] = pack_acc_pair(ds[qb][0], ds[qb][1]);     // packed pair by pair: 16 fewer live registers
+                for (int qb = 0; qb < QB; ++qb) {
+                    f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], st, 0, 0, 0);
+                    f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp, 0, 0, 0);
+                    if constexpr (NB) add_bias(st, ck, nk, cq[qb]);
+                    f32x4 pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, nlse2[qb]));
+                    if (NB && wave_pad) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = padq[qb] ? ((ck[r] == CODE_NONE) ? 0.f : inv_S) : pv[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[qb][kb & 1][r] = pv[r] * (dp[r] - del[qb]);
+                    if (kb & 1) dsf[qb][kb >> 1] = pack_acc_pair(ds[qb][0], ds[qb][1]);     // packed pair by pair: 16 fewer live registers
+                }
             }
+        };
+        if constexpr (MASKED) {
+            if (need_bias) scores(std::true_type{});
+            else scores(std::false_type{});
+        } else {
+            scores(nb_c);
         }
         // K^T fragments (asm reads, explicit waits: see tr_frag_d_issue), one 32-key half at a time: the second half is requested once
         // the first half's MFMAs are issued and lands under them (its 16 registers are the first half's: 3 waves per SIMD)
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
             for (int db = 0; db < 4; ++db) {
                 const int d = db * 16 + g * 4;
                 f32x4 x = dq[qb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + qi[qb]) % rot_rows) * 32 + d);
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)qi[qb], (int)rot_rows, rot_short) * 32 + d);
                 bf16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; cs[db][r] += (float)v[r]; }
@@ -727,6 +754,8 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
+    const bool rot_short = rot_rows < S;
 
     bf16x8 kf[KB][2], vf[KB][2];
     int64_t ki[KB];
@@ -788,10 +817,12 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     auto side_load = [&](int64_t q0) {        // wave 0 (tid < TK) stages the 64 queries' scalars
         if (tid < TK) {
             const bool ok = q0 + tid < S;
-            const float L = ok ? Lg[q0 + tid] : INFINITY;
-            const bool pad = MASKED && ok && L < PAD_LSE;
-            lr = -L * LOG2E;
+            float L = ok ? Lg[q0 + tid] : INFINITY;
             er = ok ? Eg[q0 + tid] : 0.f;
+            // a PAD row whose upstream gradient is zero (marked delta = -0.0 by the dQ kernel) weighs nothing in dK / dV: an absent row (p = 0), see there
+            bool pad = MASKED && ok && L < PAD_LSE;
+            if (pad && tile_modes != 0 && __float_as_uint(er) == 0x80000000u) { pad = false; L = INFINITY; }
+            lr = -L * LOG2E;
             int c = ok ? (MASKED ? code_seq[q0 + tid] : 0) : CODE_PADQ;
             cr = (c < 0) ? CODE_PADQ : c;
             ur = pad ? inv_S : 0.f;
@@ -831,52 +862,58 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         const bool tile_pad = MASKED && !FAST && Fs[b] != 0;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-            f32x4 pp[KB][2], ds[KB][2];
+            // this half-tile's P and dS (32 queries) go straight into dV^T / dK^T: only one half's fragments are ever live
+            bf16x8 pf[KB], dsf[KB];
+            // S, dP, P, dS of the half-tile.  Masked kernels: instantiated twice under ONE wave-uniform branch -- with the code compare / bias add /
+            // uniform-row select (general) and without (every pair of the tile and this wave's keys allowed)
+            auto scores = [&](auto fast_c) {
+                constexpr bool FST = decltype(fast_c)::value;
+                f32x4 pp[KB][2], ds[KB][2];
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int qb = 2 * t2 + q2;
-                const bf16x8 q0f = row_frag_d(Qs[b], qb * 16, 0, lane), q1f = row_frag_d(Qs[b], qb * 16, 1, lane);
-                const bf16x8 d0f = row_frag_d(Ds[b], qb * 16, 0, lane), d1f = row_frag_d(Ds[b], qb * 16, 1, lane);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
-                const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
-                i32x4 c4 = {0, 0, 0, 0};
-                if (MASKED && !FAST) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);       // (wave-uniform branch)
-                f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
-                if (tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int qb = 2 * t2 + q2;
+                    const bf16x8 q0f = row_frag_d(Qs[b], qb * 16, 0, lane), q1f = row_frag_d(Qs[b], qb * 16, 1, lane);
+                    const bf16x8 d0f = row_frag_d(Ds[b], qb * 16, 0, lane), d1f = row_frag_d(Ds[b], qb * 16, 1, lane);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
+                    i32x4 c4 = {0, 0, 0, 0};
+                    if (MASKED && !FST) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+                    f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
+                    if (!FST && tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
-                    f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
-                    f32x4 pv;
-                    if (FAST) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], LOG2E, l4[r]));
-                    } else {
+                    for (int kb = 0; kb < KB; ++kb) {
+                        f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
+                        f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
+                        f32x4 pv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // allowed = same code (a PAD key's -1 and a missing key's -2 equal no query code; unmasked: codes are 0,
                             // missing keys -2, missing queries have l4 = -inf)
-                            const float s = (c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                            const float s = (FST || c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
                             pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E, l4[r]));
                         }
-                    }
-                    if (tile_pad) {       // rows without allowed key: uniform over the existing keys
+                        if (!FST && tile_pad) {       // rows without allowed key: uniform over the existing keys
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pv[r] = (u4[r] > 0.f) ? u4[r] * unil[kb] : pv[r];
-                    }
-                    pp[kb][q2] = pv;
+                            for (int r = 0; r < 4; ++r) pv[r] = (u4[r] > 0.f) ? u4[r] * unil[kb] : pv[r];
+                        }
+                        pp[kb][q2] = pv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[kb][q2][r] = pv[r] * (dp[r] - e4[r]);
+                        for (int r = 0; r < 4; ++r) ds[kb][q2][r] = pv[r] * (dp[r] - e4[r]);
+                    }
                 }
-            }
-            // this half-tile's P and dS (32 queries) go straight into dV^T / dK^T: only one half's fragments are ever live
-            bf16x8 pf[KB], dsf[KB];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                pf[kb] = pack_acc_pair(pp[kb][0], pp[kb][1]);
-                dsf[kb] = pack_acc_pair(ds[kb][0], ds[kb][1]);
+                for (int kb = 0; kb < KB; ++kb) {
+                    pf[kb] = pack_acc_pair(pp[kb][0], pp[kb][1]);
+                    dsf[kb] = pack_acc_pair(ds[kb][0], ds[kb][1]);
+                }
+            };
+            if constexpr (MASKED) {
+                if (FAST) scores(std::true_type{});
+                else scores(std::false_type{});
+            } else {
+                scores(std::false_type{});
             }
             // dO^T / Q^T fragments of this half-tile (asm reads, explicit waits: see tr_frag_d_issue): dims 0-31 and 32-63 as two
             // groups of 8 reads, the second landing under the first's MFMAs
@@ -921,7 +958,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
             for (int db = 0; db < 4; ++db) {
                 const int d = db * 16 + g * 4;
                 f32x4 x = dk[kb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + ki[kb]) % rot_rows) * 32 + d);
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)ki[kb], (int)rot_rows, rot_short) * 32 + d);
                 bf16x4 a, c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -977,6 +1014,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
+    const bool rot_short = rot_rows < S;
 
     // ---- this wave's keys: K / 8 and V fragments, codes ----
     bf16x8 kf[2][2], vf[2][2];
@@ -1069,6 +1108,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     f32x4 csq = {0.f, 0.f, 0.f, 0.f};
     auto dq_tile = [&](int t, int b) {
         f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // the "rotary" scales of this wave's two query blocks (dims < 32 only: waves with qdb < 2), requested BEFORE the products they are applied
+        // behind: loaded where they are used, the dependent global load sat in front of every tile's stores (~6 us of the ViT launch)
+        f32x4 rv[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
+        if (rot_tab != nullptr && qdb < 2) {
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                int q = t * TK + 16 * (2 * qh + q2) + i;
+                q = q < S ? q : (int)S - 1;
+                rv[q2] = *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, q, (int)rot_rows, rot_short) * 32 + qdb * 16 + g * 4);
+            }
+        }
 #pragma unroll
         for (int ks2 = 0; ks2 < 4; ++ks2) {          // two 32-key steps per group of reads: 12 transposed reads in flight
             s16x4 klo[2], khi[2], slo[2][2], shi[2][2];
@@ -1097,7 +1147,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
             if (q < S) {
                 const int d = qdb * 16 + g * 4;
                 f32x4 x = dq[q2] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + q) % rot_rows) * 32 + d);
+                x *= rv[q2];
                 bf16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; csq[r] += (float)v[r]; }
@@ -1213,7 +1263,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
             for (int db = 0; db < 4; ++db) {
                 const int d = db * 16 + g * 4;
                 f32x4 x = dk[kb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + ((seq * S + ki[kb]) % rot_rows) * 32 + d);
+                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)ki[kb], (int)rot_rows, rot_short) * 32 + d);
                 bf16x4 a, c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1252,6 +1302,250 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
         if (i == 0) *reinterpret_cast<f32x4*>(&red[qh][qdb * 16 + g * 4]) = csq;
         __syncthreads();
         if (tid < 64) prow[h * 64 + tid] = red[0][tid] + red[1][tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ, dK, dV of a SHORT sequence (S <= 32): one WAVE per (sequence, head)
+// The audio (S = 31) and span (S = 16) towers: 2304 (sequence, head) pairs of <= 32 positions each.  On the two-pass kernels a pair was a workgroup of
+// four waves for <= 32 queries -- two of them idle, two barriers per tile, two launches, every operand fetched twice -- and the pair of launches took
+// 33 us against ~14 us of HBM time.  Here a wave owns a pair outright: Q, K and dO are fetched once by LDS-DMA into a region of LDS private to the
+// wave (4 KiB images in the tile format of dma_src; no barrier anywhere, the wave's own vmcnt / lgkmcnt waits order everything), K / 8 and V fragments
+// and the per-query scalars come straight from global memory, and the arithmetic is the one-pass kernel's (attn_bwd1_kernel) for a single 32-query
+// half-tile: S = Q K^T and dP = dO V^T with the key on the lane, P / dS as the B operands of dV^T += dO^T P and dK^T += Q^T dS, dS^T through the
+// wave's LDS region once for dQ^T = K^T dS^T.  40 MFMAs per pair: the kernel is a latency chain per wave, so what matters is that every load of a
+// wave is in flight at once and that a CU holds many waves (16 KiB of LDS and < 128 registers each: 8-10 per CU).
+// Column sums: one partial row per sequence, this head's 64 columns of the q, k and v thirds, written by the wave alone.
+constexpr int SMALL_S = 32;
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const __bf16* __restrict__ qkv, const int32_t* __restrict__ code,
+                                                                const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
+                                                                const float* __restrict__ lse, __bf16* __restrict__ dqkv,
+                                                                const float* __restrict__ rot_tab, int64_t rot_rows,
+                                                                float* __restrict__ colsum, int64_t S, int64_t nh, int64_t npairs) {
+    constexpr int IMG = SMALL_S * 128;                                   // [32 rows][64 dims] bf16 in the 128-byte-row tile format
+    __shared__ __attribute__((aligned(16))) char Qs[4][IMG];             // row reads (S) and tr reads (dK^T)
+    __shared__ __attribute__((aligned(16))) char Ks[4][IMG];             // tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) char Ds[4][IMG];             // dO: row reads (dP) and tr reads (dV^T)
+    __shared__ __attribute__((aligned(16))) char dSs[4][IMG];            // dS^T [32 keys][32 queries (64-wide rows)]: tr reads (dQ^T)
+    __shared__ __attribute__((aligned(16))) float Ls[4][SMALL_S], Dl[4][SMALL_S], Us[4][SMALL_S];
+    __shared__ __attribute__((aligned(16))) int32_t Cs[4][SMALL_S];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+    if (pair >= npairs) return;                                          // (wave-uniform; no barrier in this kernel)
+    const int64_t seq = pair / nh, h = pair % nh;
+    const int64_t H = nh * 64, ld = 3 * H;
+    const __bf16* base = qkv + seq * S * ld;
+    const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
+    const float inv_S = 1.0f / (float)S;
+    const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;
+    const bool rot_short = rot_rows < S;
+    char* const qs = Qs[wave];
+    char* const ks = Ks[wave];
+    char* const dsm = Ds[wave];
+    char* const dss = dSs[wave];
+
+    // ---- everything this wave reads, requested at once: Q, K, dO images by LDS-DMA (4 pieces of 8 rows each; rows past S are beyond the
+    // descriptors' extent: zeros), K / 8 and V fragments, the per-query scalars ----
+    const __bf16* Qg = base + h * 64;
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Dg = dout + seq * S * H + h * 64;
+    const __bf16* Og = o + seq * S * H + h * 64;
+    const float* Lg = lse + (seq * nh + h) * S;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Dg), 0, (int)(((S - 1) * H + 64) * 2), 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qs + p * 1024), 16, dma_src(p, lane, ld), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, ks + p * 1024), 16, dma_src(p, lane, ld), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dsm + p * 1024), 16, dma_src(p, lane, H), 0, 0, 0);
+    }
+    bf16x8 kf[2][2], vf[2][2];
+    int ki[2], ck[2];
+    float nkl[2], unil[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        ki[kb] = kb * 16 + i;
+        const bool ok = ki[kb] < S;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+            if (ok) {
+                v = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
+                w = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
+            }
+            kf[kb][dd] = scale_eighth(v);
+            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
+        }
+        ck[kb] = ok ? (MASKED ? code_seq[ki[kb]] : 0) : CODE_NONE;
+        nkl[kb] = ok ? NEG_BIAS : -INFINITY;
+        unil[kb] = ok ? 1.0f : 0.0f;
+    }
+    {   // per-query scalars: lane (q = lane >> 1, half = lane & 1) holds 32 dims of dO and O -> delta = rowsum(dO * O); the even lane stores
+        const int q = lane >> 1, hf = lane & 1;
+        const bool ok = q < S;
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+            if (ok) {
+                a = *reinterpret_cast<const u32x4*>(Dg + (int64_t)q * H + hf * 32 + c * 8);
+                bb = *reinterpret_cast<const u32x4*>(Og + (int64_t)q * H + hf * 32 + c * 8);
+            }
+            float x[8], y[8];
+            unpack8(a, x);
+            unpack8(bb, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum += x[e] * y[e];
+        }
+        dsum += __shfl_xor(dsum, 1, 64);
+        const float L = ok ? Lg[q] : INFINITY;
+        const bool pad = MASKED && ok && L < PAD_LSE;
+        int c = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
+        if (hf == 0) {
+            Ls[wave][q] = -L * LOG2E;
+            Dl[wave][q] = dsum;
+            Cs[wave][q] = (c < 0) ? CODE_PADQ : c;
+            Us[wave][q] = pad ? inv_S : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the wave's images have landed, its scalars are stored
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- S, dP, P, dS of the 32 x 32 block; dS^T -> the wave's LDS region ----
+    const bool keys_inside = !MASKED && SMALL_S <= S;
+    bf16x4 pb[2][2], sb[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const bf16x8 q0f = row_frag_d(qs, qb * 16, 0, lane), q1f = row_frag_d(qs, qb * 16, 1, lane);
+        const bf16x8 d0f = row_frag_d(dsm, qb * 16, 0, lane), d1f = row_frag_d(dsm, qb * 16, 1, lane);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[wave][qb * 16 + g * 4]);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[wave][qb * 16 + g * 4]);
+        const i32x4 c4 = *reinterpret_cast<const i32x4*>(&Cs[wave][qb * 16 + g * 4]);
+        f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
+        if (MASKED) u4 = *reinterpret_cast<const f32x4*>(&Us[wave][qb * 16 + g * 4]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb][1], st, 0, 0, 0);
+            f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[kb][1], dp, 0, 0, 0);
+            f32x4 pv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // allowed = same code (a PAD key's -1 and a missing key's -2 equal no query code; unmasked: codes are 0, missing keys -2, a
+                // missing query has l4 = -inf: p = 0)
+                const float sc = (keys_inside || c4[r] == ck[kb]) ? st[r] : st[r] + nkl[kb];
+                pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, LOG2E, l4[r]));
+            }
+            if (MASKED) {         // rows without allowed key (PAD queries): uniform weight 1 / S over the existing keys
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = (u4[r] > 0.f) ? u4[r] * unil[kb] : pv[r];
+            }
+            bf16x4 p4, w4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p4[r] = (__bf16)pv[r]; w4[r] = (__bf16)(pv[r] * (dp[r] - e4[r])); }
+            pb[kb][qb] = p4;
+            sb[kb][qb] = w4;
+            {   // dS^T: key row 16 kb + i, queries 16 qb + 4 g .. + 3 (8 bytes), in the images' swizzled format
+                const int row = 16 * kb + i, col = 16 * qb + 4 * g;
+                char* dst = dss + row * 128 + (((col >> 3) ^ dswz(row)) << 4) + (col & 7) * 2;
+                *reinterpret_cast<bf16x4*>(dst) = w4;
+            }
+        }
+    }
+    // ---- dV^T += dO^T P, dK^T += Q^T dS over the 32 queries (one k-step) ----
+    f32x4 dk[2][4], dv[2][4];
+    {
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            pf[kb] = __builtin_shufflevector(pb[kb][0], pb[kb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            dsf[kb] = __builtin_shufflevector(sb[kb][0], sb[kb][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            tr_frag_d_issue(dsm, 0, 16 * db, lane, dlo[db], dhi[db]);
+            tr_frag_d_issue(qs, 0, 16 * db, lane, qlo[db], qhi[db]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (also: the dS^T stores above are out)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 dot = tr_join(dlo[db], dhi[db]);
+            const bf16x8 qt = tr_join(qlo[db], qhi[db]);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                dv[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+        }
+    }
+    // ---- dQ^T = K^T dS^T over the 32 keys (one k-step): all four 16-dim blocks, both query blocks ----
+    f32x4 dq[2][4];
+    {
+        s16x4 klo[4], khi[4], slo[2], shi[2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) tr_frag_d_issue(ks, 0, 16 * db, lane, klo[db], khi[db]);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) tr_frag_d_issue(dss, 0, 16 * qb, lane, slo[qb], shi[qb]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 kt = tr_join(klo[db], khi[db]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+                dq[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, tr_join(slo[qb], shi[qb]), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+    // ---- stores: the lane holds [d = 16 db + 4 g + r][position i] of each 16-position block; column sums over the positions ----
+    f32x4 csq[4], csk[4], csv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { csq[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int pbk = 0; pbk < 2; ++pbk) {
+        const int pos = pbk * 16 + i;
+        if (pos < S) {
+            const int rr = rot_tab != nullptr ? rot_row_index(seq_rot0, pos, (int)rot_rows, rot_short) : 0;
+            __bf16* row = dqkv + (seq * S + pos) * ld + h * 64;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int d = db * 16 + g * 4;
+                f32x4 xq = dq[pbk][db] * 0.125f, xk = dk[pbk][db] * 0.125f;
+                if (rot_tab != nullptr && d < 32) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rr * 32 + d);
+                    xq *= tv;
+                    xk *= tv;
+                }
+                bf16x4 a, b, c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[r] = (__bf16)xq[r]; b[r] = (__bf16)xk[r]; c[r] = (__bf16)dv[pbk][db][r];
+                    csq[db][r] += (float)a[r]; csk[db][r] += (float)b[r]; csv[db][r] += (float)c[r];
+                }
+                *reinterpret_cast<bf16x4*>(row + d) = a;
+                *reinterpret_cast<bf16x4*>(row + H + d) = b;
+                *reinterpret_cast<bf16x4*>(row + 2 * H + d) = c;
+            }
+        }
+    }
+    if (colsum != nullptr) {      // wave-uniform: ONE partial row per sequence; this head's 64 columns of q, k, v
+        float* prow = colsum + seq * ld + h * 64;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { csq[db][r] = row16_sum(csq[db][r]); csk[db][r] = row16_sum(csk[db][r]); csv[db][r] = row16_sum(csv[db][r]); }
+            if (i == 0) {
+                *reinterpret_cast<f32x4*>(prow + db * 16 + g * 4) = csq[db];
+                *reinterpret_cast<f32x4*>(prow + H + db * 16 + g * 4) = csk[db];
+                *reinterpret_cast<f32x4*>(prow + 2 * H + db * 16 + g * 4) = csv[db];
+            }
+        }
     }
 }
 
@@ -1294,9 +1588,11 @@ static bool attn_onepass(int64_t S) {
     if (v == 0 || S > KP) return false;
     return v == 1 || S > 128;
 }
+// ... and sequences of at most 32 positions go to the one-wave-per-pair kernel (option "attn_onepass": -1 or 1; 0 = the kernel pair)
+static bool attn_small(int64_t S) { return mr_opts().attn_onepass != 0 && S <= SMALL_S; }
 
 extern "C" int64_t mr_attention_bwd_colsum_rows(int64_t nseq, int64_t S) {
-    if (attn_onepass(S)) return nseq;                                   // one partial row per sequence
+    if (attn_small(S) || attn_onepass(S)) return nseq;                  // one partial row per sequence
     const int64_t per = (S > attn_qb_threshold()) ? 128 : 64;          // queries (keys) per workgroup
     return nseq * ((S + per - 1) / per);
 }
@@ -1313,6 +1609,14 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     const __bf16* d = static_cast<const __bf16*>(dout);
     __bf16* g = static_cast<__bf16*>(dqkv);
     const __bf16* oo = static_cast<const __bf16*>(out);       // delta = rowsum(dO * O) is computed by the dQ kernel (for itself and for dK / dV)
+    if (attn_small(S)) {
+        const int64_t npairs = nh * nseq;
+        const dim3 grid((unsigned)((npairs + 3) / 4));
+        if (code) hipLaunchKernelGGL((attn_bwd_small_kernel<true>), grid, dim3(256), 0, s, q, code, oo, d, lse, g, rot_tab, rot_rows, colsum, S, nh, npairs);
+        else hipLaunchKernelGGL((attn_bwd_small_kernel<false>), grid, dim3(256), 0, s, q, code, oo, d, lse, g, rot_tab, rot_rows, colsum, S, nh, npairs);
+        MR_CHECK_LAUNCH("mr_attention_bwd (short sequences)");
+        return MR_OK;
+    }
     if (attn_onepass(S)) {
         const dim3 grid((unsigned)(nh * nseq));
         if (code) hipLaunchKernelGGL((attn_bwd1_kernel<true>), grid, dim3(512), 0, s, q, code, oo, d, lse, g, rot_tab, rot_rows, colsum, S, nh);

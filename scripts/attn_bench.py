@@ -30,6 +30,7 @@ for name, nseq, S, nh, masked in shapes:
     rows = nseq * ((S + 15) // 16 + 4)
     ws = torch.zeros(rows * 3 * H, device=dev)
     bg = torch.zeros(3 * H, dtype=BF16, device=dev)
+    rot = torch.rand(nseq * S if masked else S, 32, device=dev) * 2 - 1     # the step passes the towers' "rotary" scale tables: per position of the batch (joint) / of a sequence
     ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)
     res = {}
     graphs = {}
@@ -39,7 +40,7 @@ for name, nseq, S, nh, masked in shapes:
         if mode != 'fwd':
             ops.set_option('attn_onepass', mode)
         fn = (lambda: ops.attention_fwd(qkv, code, out, lse, nseq, S, nh)) if mode == 'fwd' else \
-             (lambda: ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, None, nseq, S, nh, colsum_ws=ws, bias_grad=bg, jobs=[]))
+             (lambda: ops.attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot, nseq, S, nh, colsum_ws=ws, bias_grad=bg, jobs=[]))
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             fn(); torch.cuda.synchronize()

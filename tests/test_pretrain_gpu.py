@@ -320,12 +320,14 @@ def test_full_size_forward_parity(dev, case):
     print(f'{case}-size parity: loss fp32 {loss32:.6f} oracle {float(loss):.6f} bf16 {e16.loss_info()["loss"]:.6f}')
 
 
-@pytest.mark.parametrize('case', ['base', 'large', 'base_resadapt', 'large_resadapt_shallow', 'base_resadapt24'])
+@pytest.mark.parametrize('case', ['base_resadapt', 'large_resadapt', 'base_resadapt24'])
 def test_full_size_backward_parity(dev, case):
     """Every parameter gradient of the FULL-width model (one record) for an injected upstream gradient dE against autograd
     of the oracle on the host cores: |d| <= 3e-2 |g| + 6e-3 max|g| and cos >= 0.9995 on every leaf that carries gradient = 3 x
     what is measured (worst relative error on a significant leaf 0.6-1.2e-2, lowest cosine 0.99992; round 2 allowed 8e-2 / 0.995).  base / large: the 256-row GEMM tiles, grouped weight gradients (256 x 256
-    tiles for large, nh = 16) and sequences of 241 / 640; *_resadapt: the flash backward at S = 577 / 1312."""
+    tiles for large, nh = 16) and sequences of 241 / 640; *_resadapt: the flash backward at S = 577 / 1312.  large_resadapt (BASELINE config 4) runs at
+    FULL depth since round 5 (24 / 24 / 12 / 4 layers: the host holds the autograd graph, ~60 GB); the stock large model's backward is checked at the
+    benchmarked B = 4 in tests/test_trainer_fullsize_gpu.py."""
     import os
     from merlot_reserve_amd.config import Dims
     from merlot_reserve_amd.engine import PretrainEngine

@@ -1,6 +1,6 @@
-"""The Trainer at the sizes that are benchmarked.
+"""The Trainer at the sizes that are benchmarked (round 4, item 3c: the large model at B = 4 too).
 
-* base, B = 4 records per GPU (BASELINE config 2: the workload of bench.py's headline): forward x / y tensors and loss, every
+* base and large, B = 4 records per GPU (BASELINE config 2: the workload of bench.py's headline; config 3's per-GPU workload): forward x / y tensors and loss, every
   parameter gradient of an injected dE through the bucketed backward, two optimizer steps leaf by leaf, and hipGraph replays equal
   to eager steps bit for bit -- against the oracle on the host cores.  At B = 4 (M = 15 424 rows) the GEMM dispatcher picks other
   kernels than at the B = 1 of tests/test_pretrain_gpu.py (ping-pong 256 x 256 / 256 x 192 tiles over three rounds of the CUs, two
@@ -35,12 +35,15 @@ def _restore(tr, snap, step):
     tr.state.step = step
 
 
-def test_base_b4_trainer_step_against_oracle(dev):
+@pytest.mark.parametrize('model_name', ['base', 'large'])
+def test_b4_trainer_step_against_oracle(dev, model_name):
+    """base: BASELINE config 2, the headline workload; large: config 3's per-GPU workload (bench.py `secondary.large_b4`) -- both at the
+    benchmarked B = 4 records per GPU."""
     from merlot_reserve_amd.config import load_config
     from merlot_reserve_amd.synthetic import make_batch, make_draws
     from merlot_reserve_amd.trainer import Trainer
     from oracle import ref_torch as R
-    cfg = load_config('base')
+    cfg = load_config(model_name)
     cfg['optimizer'].update(num_warmup_steps=2, learning_rate=1e-3)          # a visible second update (the first is zero: count starts at 0)
     B = 4
     tr = Trainer(cfg, B, dev, seed=0)
@@ -73,7 +76,7 @@ def test_base_b4_trainer_step_against_oracle(dev):
         worst = max(worst, e)
         assert e <= 2e-2, f'B = 4 forward {k}/{k2}: rel err {e:.3e}'
     assert abs(li['loss'] - float(loss)) <= 2e-3 * abs(float(loss)), (li['loss'], float(loss))
-    print(f'base B=4 forward: worst rel-L2 {worst:.3e}; loss {li["loss"]:.5f} vs oracle {float(loss):.5f}')
+    print(f'{model_name} B=4 forward: worst rel-L2 {worst:.3e}; loss {li["loss"]:.5f} vs oracle {float(loss):.5f}')
 
     # ---- (2) every gradient leaf of an injected dE through the Trainer's bucketed backward (no update)
     dE = (torch.randn(eng.R, eng.d.H, generator=g) * 1e-2).to(torch.bfloat16)
@@ -102,11 +105,13 @@ def test_base_b4_trainer_step_against_oracle(dev):
         wabs = max(wabs, err / gmax)
         if err > 2.5e-2 * gn + 5e-3 * gmax or (gn > 5e-2 * gmax and cos < 0.999):
             bad.append((name, err, gn, cos))
-    print(f'base B=4 backward: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]}), lowest cosine {wcos:.6f}, '
+    print(f'{model_name} B=4 backward: {len(leaves)} leaves, worst rel. error on a significant leaf {worst[0]:.3e} ({worst[1]}), lowest cosine {wcos:.6f}, '
           f'worst |d| / max|g| over all leaves {wabs:.3e}')
     assert not bad, bad[:10]
     del leaves, params
 
+    if model_name != 'base':       # (3) and (4) do not depend on the model size beyond what test_large_trainer_capture_replay_equals_eager covers
+        return
     # ---- (3) two optimizer steps on these gradients, leaf by leaf (pretrain/optimization.py:54-114, 180-195)
     before = p.master_tree()
     grads = tree_to(p.grad_tree(), torch.float32)
