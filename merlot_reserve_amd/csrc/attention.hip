@@ -569,13 +569,20 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     bool wq_uniform = false;
     int wq_code = 0;
     if constexpr (MASKED) {
-        wq_code = __builtin_amdgcn_readfirstlane(cq[0]);
+        // the LIVE rows' codes: a row beyond the sequence or a PAD row with a zero upstream gradient has p = exp2(-inf) = 0 under any bias: a wildcard
+        bool live[QB];
+        int first_code = CODE_PADQ - 1;                       // (equals no tile class: a wave without live rows skips every tile)
+#pragma unroll
+        for (int qb = QB - 1; qb >= 0; --qb) {
+            live[qb] = qi[qb] < S && nlse2[qb] != -INFINITY;
+            const unsigned long long bl = __ballot(live[qb]);
+            if (bl != 0ull) first_code = __builtin_amdgcn_readlane(cq[qb], (int)__builtin_ctzll(bl));
+        }
+        wq_code = first_code;
         bool ok = true;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) ok = ok && (qi[qb] >= S || cq[qb] == wq_code);
-        const bool first_inside = q0 + wave * QB * 16 < S;
-        wq_uniform = tile_modes != 0 && (!first_inside || (wq_code >= 0 && !__any(!ok)));
-        if (!first_inside) wq_code = CODE_PADQ - 1;
+        for (int qb = 0; qb < QB; ++qb) ok = ok && (!live[qb] || cq[qb] == wq_code);
+        wq_uniform = tile_modes != 0 && (wq_code >= 0 || wq_code == CODE_PADQ - 1) && !__any(!ok);
     }
     f32x4 dq[QB][4];
 #pragma unroll
@@ -827,11 +834,15 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
             cr = (c < 0) ? CODE_PADQ : c;
             ur = pad ? inv_S : 0.f;
             fr = MASKED ? (int)__any(pad) : 0;
-            if (MASKED) {                     // a tile with a PAD (or missing) query is never uniform: PAD rows weigh EVERY key
-                qur = tile_class(cr, true);
-                if (qur < 0) qur = CODE_MIXED;
-                // ... unless every row of the tile is beyond the sequence or marked by the dQ kernel as having a zero upstream gradient
-                // (delta = -0.0): such a tile contributes exactly nothing to dK / dV and is skipped by every wave
+            if (MASKED) {
+                // the tile's class over its LIVE rows: a row beyond the sequence or a PAD row with a zero upstream gradient has lr = -inf, i.e. p = 0
+                // under any bias -- a wildcard; a live PAD row weighs EVERY key: never uniform
+                const bool live = lr != -INFINITY;
+                const unsigned long long bl = __ballot(live);
+                const int c0 = bl != 0ull ? __builtin_amdgcn_readlane(cr, (int)__builtin_ctzll(bl)) : 0;
+                qur = (tile_modes == 0 || c0 < 0 || __any(live && cr != c0)) ? CODE_MIXED : c0;
+                // every row of the tile beyond the sequence or marked by the dQ kernel as having a zero upstream gradient (delta = -0.0): such a
+                // tile contributes exactly nothing to dK / dV and is skipped by every wave
                 if (tile_modes != 0 && !__any(ok && __float_as_uint(er) != 0x80000000u)) qur = CODE_DEAD;
             }
         }
