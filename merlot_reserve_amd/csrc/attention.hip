@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     __shared__ __attribute__((aligned(16))) char dSs[2][4][TILE_B];      // dS^T: [64 keys][64 queries] images, tr reads (dQ^T)
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
-    __shared__ __attribute__((aligned(16))) float red[8][64];
+    __shared__ __attribute__((aligned(16))) float red[8][192];          // column-sum partials: [wave][q | k | v third][64]
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block(1, (int)nh);
@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    MR_ASTAMP_WG(0);
     const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
     const bool rot_short = rot_rows < S;
 
@@ -1038,13 +1039,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
         const bool ok = ki[kb] < S;
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
-            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
-            if (ok) {
-                v = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
-                w = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
-            }
-            kf[kb][dd] = scale_eighth(v);
-            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (ok) w = *reinterpret_cast<const u32x4*>(base + (int64_t)ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
+            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);          // (kf: from the K images in LDS, below -- K is fetched once)
         }
         ck[kb] = ok ? (MASKED ? code_seq[ki[kb]] : 0) : CODE_NONE;
         nkl[kb] = ok ? NEG_BIAS : -INFINITY;
@@ -1077,19 +1074,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     };
     // per-query scalars of a tile: thread (q = tid >> 3, c = tid & 7) holds 8 dims of dO and O -> delta = rowsum(dO * O) over the 8
     // lanes of a query; lane c == 0 also fetches the query's lse and code
+    // (two steps: the loads are issued at the top of a tile, the arithmetic on them runs at its end -- as one step the wave sat ~1 500 cycles at the
+    // top of every tile waiting for these global loads: stamps)
     float er = 0.f, lr = 0.f, ur = 0.f;
     int cr = 0;
-    auto side_load = [&](int64_t q0) {
+    u32x4 s_a = {0u, 0u, 0u, 0u}, s_b = {0u, 0u, 0u, 0u};
+    float s_L = INFINITY;
+    int s_c = CODE_PADQ;
+    auto side_issue = [&](int64_t q0) {
         const int64_t q = q0 + (tid >> 3);
         const bool ok = q < S;
-        u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+        s_a = u32x4{0u, 0u, 0u, 0u};
+        s_b = u32x4{0u, 0u, 0u, 0u};
         if (ok) {
-            a = *reinterpret_cast<const u32x4*>(Dg + q * H + (tid & 7) * 8);
-            bb = *reinterpret_cast<const u32x4*>(Og + q * H + (tid & 7) * 8);
+            s_a = *reinterpret_cast<const u32x4*>(Dg + q * H + (tid & 7) * 8);
+            s_b = *reinterpret_cast<const u32x4*>(Og + q * H + (tid & 7) * 8);
         }
+        s_L = ok ? Lg[q] : INFINITY;
+        s_c = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
+    };
+    auto side_compute = [&]() {
         float x[8], y[8];
-        unpack8(a, x);
-        unpack8(bb, y);
+        unpack8(s_a, x);
+        unpack8(s_b, y);
         float dsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum += x[e] * y[e];
@@ -1097,21 +1104,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
         dsum += __shfl_xor(dsum, 2, 64);
         dsum += __shfl_xor(dsum, 4, 64);
         er = dsum;
-        const float L = ok ? Lg[q] : INFINITY;
-        const bool pad = MASKED && ok && L < PAD_LSE;
-        lr = -L * LOG2E;
-        int c = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
-        cr = (c < 0) ? CODE_PADQ : c;
+        const bool pad = MASKED && s_L != INFINITY && s_L < PAD_LSE;
+        lr = -s_L * LOG2E;
+        cr = (s_c < 0) ? CODE_PADQ : s_c;
         ur = pad ? inv_S : 0.f;
     };
     auto side_store = [&](int b) {
         if ((tid & 7) == 0) { const int q = tid >> 3; Ls[b][q] = lr; Dl[b][q] = er; Cs[b][q] = cr; Us[b][q] = ur; }
     };
     stage(0, 0);
-    side_load(0);
+    side_issue(0);
+    side_compute();
     side_store(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // this wave's K / 8 fragments from the staged images (rows past the sequence are zeros there): the prologue of every workgroup of a round runs
+    // at once and is bound by the bytes it requests (~11 B / clk / CU: stamps, scripts/attn_bwd1_stamps.py); K came twice, 31 of its 117 KB
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+            kf[kb][dd] = scale_eighth(__builtin_bit_cast(u32x4, row_frag_d(Kt[wave >> 1], (wave & 1) * 32 + kb * 16, dd, lane)));
 
     const bool keys_inside = !MASKED && 32 * wave + 32 <= S;
     // dQ^T of one tile: wave (db = wave & 3, query half wave >> 2) over all 256 keys
@@ -1170,11 +1183,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     const int nt = (int)((S + TK - 1) / TK);
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
+        MR_ASTAMP(0);
         if (t + 1 < nt) {
             stage(t + 1, b ^ 1);
-            side_load((int64_t)(t + 1) * TK);
+            side_issue((int64_t)(t + 1) * TK);
         }
+        MR_ASTAMP(1);
         if (t > 0) dq_tile(t - 1, b ^ 1);
+        MR_ASTAMP(2);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             // P and dS of this 32-query half, rounded to bf16 as soon as they exist (they are MFMA operands and the LDS payload as bf16
@@ -1256,64 +1272,85 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
                     dk[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[kb][db], 0, 0, 0);
                 }
             }
+            MR_ASTAMP(3 + t2);
         }
-        if (t + 1 < nt) side_store(b ^ 1);
+        if (t + 1 < nt) { side_compute(); side_store(b ^ 1); }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 1 have landed; its dS stores are out
+        MR_ASTAMP(5);
         __syncthreads();
+        MR_ASTAMP(6);
     }
+    { const int t = 13; MR_ASTAMP(0); }
     dq_tile(nt - 1, (nt - 1) & 1);
+    { const int t = 13; MR_ASTAMP(1); }
 
-    // ---- dK / dV of this wave's 32 keys (as in the two-pass kernel) + the column sums of everything this workgroup stored ----
+    // ---- dK / dV of this wave's 32 keys + the column sums of everything this workgroup stored ----
+    // The lane holds [d = 16 db + 4 g + r][key i]: stored from there, a wave instruction wrote 16 rows x 32 bytes -- 16 partial lines -- and the 16 such
+    // stores per lane took 7 900 cycles of a 61 000-cycle workgroup (stamps).  The tile goes through the wave's share of the Q / dO buffers instead (free
+    // since the loop's last barrier; [32 keys][128 B], 16-byte chunk c of row r at slot c ^ (r & 7)) and leaves as whole 128-byte rows, 16 bytes per lane.
     f32x4 csk[4], csv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { csk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    char* const stg = (wave < 4 ? &Qs[0][0] : &Ds[0][0]) + (wave & 3) * 4096;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        if (ki[kb] < S) {
+    for (int part = 0; part < 2; ++part) {           // 0: dK (x 1/8, x "rotary" scale), 1: dV
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bool ok = ki[kb] < S;
+            const int row = kb * 16 + i;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const int d = db * 16 + g * 4;
-                f32x4 x = dk[kb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)ki[kb], (int)rot_rows, rot_short) * 32 + d);
-                bf16x4 a, c;
+                f32x4 x = part ? dv[kb][db] : dk[kb][db] * 0.125f;
+                if (part == 0 && rot_tab != nullptr && d < 32 && ok)
+                    x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, ki[kb], (int)rot_rows, rot_short) * 32 + d);
+                bf16x4 a;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r];
-                    csk[db][r] += (float)a[r]; csv[db][r] += (float)c[r];
+                    a[r] = (__bf16)x[r];
+                    if (ok) { if (part) csv[db][r] += (float)a[r]; else csk[db][r] += (float)a[r]; }
                 }
-                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + H + h * 64 + d) = a;
-                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + 2 * H + h * 64 + d) = c;
+                *reinterpret_cast<bf16x4*>(stg + row * 128 + (((db * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = a;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int key = wave * 32 + row;
+            if (key < S) *reinterpret_cast<u32x4*>(dqkv + (seq * S + key) * ld + (1 + part) * H + h * 64 + ch * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the reads are done before the next part overwrites the region
     }
+    { const int t = 13; MR_ASTAMP(2); }
     if (colsum != nullptr) {      // wave-uniform: ONE partial row per sequence; this head's 64 columns of q, k, v
         float* prow = colsum + seq * ld;
-        // k and v: every wave holds all 64 dims for its keys -> sum over the 16 lanes of a DPP row, then over the 8 waves
+        // k and v: every wave holds all 64 dims for its keys -> sum over the 16 lanes of a DPP row, then over the 8 waves; q: wave (qdb, qh) holds
+        // dims 16 qdb + 4 g .. + 3 for its query half.  All three thirds go to LDS behind ONE barrier (three rounds of write / barrier / sum / barrier
+        // were 4 750 cycles of the workgroup's 54 600: stamps)
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            f32x4 (&cs)[4] = part ? csv : csk;
+        for (int db = 0; db < 4; ++db) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cs[db][r] = row16_sum(cs[db][r]);
-                if (i == 0) *reinterpret_cast<f32x4*>(&red[wave][db * 16 + g * 4]) = cs[db];
+            for (int r = 0; r < 4; ++r) { csk[db][r] = row16_sum(csk[db][r]); csv[db][r] = row16_sum(csv[db][r]); }
+            if (i == 0) {
+                *reinterpret_cast<f32x4*>(&red[wave][64 + db * 16 + g * 4]) = csk[db];
+                *reinterpret_cast<f32x4*>(&red[wave][128 + db * 16 + g * 4]) = csv[db];
             }
-            __syncthreads();
-            if (tid < 64) {
-                float sum = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) sum += red[w][tid];
-                prow[(1 + part) * H + h * 64 + tid] = sum;
-            }
-            __syncthreads();
         }
-        // q: wave (qdb, qh) holds dims 16 qdb + 4 g .. + 3 for its query half
 #pragma unroll
         for (int r = 0; r < 4; ++r) csq[r] = row16_sum(csq[r]);
         if (i == 0) *reinterpret_cast<f32x4*>(&red[qh][qdb * 16 + g * 4]) = csq;
         __syncthreads();
         if (tid < 64) prow[h * 64 + tid] = red[0][tid] + red[1][tid];
+        else if (tid < 192) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[w][tid];
+            prow[(tid >> 6) * H + h * 64 + (tid & 63)] = sum;
+        }
     }
+    MR_ASTAMP_WG(1);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ, dK, dV of a SHORT sequence (S <= 32): one WAVE per (sequence, head)

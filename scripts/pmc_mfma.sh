@@ -31,10 +31,10 @@ SIMDS = 256 * 4
 for k, a in agg.items():
     ns = a['_ns']
     if ns <= 0: continue
-    # clock of the profiled run from GRBM_GUI_ACTIVE (summed over the 8 XCDs; MI355X_MICROARCH.md, DVFS note)
-    ghz = a.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / ns if ns else 0.0
+    # (no clock figure: GRBM_GUI_ACTIVE / 8 / time reads 3-4 GHz on these sub-0.3-ms dispatches -- MI355X_MICROARCH.md, DVFS note: the quotient is only
+    # usable for dispatches of ~10 ms; the utilisation ratios below are cycle / cycle and unaffected)
     mfma_busy = a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
-    res[k] = {'launches': int(a['_launches']), 'ms_total': ns / 1e6, 'clock_ghz': round(ghz, 3),
+    res[k] = {'launches': int(a['_launches']), 'ms_total': ns / 1e6,
               # busy cycles of the matrix pipes / (SIMDs x elapsed cycles): the fraction of the chip's MFMA issue slots in use
               'mfma_pipe_util': round(mfma_busy / (SIMDS * a.get('GRBM_GUI_ACTIVE', 1.0) / 8.0), 4) if a.get('GRBM_GUI_ACTIVE') else None,
               'mfma_tflops_executed': round(a.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.0) * 512 / ns / 1e3, 1),
@@ -49,5 +49,5 @@ python3 - <<PY
 import json
 d = json.load(open('$out/pmc_mfma_$tag.json'))['kernels']
 for k, v in sorted(d.items(), key=lambda kv: -kv[1]['ms_total'])[:14]:
-    print(f"{k[:60]:60s} ms={v['ms_total']:8.2f} util={v['mfma_pipe_util']} TF/s={v['mfma_tflops_executed']} clk={v['clock_ghz']} wait={v['wave_cycles_waiting_frac']}")
+    print(f"{k[:60]:60s} ms={v['ms_total']:8.2f} util={v['mfma_pipe_util']} TF/s={v['mfma_tflops_executed']} wait={v['wave_cycles_waiting_frac']}")
 PY
