@@ -206,6 +206,30 @@ __device__ __forceinline__ int rot_row_index(int seq_rot0, int pos, int rot_rows
     return r >= rot_rows ? r - rot_rows : r;
 }
 
+// A wave's [16 NB rows][64 dims] bf16 tile, held as the MFMA leaves it (lane: dims 16 db + 4 g .. + 3 of row 16 nb + i), to global memory as WHOLE
+// 128-byte rows, 16 bytes per lane, through a 2 NB KiB LDS region private to the wave ([row][128 B], 16-byte chunk c of row r at slot c ^ (r & 7)).  Stored
+// straight from the MFMA layout a wave instruction wrote 16 rows x 32 bytes -- 16 partial lines: 7 900 of the one-pass backward's 61 000 cycles per
+// workgroup (scripts/attn_bwd1_stamps.py).  Row `row0 + r` goes to gdst + r * ld (elements) if it is < n_rows.  No barrier: the wave's own waits order it.
+template <int NB>
+__device__ __forceinline__ void store_rows_via_lds(char* stg, const bf16x4 (&v)[NB][4], __bf16* gdst, int64_t ld, int row0, int64_t n_rows, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = nb * 16 + i;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+            *reinterpret_cast<bf16x4*>(stg + row * 128 + (((db * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = v[nb][db];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2 * NB; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+        if (row0 + row < n_rows) *reinterpret_cast<u32x4*>(gdst + (int64_t)row * ld + ch * 8) = w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the reads are done before the region is written again
+}
+
 // XCD-aware block order.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, so with the plain
 // (block, head, sequence) grid the query blocks of ONE (sequence, head) -- which all stream the same K / V rows -- landed
 // on different XCDs and every XCD's L2 fetched those rows for itself (rocprofv3 FETCH_SIZE: 3.7x the algorithmic bytes
@@ -716,18 +740,36 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     f32x4 cs[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) cs[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (MASKED || QB == 1) {   // whole rows through the wave's share of the K buffers (free since the loop's last barrier)
+        bf16x4 ov[QB][4];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        if (qi[qb] < S) {
+        for (int qb = 0; qb < QB; ++qb) {
+            const bool ok = qi[qb] < S;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const int d = db * 16 + g * 4;
                 f32x4 x = dq[qb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)qi[qb], (int)rot_rows, rot_short) * 32 + d);
-                bf16x4 v;
+                if (rot_tab != nullptr && d < 32 && ok) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)qi[qb], (int)rot_rows, rot_short) * 32 + d);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; cs[db][r] += (float)v[r]; }
-                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + qi[qb]) * ld + h * 64 + d) = v;
+                for (int r = 0; r < 4; ++r) { ov[qb][db][r] = (__bf16)x[r]; if (ok) cs[db][r] += (float)ov[qb][db][r]; }
+            }
+        }
+        const int row0 = (int)q0 + wave * QB * 16;
+        store_rows_via_lds<QB>(&Ks[0][0] + wave * (QB * 2048), ov, dqkv + (seq * S + row0) * ld + h * 64, ld, row0, S, lane);
+    } else {                             // (the unmasked two-block instance sits at its register limit: with the staging it spilled into its MFMA blocks)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (qi[qb] < S) {
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const int d = db * 16 + g * 4;
+                    f32x4 x = dq[qb][db] * 0.125f;
+                    if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)qi[qb], (int)rot_rows, rot_short) * 32 + d);
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = (__bf16)x[r]; cs[db][r] += (float)v[r]; }
+                    *reinterpret_cast<bf16x4*>(dqkv + (seq * S + qi[qb]) * ld + h * 64 + d) = v;
+                }
             }
         }
     }
@@ -957,29 +999,33 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     }
-    // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i]: 8-byte stores.  dK: the 1/8 folded into kf was on the OTHER operand
-    // of S = q . (k/8), so d(score)/dk = q / 8 still has to be applied here.
+    // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i].  dK: the 1/8 folded into kf was on the OTHER operand of S = q . (k/8), so
+    // d(score)/dk = q / 8 still has to be applied here.  Both tiles leave as whole rows through the wave's share of the Q / dO buffers (free since the
+    // loop's last barrier): store_rows_via_lds.
     f32x4 csk[4], csv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { csk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; csv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bf16x4 ok_[KB][4], ov_[KB][4];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        if (ki[kb] < S) {
+        const bool ok = ki[kb] < S;
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const int d = db * 16 + g * 4;
-                f32x4 x = dk[kb][db] * 0.125f;
-                if (rot_tab != nullptr && d < 32) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)ki[kb], (int)rot_rows, rot_short) * 32 + d);
-                bf16x4 a, c;
+        for (int db = 0; db < 4; ++db) {
+            const int d = db * 16 + g * 4;
+            f32x4 x = dk[kb][db] * 0.125f;
+            if (rot_tab != nullptr && d < 32 && ok) x *= *reinterpret_cast<const f32x4*>(rot_tab + (int64_t)rot_row_index(seq_rot0, (int)ki[kb], (int)rot_rows, rot_short) * 32 + d);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a[r] = (__bf16)x[r]; c[r] = (__bf16)dv[kb][db][r];
-                    csk[db][r] += (float)a[r]; csv[db][r] += (float)c[r];
-                }
-                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + H + h * 64 + d) = a;
-                *reinterpret_cast<bf16x4*>(dqkv + (seq * S + ki[kb]) * ld + 2 * H + h * 64 + d) = c;
+            for (int r = 0; r < 4; ++r) {
+                ok_[kb][db][r] = (__bf16)x[r]; ov_[kb][db][r] = (__bf16)dv[kb][db][r];
+                if (ok) { csk[db][r] += (float)ok_[kb][db][r]; csv[db][r] += (float)ov_[kb][db][r]; }
             }
         }
+    }
+    {
+        const int row0 = (int)kbase + wave * KB * 16;
+        __bf16* grow = dqkv + (seq * S + row0) * ld + h * 64;
+        store_rows_via_lds<KB>(&Qs[0][0] + wave * (KB * 2048), ok_, grow + H, ld, row0, S, lane);
+        store_rows_via_lds<KB>(&Ds[0][0] + wave * (KB * 2048), ov_, grow + 2 * H, ld, row0, S, lane);
     }
     if (colsum != nullptr) {      // wave-uniform: partial row (sequence, key block), columns of this head's k and v
         float* prow = colsum + (seq * ((S + 64 * KB - 1) / (64 * KB)) + ab_.blk) * ld;

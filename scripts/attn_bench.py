@@ -6,7 +6,8 @@ from merlot_reserve_amd import ops
 dev = torch.device('cuda:0')
 BF16 = torch.bfloat16
 shapes = [('base ViT', 64, 241, 12, False), ('large ViT', 64, 241, 16, False), ('base joint', 24, 640, 12, True), ('large joint', 24, 640, 16, True), ('audio', 192, 31, 12, False),
-          ('span', 192, 16, 12, True), ('S=200 masked', 64, 200, 12, True), ('S=256', 64, 256, 12, False), ('S=130', 64, 130, 12, False)]
+          ('span', 192, 16, 12, True), ('S=200 masked', 64, 200, 12, True), ('S=256', 64, 256, 12, False), ('S=130', 64, 130, 12, False),
+          ('resadapt ViT', 32, 577, 16, False), ('resadapt joint', 12, 1312, 16, True), ('VCR joint', 32, 288, 16, True)]
 for name, nseq, S, nh, masked in shapes:
     H = nh * 64
     g = torch.Generator().manual_seed(0)
@@ -15,10 +16,10 @@ for name, nseq, S, nh, masked in shapes:
     code = None
     if masked:
         c = torch.zeros(nseq, S, dtype=torch.int32)
-        if S == 640:      # the run structure of the bench batch's joint sequences (planner.joint_code: ~18 % PAD in one gap or tail per sequence)
+        if S in (640, 1312):      # the run structure of the bench batch's joint sequences (planner.joint_code: ~18 % PAD in one gap or tail per sequence)
             for q in range(nseq):
                 a, n = [(108, 52), (89, 71), (527, 113), (485, 155), (58, 102), (58, 102)][q % 6]
-                c[q, a:a + n] = -1
+                c[q, a * S // 640:(a + n) * S // 640] = -1
         else:
             c[:, S // 6:S // 6 + S // 10] = -1
         code = c.reshape(-1).to(dev)

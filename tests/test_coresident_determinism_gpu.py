@@ -3,7 +3,7 @@
 Round 3 found LayerNorm rows that changed from run to run while a second stream was active; round 4 reduced it to this (scripts/slp_repro.py): code
 the SLP vectoriser packed into v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers returns wrong values in lanes 48-63 of a wave WHILE
 waves of an MFMA kernel (the 128 x 128 small-GEMM kernel: few, small workgroups) share its SIMD -- never alone, never beside whole-CU GEMMs, never in a
-scalar (-fno-slp-vectorize) build.  The HBM-bound files are built scalar (merlot_reserve_amd/build.py); the GEMM files keep packed epilogues (3.2 ms of
+scalar (-fno-slp-vectorize) build.  Round 5: a second neighbour, the attention kernels' MFMA waves, alternates with it.  The HBM-bound files are built scalar (merlot_reserve_amd/build.py); the GEMM files keep packed epilogues (3.2 ms of
 the step), so this test holds EVERY kernel family with vector epilogue or row code against its own lone launch, bit for bit, under that neighbour."""
 import pytest
 import torch
@@ -28,18 +28,42 @@ def _neighbour(dev, gen):
     return run
 
 
+def _neighbour_attention(dev, gen):
+    """Second neighbour (round 5): the attention kernels' MFMA waves -- 256-thread workgroups at two or three per CU that leave wave slots on every
+    SIMD free, so the kernel under test really shares SIMDs with them (forward, and the short-sequence backward: one wave per (sequence, head))."""
+    from merlot_reserve_amd import ops
+    nseq, S, nh = 48, 31, 12
+    H = nh * 64
+    qkv = torch.randn(nseq * S, 3 * H, generator=gen).to(BF16).to(dev)
+    dout = torch.randn(nseq * S, H, generator=gen).to(BF16).to(dev)
+    out = torch.zeros(nseq * S, H, dtype=BF16, device=dev)
+    lse, delta = torch.zeros(nseq, nh, S, device=dev), torch.zeros(nseq, nh, S, device=dev)
+    dqkv = torch.zeros_like(qkv)
+    qkv2 = torch.randn(8 * 241, 3 * H, generator=gen).to(BF16).to(dev)
+    out2 = torch.zeros(8 * 241, H, dtype=BF16, device=dev)
+    lse2 = torch.zeros(8, nh, 241, device=dev)
+
+    def run():
+        for _ in range(3):
+            ops.attention_fwd(qkv, None, out, lse, nseq, S, nh)
+            ops.attention_bwd(qkv, None, out, dout, lse, delta, dqkv, None, nseq, S, nh)
+            ops.attention_fwd(qkv2, None, out2, lse2, 8, 241, nh)
+    return run
+
+
 def _hold(dev, launch, outputs, reps=12, per_rep=8):
     """launch(i) writes outputs[i]; the lone launches are the reference; then `reps` times: the neighbour loops on a second stream while the launches
     are repeated on the first; returns the number of launches whose output differed from the lone one."""
     gen = torch.Generator().manual_seed(5)
-    nb = _neighbour(dev, gen)
+    nbs = [_neighbour(dev, gen), _neighbour_attention(dev, gen)]
     for i in range(per_rep):
         launch(i)
     torch.cuda.synchronize()
     refs = [[t.clone() for t in outputs[i]] for i in range(per_rep)]
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     bad = 0
-    for _ in range(reps):
+    for rep in range(reps):
+        nb = nbs[rep % 2]                           # the two neighbours take turns
         for i in range(per_rep):
             for t in outputs[i]:
                 t.zero_()
