@@ -309,6 +309,11 @@ int mr_transpose_leaves(const void* work_bf16, void* workT_bf16, const int32_t* 
 int mr_f32_gemm(const mr_gemm_args* args, void* stream);
 int mr_f32_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                          int64_t rows, int64_t H, float eps, void* stream);
+/* Attention forward under an ARBITRARY boolean mask (mreserve/modeling.py:303, 350-356: TransformerEncoder's attention_mask [*, L, L]; bias 0 where
+ * mask != 0, -1e10 elsewhere; a row without any allowed key is uniform over the L keys, as in the reference).  qkv / out as mr_attention_fwd, in bf16
+ * (MR_DT_BF16) or fp32 (MR_DT_F32); mask: uint8 [nseq, S, S], shared by the heads.  Forward only (the zero-shot API surface): every mask the model builds
+ * itself has the block form the code-based kernels take. */
+int mr_attention_fwd_dense_mask(const void* qkv, int32_t dtype, const uint8_t* mask, void* out, int64_t nseq, int64_t S, int64_t nh, void* stream);
 /* qkv [nseq*S, 3H] fp32 (layout of mr_attention_fwd); lse may be NULL */
 int mr_f32_attention_fwd(const float* qkv, const int32_t* code, float* out, float* lse, int64_t nseq, int64_t S,
                          int64_t nh, void* stream);

@@ -481,6 +481,70 @@ extern "C" int mr_f32_layernorm_fwd(const float* x, int64_t ldx, const float* ga
     return MR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- attention forward under an ARBITRARY [L, L] mask
+// TransformerEncoder accepts any boolean attention_mask [*, L, L] (mreserve/modeling.py:303, 350-356: bias = 0 where allowed, -1e10 elsewhere).  Every mask the
+// model itself builds is of the block form the other attention kernels take as one code per position; anything else comes here: a plain fp32 kernel, one wave
+// per (sequence, head, query) -- scores of its keys on the lanes (q broadcast from LDS, K rows read per lane), the reference's literal -1e10 added where the
+// mask byte is 0 (so a row without an allowed key is uniform over all L keys, as in the reference), softmax by wave reductions, then the output with one
+// head dim per lane.  An API-completeness path (forward only, the zero-shot / feature-extraction surface), not a training kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_mask_attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ mask, T* __restrict__ out,
+                                                                  int64_t S, int64_t nh, int64_t nrows) {
+    extern __shared__ float dm_smem[];                 // per wave: 64 floats of q, then S scores
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;          // (sequence, head, query)
+    if (row >= nrows) return;                                     // (wave-uniform; no barrier in this kernel)
+    float* qs = dm_smem + (size_t)wave * (64 + S);
+    float* sc = qs + 64;
+    const int64_t qi = row % S, h = (row / S) % nh, seq = row / (S * nh);
+    const int64_t H = nh * 64, ld = 3 * H;
+    const T* base = qkv + seq * S * ld;
+    qs[lane] = (float)base[qi * ld + h * 64 + lane] * 0.125f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the wave's own LDS writes (wave-private region)
+    const uint8_t* mrow = mask + (seq * S + qi) * S;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < S; j += 64) {
+        const T* kr = base + j * ld + H + h * 64;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) a += qs[d] * (float)kr[d];
+        a += mrow[j] ? 0.f : -1e10f;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int64_t j = lane; j < S; j += 64) {
+        const float pv = __expf(sc[j] - mx);
+        sc[j] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float acc = 0.f;
+    const T* vcol = base + 2 * H + h * 64 + lane;
+    for (int64_t j = 0; j < S; ++j) acc += sc[j] * (float)vcol[j * ld];
+    out[(seq * S + qi) * H + h * 64 + lane] = (T)(acc / sum);
+}
+
+extern "C" int mr_attention_fwd_dense_mask(const void* qkv, int32_t dtype, const uint8_t* mask, void* out, int64_t nseq, int64_t S, int64_t nh,
+                                           void* stream) {
+    MR_CHECK_ARG(qkv && mask && out, "mr_attention_fwd_dense_mask: null pointer");
+    MR_CHECK_ARG(nseq > 0 && S > 0 && nh > 0 && S <= 3968, "mr_attention_fwd_dense_mask: bad shape (S <= 3968: the scores of a query live in LDS)");
+    MR_CHECK_ARG(dtype == MR_DT_BF16 || dtype == MR_DT_F32, "mr_attention_fwd_dense_mask: dtype must be MR_DT_BF16 or MR_DT_F32");
+    const int64_t nrows = nseq * nh * S;
+    MR_CHECK_ARG((nrows + 3) / 4 < (1LL << 31), "mr_attention_fwd_dense_mask: too many rows");
+    const dim3 grid((unsigned)((nrows + 3) / 4));
+    const size_t smem = 4 * (64 + (size_t)S) * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MR_DT_F32)
+        hipLaunchKernelGGL(dense_mask_attn_fwd_kernel<float>, grid, dim3(256), smem, s, static_cast<const float*>(qkv), mask, static_cast<float*>(out), S, nh, nrows);
+    else
+        hipLaunchKernelGGL(dense_mask_attn_fwd_kernel<__bf16>, grid, dim3(256), smem, s, static_cast<const __bf16*>(qkv), mask, static_cast<__bf16*>(out), S, nh, nrows);
+    MR_CHECK_LAUNCH("mr_attention_fwd_dense_mask");
+    return MR_OK;
+}
+
 extern "C" int mr_f32_attention_fwd(const float* qkv, const int32_t* code, float* out, float* lse, int64_t nseq, int64_t S,
                                     int64_t nh, void* stream) {
     MR_CHECK_ARG(qkv && out && nseq > 0 && S > 0 && nh > 0, "mr_f32_attention_fwd: bad args");

@@ -100,8 +100,8 @@ def _np(x, dtype=None):
 def _mask_to_code(mask):
     """A dense [n, L, L] boolean attention mask -> one int32 code per position such that
     mask[b, i, j] == (code[b, i] == code[b, j] >= 0).  Every mask the reference builds has this form (validity x
-    validity, optionally ANDed with equality of a per-position source id: M:343-345, 743-756); anything else is
-    rejected rather than silently approximated."""
+    validity, optionally ANDed with equality of a per-position source id: M:343-345, 743-756); anything else raises
+    NotImplementedError here and TransformerEncoder falls back to the dense-mask kernel (ops.attention_fwd_dense_mask)."""
     m = _np(mask).astype(bool)
     n, L, _ = m.shape
     valid = m[:, np.arange(L), np.arange(L)]
@@ -127,6 +127,17 @@ class _Weights:
             if tuple(leaf.shape) != tuple(fshape):
                 raise ValueError(f'parameter {name}: shape {tuple(leaf.shape)}, expected {tuple(fshape)}')
             self.w[name] = leaf.reshape(vshape).to(device=self.device, dtype=dtype).contiguous()
+        # optional leaves: learned position embeddings `pe` [L, H] of an encoder that was initialised WITHOUT rotary coordinates (M:335-341; no
+        # released MERLOT Reserve model has them, param_specs does not list them)
+
+        def walk(node, path):
+            for k, v in (node.items() if isinstance(node, dict) else []):
+                if k == 'pe' and not isinstance(v, dict):
+                    leaf = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+                    self.w['/'.join(path + ['pe'])] = leaf.to(device=self.device, dtype=dtype).contiguous()
+                else:
+                    walk(v, path + [k])
+        walk(tree, [])
         self.zero_scale = torch.zeros(1, device=self.device, dtype=dtype)       # log-temperature 0 -> factor 1
 
 
@@ -181,9 +192,15 @@ class TransformerEncoder(_Module):
             code = _np(attention_code, np.int32).reshape(nseq, L)
         elif is_valid is not None:
             code = np.where(_np(is_valid).astype(bool).reshape(nseq, L), 0, -1).astype(np.int32)
-        elif attention_mask is not None:
-            code = _mask_to_code(_np(attention_mask).reshape(nseq, L, L))
-        xf = self._run(xin, nseq, S, rotary_coords, code)
+        dense = None
+        elif_mask = attention_code is None and is_valid is None and attention_mask is not None
+        if elif_mask:
+            m = _np(attention_mask).astype(bool).reshape(nseq, L, L)
+            try:
+                code = _mask_to_code(m)             # the block form every mask of the model has: one code per position, the fast kernels
+            except NotImplementedError:
+                dense = torch.from_numpy(np.ascontiguousarray(m.astype(np.uint8))).to(self.device)      # anything else: mr_attention_fwd_dense_mask
+        xf = self._run(xin, nseq, S, rotary_coords, code, dense_mask=dense)
         info = {}
         if self.add_cls_token:
             info['cls'] = self._cls_proj(xf, nseq, S).reshape(*batch_dims, H)
@@ -198,23 +215,33 @@ class TransformerEncoder(_Module):
         ops.gemm(xf.view(nseq, S * H)[:, :H], W[f'{self.prefix}/cls_proj/kernel'], out, bias=W[f'{self.prefix}/cls_proj/bias'])
         return out
 
-    def _run(self, xin, nseq, S, rotary_coords, code):
+    def _run(self, xin, nseq, S, rotary_coords, code, dense_mask=None):
         """xin [nseq*S, H] with the CLS rows (if any) still to be filled; rotary_coords / code WITHOUT the CLS position.
         Returns final_ln(x) [nseq*S, H]."""
         W, H, p = self.W, self.hidden_size, self.prefix
         nh, M, dev = H // 64, nseq * S, self.device
-        if rotary_coords is None:
-            raise NotImplementedError('learned positional embeddings (`pe`, M:335-341) are not used by any MERLOT Reserve encoder')
-        rc = _np(rotary_coords, np.float64)
         if self.add_cls_token:
             ops.fill_rows(W[f'{p}/cls'], xin, nseq, S, 0)
-            rc = np.concatenate([np.zeros_like(rc[..., :1, :]), rc], -2)         # CLS coordinates are 0 (M:324-326)
             if code is not None:
                 code = np.concatenate([np.zeros((nseq, 1), np.int32), code], 1)  # CLS is always valid (M:321-322)
-        assert rc.shape[-2] == S, f'rotary_coords cover {rc.shape[-2]} positions, sequence has {S}'
-        rc = rc.reshape(-1, rc.shape[-1])
-        assert rc.shape[0] in (S, M), 'rotary_coords batch dims must be absent or equal to the batch dims of x'
-        rot = torch.from_numpy(rot_scale_table(rc)).to(dev)
+        if rotary_coords is None:
+            # learned position embeddings instead of the "rotary" scales (M:335-341): x += pe[S, H], no scaling of q / k
+            pe = W.get(f'{p}/pe')
+            if pe is None:
+                raise KeyError(f"rotary_coords is None and the parameters hold no '{p}/pe' (learned position embeddings, mreserve/modeling.py:335-341): "
+                               'this encoder was initialised with rotary coordinates')
+            assert tuple(pe.shape) == (S, H), f'pe has shape {tuple(pe.shape)}, the sequence (with CLS, if any) needs {(S, H)}'
+            for n_ in range(nseq):
+                ops.add_(xin[n_ * S:(n_ + 1) * S], pe)
+            rot = None
+        else:
+            rc = _np(rotary_coords, np.float64)
+            if self.add_cls_token:
+                rc = np.concatenate([np.zeros_like(rc[..., :1, :]), rc], -2)         # CLS coordinates are 0 (M:324-326)
+            assert rc.shape[-2] == S, f'rotary_coords cover {rc.shape[-2]} positions, sequence has {S}'
+            rc = rc.reshape(-1, rc.shape[-1])
+            assert rc.shape[0] in (S, M), 'rotary_coords batch dims must be absent or equal to the batch dims of x'
+            rot = torch.from_numpy(rot_scale_table(rc)).to(dev)
         code_t = None if code is None else torch.from_numpy(np.ascontiguousarray(code.reshape(-1))).to(dev)
         e = self._empty
         xa, xb, ln, qkv, att, xmid, hid = e(M, H), e(M, H), e(M, H), e(M, 3 * H), e(M, H), e(M, H), e(M, 4 * H)
@@ -223,8 +250,11 @@ class TransformerEncoder(_Module):
         for l in range(self.num_layers):
             q = f'{p}/layer_{l:02d}'
             ops.layernorm_fwd(xa, W[f'{q}/pre_attn_ln/scale'], W[f'{q}/pre_attn_ln/bias'], ln)
-            ops.gemm(ln, W[f'{q}/attention_layer/qkv/kernel'], qkv, bias=W[f'{q}/attention_layer/qkv/bias'], rot_tab=rot, rot_cols=2 * H)
-            ops.attention_fwd(qkv, code_t, att, lse, nseq, S, nh)
+            ops.gemm(ln, W[f'{q}/attention_layer/qkv/kernel'], qkv, bias=W[f'{q}/attention_layer/qkv/bias'], rot_tab=rot, rot_cols=2 * H if rot is not None else 0)
+            if dense_mask is not None:
+                ops.attention_fwd_dense_mask(qkv, dense_mask, att, nseq, S, nh)
+            else:
+                ops.attention_fwd(qkv, code_t, att, lse, nseq, S, nh)
             ops.gemm(att, W[f'{q}/attention_layer/attn_proj/kernel'], xmid, residual=xa)
             ops.layernorm_fwd(xmid, W[f'{q}/pre_mlp_ln/scale'], W[f'{q}/pre_mlp_ln/bias'], ln)
             ops.gemm(ln, W[f'{q}/mlp_layer/intermediate/kernel'], hid, bias=W[f'{q}/mlp_layer/intermediate/bias'], act=ops.ACT_GELU)

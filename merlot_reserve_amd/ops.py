@@ -331,6 +331,16 @@ def attention_fwd(qkv, code, out, lse, nseq, S, nh):
 
 
 @_timed('attention')
+def attention_fwd_dense_mask(qkv, mask, out, nseq, S, nh):
+    """Arbitrary boolean attention mask [nseq, S, S] (uint8, != 0 = allowed): forward only, bf16 or fp32."""
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (nseq * S, 3 * nh * 64) and qkv.dtype in (BF16, F32)
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == nseq * S * S and mask.device == qkv.device
+    check(_lib.load().mr_attention_fwd_dense_mask(qkv.data_ptr(), MR_DT_F32 if qkv.dtype == F32 else MR_DT_BF16, mask.data_ptr(), out.data_ptr(),
+                                                  nseq, S, nh, _stream()), 'mr_attention_fwd_dense_mask')
+    return out
+
+
+@_timed('attention')
 def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh, colsum_ws=None, bias_grad=None, jobs=None):
     """With colsum_ws / bias_grad / jobs: the qkv bias gradient (column sums of dqkv) comes out of the backward kernels as
     per-block partial rows in colsum_ws, reduced later with the layer's other deferred jobs (no pass over dqkv)."""

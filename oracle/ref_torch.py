@@ -149,8 +149,11 @@ def transformer_encoder(p, x, num_layers, rotary_coords=None, attention_mask=Non
             is_valid = torch.cat([torch.ones(N, 1, dtype=torch.bool), is_valid], -1)
         if rotary_coords is not None:
             rotary_coords = np.concatenate([np.zeros_like(rotary_coords[..., :1, :]), rotary_coords], -2)
-    assert rotary_coords is not None, "learned 'pe' branch (M:335-341) is unused on the pretraining path"
-    sinusoids = torch.as_tensor(construct_rotary_sinusoids(rotary_coords)).to(x.dtype)
+    if rotary_coords is not None:
+        sinusoids = torch.as_tensor(construct_rotary_sinusoids(rotary_coords)).to(x.dtype)
+    else:                                  # M:335-341: learned position embeddings pe [S, H] (S includes the CLS position), no rotary
+        sinusoids = None
+        x = x + p['pe'][None].to(x.dtype)
 
     if (is_valid is not None) and (attention_mask is None):
         attention_mask = is_valid[..., None] & is_valid[..., None, :]

@@ -214,3 +214,58 @@ def test_image_only_embedding_methods(dev):
     joint = R.transformer_encoder(params['joint_transformer'], mm['x'], 2, rotary_coords=mm['rotary_coords'], attention_mask=mm['attention_mask'])['seq']
     ref = R.unit_normalize(R.dense(joint[0, :32], params['head']))
     assert relerr(a[valid], ref[valid.cpu()]) < 1e-3
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_transformer_encoder_arbitrary_mask_and_learned_pe(dev, bf16):
+    """The two branches of TransformerEncoder.__call__ no MERLOT Reserve encoder takes (mreserve/modeling.py:303, 335-341, 350-356): an attention_mask that
+    is NOT of the block form valid x valid x same-source (here: causal, and a random one with an entirely masked row, which the reference's -1e10
+    bias turns into a uniform row) -> the dense-mask attention kernel; and rotary_coords = None -> learned position embeddings `pe` added to x, no
+    rotary scaling.  Against the oracle's encoder on the same weights."""
+    cfg, model, params = make_model(dev, bf16)
+    tol = 2e-2 if bf16 else 1e-3
+    rng = np.random.default_rng(3)
+    q = (lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()) if bf16 else (lambda a: a)
+    N, L, H = 3, 37, 128
+    x = q(rng.standard_normal((N, L, H)).astype(np.float32))
+    coords = (M.get_rotary_coordinates(L, center_origin=False) / L).reshape(L, 1)
+    enc = model.joint_transformer
+    nl = cfg['model']['joint_num_layers']
+    model.bind(params)
+    # (a) causal mask and a random mask with an empty row: not expressible as one code per position
+    causal = np.tril(np.ones((L, L), bool))[None].repeat(N, 0)
+    rnd = rng.random((N, L, L)) < 0.6
+    rnd[:, np.arange(L), np.arange(L)] = True
+    rnd[1, 5, :] = False
+    for mask in (causal, rnd):
+        with pytest.raises(NotImplementedError):
+            M._mask_to_code(mask)
+        got = enc(x, rotary_coords=coords, attention_mask=mask)['seq']
+        ref = R.transformer_encoder(params['joint_transformer'], torch.from_numpy(x), nl, rotary_coords=coords, attention_mask=torch.from_numpy(mask))['seq']
+        assert got.shape == ref.shape and relerr(got, ref) < tol, relerr(got, ref)
+    # a block-form mask still goes to the code-based kernels and agrees with the dense kernel on the same mask
+    valid = rng.random((N, L)) < 0.8
+    valid[:, 0] = True
+    blockm = valid[:, :, None] & valid[:, None, :]
+    a = enc(x, rotary_coords=coords, attention_mask=blockm)['seq']
+    from merlot_reserve_amd import ops
+    qkv = torch.randn(N * L, 3 * H, device=dev).to(a.dtype)
+    o1, o2 = torch.zeros(N * L, H, device=dev, dtype=a.dtype), torch.zeros(N * L, H, device=dev, dtype=a.dtype)
+    lse = torch.zeros(N, H // 64, L, device=dev)
+    code = torch.from_numpy(M._mask_to_code(blockm).reshape(-1)).to(dev)
+    ops.attention_fwd(qkv, code, o1, lse, N, L, H // 64)
+    ops.attention_fwd_dense_mask(qkv, torch.from_numpy(blockm.astype(np.uint8)).to(dev), o2, N, L, H // 64)
+    assert relerr(o2, o1) < (1e-2 if bf16 else 1e-5), relerr(o2, o1)
+    # (b) learned position embeddings
+    with pytest.raises(KeyError):
+        enc(x, rotary_coords=None)
+    g = torch.Generator().manual_seed(9)
+    pe = torch.randn(L, H, generator=g) * 0.02
+    if bf16:
+        pe = pe.to(torch.bfloat16).float()
+    params2 = jax_tree_map(lambda t: t, params)
+    params2['joint_transformer'] = dict(params['joint_transformer'], pe=pe)
+    model.bind(params2)
+    got = model.joint_transformer(x, rotary_coords=None, is_valid=valid)['seq']
+    ref = R.transformer_encoder(params2['joint_transformer'], torch.from_numpy(x), nl, rotary_coords=None, is_valid=torch.from_numpy(valid))['seq']
+    assert relerr(got, ref) < tol, relerr(got, ref)
