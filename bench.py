@@ -227,6 +227,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the hipGraph')
     ap.add_argument('--force-comm', action='store_true', help='(rehearsal) run the N > 1 code path -- RCCL communicator, collectives inside the graph -- with a single rank')
     ap.add_argument('--strict-graph', action='store_true', help='exit non-zero (value null) instead of timing eager steps when the hipGraph capture fails')
+    ap.add_argument('--no-calibration', action='store_true', help='skip the 8192^3 calibration GEMMs around the timed region (profiling runs: they would be counted as step kernels)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the short timings of BASELINE configs 3-5 (large, large resadapt, VCR large) at N = 1')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE', help='library option for this run (mr_set_option; A/B of kernel paths), e.g. --option attn_onepass=0')
     ap.add_argument('--comm', default='native', choices=['native', 'torch'], help="native: the library's RCCL communicator (captured into the hipGraph); torch: torch.distributed nccl (eager step)")
@@ -355,14 +356,14 @@ def main():
             degraded.append('the captured hipGraph step does NOT reproduce the eager step (loss / master parameters differ on some rank): the timed program is suspect')
         restore()
         del snap, ref_master
-    calib = [calibrate(dev)] if rank == 0 else []
+    calib = [calibrate(dev)] if rank == 0 and not args.no_calibration else []
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if rank == 0:
+    if rank == 0 and not args.no_calibration:
         calib.append(calibrate(dev))
         if abs(calib[0] - calib[1]) > 0.03 * max(calib):
             degraded.append(f'calibration GEMM before / after the timed region disagree by more than 3 % ({calib[0]:.0f} vs {calib[1]:.0f} TFLOP/s): the box did not hold one speed')

@@ -304,8 +304,9 @@ int mr_transpose_leaves(const void* work_bf16, void* workT_bf16, const int32_t* 
  * (mr_f32_*_bwd, round 4) follow below.
  * Leading dims and H must be multiples of 4 (16-byte vectors) except mr_f32_gemm's lda / ldb (unaligned operands take a
  * scalar-load path). */
-/* mr_gemm_args with A, B, C, bias, residual = fp32; c_dtype must be MR_DT_F32; c2 / aux / workspace unused (NULL).
- * Epilogue order: + bias, * rot_tab, gelu1702, + residual (residual addressed with the mapped output row). */
+/* mr_gemm_args with A, B, C, bias, residual, c2, aux = fp32; c_dtype must be MR_DT_F32; workspace unused (NULL).
+ * Epilogue order: + bias, * rot_tab, gelu1702 (with the gelu' copy to c2 when given: the fp32 training step), + residual (residual addressed with
+ * the mapped output row), * aux. */
 int mr_f32_gemm(const mr_gemm_args* args, void* stream);
 int mr_f32_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                          int64_t rows, int64_t H, float eps, void* stream);

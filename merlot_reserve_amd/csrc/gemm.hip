@@ -372,6 +372,10 @@ extern "C" int mr_gemm(const mr_gemm_args* a, void* stream) {
                  "mr_gemm: colsum is only produced by the 256-row kernel with the aux epilogue (ask mr_gemm_colsum_supported)");
     mr_gemm_args with_ws;                    // the current handle's split-K workspace when the caller brings none
     if (a->workspace == nullptr && mr_current_handle() != nullptr && mr_current_handle()->ws != nullptr) {
+        int dev_now = -1;                    // the workspace lives on the handle's device: never hand it to a launch on another one
+        (void)hipGetDevice(&dev_now);
+        MR_CHECK_ARG(dev_now == mr_current_handle()->device, "mr_gemm: the current handle was created for device %d, this thread launches on device %d",
+                     mr_current_handle()->device, dev_now);
         with_ws = *a;
         with_ws.workspace = mr_current_handle()->ws;
         with_ws.workspace_bytes = mr_current_handle()->ws_bytes;

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, (Geo5<NW, TM, NS>::OCC)) void gemm5_kernel
 }  // namespace g5
 
 
-// Same operand / epilogue contract as the ping-pong kernel (the caller has checked mr_gemm3_eligible's operand conditions).
+// Same operand / epilogue contract as the ping-pong kernel; mr_gemm asks this kernel FIRST (mr_gemm5_wanted -> mr_gemm5_takes checks the operand conditions itself).
 bool mr_gemm5_takes(const mr_gemm_args* a) {
     if (a->transA || !a->transB || a->c_dtype != MR_DT_BF16 || a->K % 64 != 0 || a->K < 128) return false;
     if (a->M * a->lda * 2 >= (1LL << 31) || a->N * a->ldb * 2 >= (1LL << 31)) return false;

@@ -2,6 +2,7 @@
 // mr_make_current, mr_set_option / mr_get_option, mr_last_gemm_kernel).
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -54,6 +55,7 @@ extern "C" int mr_create(int32_t device, int64_t ws_bytes, mr_handle* out) {
     if (device < 0 || ws_bytes < 0) { mr_set_error("mr_create: bad device %d / workspace size %ld", (int)device, (long)ws_bytes); return MR_EINVAL; }
     mr_handle_s* h = new mr_handle_s();
     h->device = device;
+    h->current_on = 0;
     h->opt = g_default_opts;            // a new handle starts from the process defaults as they are now
     h->ws = nullptr;
     h->ws_bytes = 0;
@@ -74,15 +76,36 @@ extern "C" int mr_create(int32_t device, int64_t ws_bytes, mr_handle* out) {
     return MR_OK;
 }
 
+// A handle may be current on several threads (each launches under its options); `current_on` counts them under g_handle_mu so that mr_destroy
+// cannot free a handle (and its workspace) that another thread's next launch would dereference.
+static std::mutex g_handle_mu;
+
 extern "C" int mr_destroy(mr_handle h) {
     if (!h) return MR_OK;
-    if (g_current == h) g_current = nullptr;
-    if (h->ws) (void)hipFree(h->ws);        // the caller has synchronised the streams that used the handle
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mu);
+        const int others = h->current_on - (g_current == h ? 1 : 0);
+        if (others > 0) {
+            mr_set_error("mr_destroy: the handle is current on %d other thread(s); mr_make_current(NULL) there first", others);
+            return MR_EINVAL;
+        }
+        if (g_current == h) g_current = nullptr;
+    }
+    // the caller has synchronised the streams that used the handle; a hipGraph captured while the handle's workspace was substituted into
+    // mr_gemm holds that pointer: destroy such graphs first
+    if (h->ws) (void)hipFree(h->ws);
     delete h;
     return MR_OK;
 }
 
-extern "C" int mr_make_current(mr_handle h) { g_current = h; return MR_OK; }
+extern "C" int mr_make_current(mr_handle h) {
+    std::lock_guard<std::mutex> lk(g_handle_mu);
+    if (g_current == h) return MR_OK;
+    if (g_current) --g_current->current_on;
+    if (h) ++h->current_on;
+    g_current = h;
+    return MR_OK;
+}
 extern "C" mr_handle mr_get_current(void) { return g_current; }
 
 extern "C" int mr_handle_set_option(mr_handle h, const char* name, int32_t value) {

@@ -21,6 +21,7 @@ struct MrOptions {
 
 struct mr_handle_s {
     int device;
+    int current_on;            // number of threads this handle is current on (mr_make_current): mr_destroy refuses while another thread holds it
     MrOptions opt;
     void* ws;                  // split-K workspace owned by the handle (mr_create's ws_bytes; NULL if 0): used by mr_gemm when the
     int64_t ws_bytes;          // caller's mr_gemm_args.workspace is NULL and this handle is current

@@ -352,7 +352,9 @@ class TowerEngine:
         ops.fill_rows(W[f'{prefix_t}/cls'], st.xin, st.nseq, st.S, 0)
         self.encoder_forward(st, prefix_t, rot, None)
         ops.rows_mean_fwd(st.xf, pool_rows, qin)
-        # the CLS head and the pool's query projection are independent small GEMMs (64 / 1152 rows): one grouped launch
+        # the CLS head and the pool's query projection are independent small GEMMs (64 / 1152 rows): handed over as a group -- ONE launch when both fall to
+        # the small-problem kernel (tiny configs); at base / large size the 1152-row query projection is claimed by the few-tile kernel (mr_gemm5_wanted)
+        # and the library launches the two separately
         self.fgemm_grouped([(self._cls_view(st.xf, st.nseq, st.S), f'{prefix_t}/cls_proj/kernel', out_cls, dict(bias=W[f'{prefix_t}/cls_proj/bias'])),
                             (qin, f'{prefix_pool}/query/kernel', q, dict(bias=W[f'{prefix_pool}/query/bias']))])
         self.fgemm(st.xf, f'{prefix_pool}/key/kernel', k, bias=W[f'{prefix_pool}/key/bias'])

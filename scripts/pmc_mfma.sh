@@ -8,7 +8,7 @@ out=$root/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
-  --kernel-trace --output-format csv -d /tmp/pmc_mfma -- python3 $root/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-h2d "$@" > /tmp/pmc_mfma.log 2>&1
+  --kernel-trace --output-format csv -d /tmp/pmc_mfma -- python3 $root/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --no-roofline --no-h2d "$@" > /tmp/pmc_mfma.log 2>&1
 tail -2 /tmp/pmc_mfma.log | cut -c1-300
 python3 - "$@" <<'PY' > $out/pmc_mfma_$tag.json
 import csv, glob, json, re, sys, collections

@@ -7,7 +7,7 @@ out=$root/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $root/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-h2d "$@" > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $root/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --no-roofline --no-h2d "$@" > /tmp/pmc_$c.log 2>&1
   tail -2 /tmp/pmc_$c.log
 done
 python3 - <<'PY' > $out/pmc_step.json

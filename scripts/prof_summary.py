@@ -7,14 +7,15 @@ def opt(name, default):
     return int(args[args.index(name) + 1]) if name in args else default
 K, W = opt('--steps', 10), opt('--warmup', 3)
 h2d = 0 if "--no-h2d" in args or "--no-graph" in args else max(3 * K, 30) + 2          # bench.py's host-fed leg
-steps = 1 + W + K + (0 if "--no-roofline" in args else 3 * min(K, 3)) + h2d
+chk = 0 if "--no-graph" in args else 2                 # round 5: the one-shot graph == eager check (one eager step + one replay)
+steps = 1 + W + K + (0 if "--no-roofline" in args else 3 * min(K, 3)) + h2d + chk
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'cast_params' not in r['Name'])
 if '--total-steps' in args:      # a run that is not bench.py (scripts/bench_vcr.py): the number of steps that launched kernels, given by the caller
     steps = opt('--total-steps', steps)
     print(f'# steps in the profiled run: {steps}')
 else:
-    print(f'# steps in the profiled run: {steps} (1 eager + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 3 x {min(K, 3)} instrumented eager')
+    print(f'# steps in the profiled run: {steps} (1 eager + {chk} of the graph == eager check + {W} warm-up + {K} timed graph replays' + ('' if '--no-roofline' in args else f' + 3 x {min(K, 3)} instrumented eager')
           + (f' + {h2d} replays fed from host memory' if h2d else '') + ')')
 if '--bench-log' in args:      # the bench line of the SAME run: under rocprofv3 every dispatch is serialised and stamped, so the step is
     import json                # slower than un-profiled and ~equal to the kernel sum; the un-profiled step overlaps the towers' tails

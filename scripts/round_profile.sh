@@ -6,7 +6,7 @@ tag=$1; shift
 out=$root/gpurun_out/prof_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $root/bench.py --no-cpu-baseline --no-calibration "$@" > $out/bench.log 2>&1
 tail -1 $out/bench.log | cut -c1-400
 f=$(ls /tmp/prof_$tag/*/*kernel_stats.csv | head -1)
 cp $f $out/kernel_stats.csv

@@ -105,6 +105,32 @@ def test_handles_carry_their_own_options():
     assert lib.mr_last_gemm_kernel() == b''             # nothing launched, tracing off
 
 
+def test_destroy_is_refused_while_another_thread_holds_the_handle():
+    """A handle current on another thread must not be freed under that thread's next launch (advisor finding, round 4): mr_destroy answers MR_EINVAL
+    until the other thread has let go."""
+    import threading
+    from merlot_reserve_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.mr_create(0, 0, ctypes.byref(h)) == 0
+    holding, release = threading.Event(), threading.Event()
+
+    def other():
+        lib.mr_make_current(h)
+        holding.set()
+        release.wait(10)
+        lib.mr_make_current(None)
+    t = threading.Thread(target=other)
+    t.start()
+    assert holding.wait(10)
+    assert lib.mr_destroy(h) == -1 and b'current on 1 other thread' in lib.mr_last_error()
+    lib.mr_make_current(h)                               # current here too: still one OTHER holder
+    assert lib.mr_destroy(h) == -1
+    release.set(); t.join()
+    assert lib.mr_destroy(h) == 0                        # only this thread holds it: destroyed, and no longer current
+    assert lib.mr_get_current() is None
+
+
 def test_grouped_gemm_validates_every_problem_before_launching():
     """mr_gemm_grouped runs mr_gemm's operand checks per problem BEFORE handing the list to any kernel (advisor finding, round 3)."""
     from merlot_reserve_amd import _lib
