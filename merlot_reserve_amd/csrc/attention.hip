@@ -135,6 +135,14 @@ __device__ __forceinline__ bf16x8 row_frag_d(const char* tile, int row0, int dd,
     const int g = lane >> 4, row = row0 + (lane & 15);
     return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((dd * 4 + g) ^ dswz(row)) << 4));
 }
+// The same read as inline asm (the caller waits with lgkmcnt): with a ring of three tiles the compiler can no longer prove that the tile being read is
+// not the one an LDS-DMA request in flight writes, and puts s_waitcnt vmcnt(0) in front of every plain LDS read of the ring -- which serialises the
+// prefetch it is meant to overlap (the two-slot kernels' b / b ^ 1 indexing it does see through).
+__device__ __forceinline__ void row_frag_d_issue(const char* tile, int row0, int dd, int lane, u32x4& out) {
+    const int g = lane >> 4, row = row0 + (lane & 15);
+    const unsigned a0 = (unsigned)(uintptr_t)MR_LDS_PTR(const char, tile + row * 128 + (((dd * 4 + g) ^ dswz(row)) << 4));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(out) : "v"(a0));
+}
 // transposed fragment (rows row0 + 4g + {0..3} and row0 + 16 + 4g + {0..3}; 16 columns from col0; lane receives column lane & 15)
 // from a DMA image.  Inline asm: with LDS-DMA in flight hipcc would put s_waitcnt vmcnt(0) in front of
 // the ds_read_tr builtin (it cannot tell it from the DMA's LDS writes) and drain the prefetch; the caller waits with lgkmcnt(0).
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
             stage(t + 1, b ^ 1);
             if (tid < TK) {
                 key_meta2((int64_t)(t + 1) * TK + tid, cr, nr);
-                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);
+                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);    // (deferred to the end of the tile this measured 4 us SLOWER on the joint tower)
             }
         }
         MR_ASTAMP(1);
@@ -789,12 +797,17 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
                                                               const float* __restrict__ rot_tab, int64_t rot_rows,
                                                               float* __restrict__ colsum, int64_t S, int64_t nh, const int tile_modes) {
     __shared__ __attribute__((aligned(16))) float red[4][64];
-    __shared__ __attribute__((aligned(16))) char Qs[2][TILE_B];        // LDS-DMA images: row reads (S) and tr reads (dK^T)
-    __shared__ __attribute__((aligned(16))) char Ds[2][TILE_B];        // dO: row reads (dP) and tr reads (dV^T)
-    __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
-    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
-    __shared__ int32_t Fs[2];                                          // tile has a row without allowed key
-    __shared__ int32_t Qu[2];                                          // masked: the query tile's common valid code, or CODE_MIXED (tile_class)
+    // A ring of THREE query tiles, requested TWO tiles ahead (round 5): with two buffers the wait for tile t + 1 at the end of tile t took ~900 of a tile's
+    // 4 300 cycles (stamps, scripts/attn_dkv_stamps.py) -- under the load of 512 resident workgroups an LDS-DMA request needs ~3 000 cycles to land, more
+    // than a tile's arithmetic.  52 KiB per workgroup: two per CU, as the registers allow anyway.
+    constexpr int NB = 3;
+    __shared__ __attribute__((aligned(16))) char Qs[NB][TILE_B];       // LDS-DMA images: row reads (S) and tr reads (dK^T)
+    __shared__ __attribute__((aligned(16))) char Ds[NB][TILE_B];       // dO: row reads (dP) and tr reads (dV^T)
+    // The per-query scalars (-lse log2 e, delta, code, the uniform weight of a live PAD row) of the WHOLE sequence and the classes of its tiles: written once,
+    // in the prologue, by all four waves (dynamic LDS: 16 bytes per padded position + 8 per tile; S = 640: 10 KiB, S = 1312: 21 KiB).  Staged tile by tile
+    // by wave 0, their global loads -- ~3 000 cycles under load -- were what the staging wave waited for at the end of every tile, and the other
+    // three waited for it at the barrier: ~700 of a tile's 4 300 cycles (stamps).
+    extern __shared__ __attribute__((aligned(16))) float dkv_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
@@ -803,6 +816,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    MR_ASTAMP_WG(0);
     const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
     const bool rot_short = rot_rows < S;
 
@@ -861,58 +875,83 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_), 16, sd0, (unsigned)t * d_step, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_ + 1024), 16, sd1, (unsigned)t * d_step, 0, 0);
     };
-    float lr = 0.f, er = 0.f, ur = 0.f;
-    int cr = 0, fr = 0, qur = 0;
-    auto side_load = [&](int64_t q0) {        // wave 0 (tid < TK) stages the 64 queries' scalars
-        if (tid < TK) {
-            const bool ok = q0 + tid < S;
-            float L = ok ? Lg[q0 + tid] : INFINITY;
-            er = ok ? Eg[q0 + tid] : 0.f;
-            // a PAD row whose upstream gradient is zero (marked delta = -0.0 by the dQ kernel) weighs nothing in dK / dV: an absent row (p = 0), see there
-            bool pad = MASKED && ok && L < PAD_LSE;
-            if (pad && tile_modes != 0 && __float_as_uint(er) == 0x80000000u) { pad = false; L = INFINITY; }
-            lr = -L * LOG2E;
-            int c = ok ? (MASKED ? code_seq[q0 + tid] : 0) : CODE_PADQ;
-            cr = (c < 0) ? CODE_PADQ : c;
-            ur = pad ? inv_S : 0.f;
-            fr = MASKED ? (int)__any(pad) : 0;
-            if (MASKED) {
-                // the tile's class over its LIVE rows: a row beyond the sequence or a PAD row with a zero upstream gradient has lr = -inf, i.e. p = 0
-                // under any bias -- a wildcard; a live PAD row weighs EVERY key: never uniform
-                const bool live = lr != -INFINITY;
-                const unsigned long long bl = __ballot(live);
-                const int c0 = bl != 0ull ? __builtin_amdgcn_readlane(cr, (int)__builtin_ctzll(bl)) : 0;
-                qur = (tile_modes == 0 || c0 < 0 || __any(live && cr != c0)) ? CODE_MIXED : c0;
-                // every row of the tile beyond the sequence or marked by the dQ kernel as having a zero upstream gradient (delta = -0.0): such a
-                // tile contributes exactly nothing to dK / dV and is skipped by every wave
-                if (tile_modes != 0 && !__any(ok && __float_as_uint(er) != 0x80000000u)) qur = CODE_DEAD;
+    const int nt = (int)((S + TK - 1) / TK);
+    const int Sp = nt * TK;
+    float* const Ls = dkv_dyn;
+    float* const Dl = Ls + Sp;
+    float* const Us = Dl + Sp;
+    int32_t* const Cs = reinterpret_cast<int32_t*>(Us + Sp);
+    int32_t* const Fs = Cs + Sp;                                       // tile has a LIVE row without allowed key
+    int32_t* const Qu = Fs + nt;                                       // masked: the tile's common valid code over its live rows, CODE_MIXED or CODE_DEAD
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    // wave w fills AND classifies tiles w, w + 4, ... (lane = query): the values are in its registers when it votes, so no barrier sits between the two;
+    // three tiles per batch, every load of a batch in flight at once
+    for (int t0 = wave; t0 < nt; t0 += 12) {
+        float L3[3], e3[3];
+        int c3[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = (t0 + 4 * u) * TK + lane;
+            const bool ok = t0 + 4 * u < nt && q < S;
+            L3[u] = ok ? Lg[q] : INFINITY;
+            e3[u] = ok ? Eg[q] : 0.f;
+            c3[u] = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            if (t < nt) {                        // (wave-uniform)
+                const int q = t * TK + lane;
+                float L = L3[u];
+                const float eq = e3[u];
+                // a PAD row whose upstream gradient is zero (marked delta = -0.0 by the dQ kernel) weighs nothing in dK / dV: an absent row (p = 0), see there
+                bool pad = MASKED && q < S && L < PAD_LSE;
+                if (pad && tile_modes != 0 && __float_as_uint(eq) == 0x80000000u) { pad = false; L = INFINITY; }
+                const float lrq = -L * LOG2E;
+                const int cq_ = (c3[u] < 0) ? CODE_PADQ : c3[u];
+                Ls[q] = lrq;
+                Dl[q] = eq;
+                Cs[q] = cq_;
+                Us[q] = pad ? inv_S : 0.f;
+                const int fr = MASKED ? (int)__any(pad) : 0;
+                int qur = CODE_MIXED;
+                if (MASKED) {
+                    // the tile's class over its LIVE rows: a row beyond the sequence or a PAD row with a zero upstream gradient has lr = -inf, i.e. p = 0
+                    // under any bias -- a wildcard; a live PAD row weighs EVERY key: never uniform
+                    const bool live = lrq != -INFINITY;
+                    const unsigned long long bl = __ballot(live);
+                    const int c0 = bl != 0ull ? __builtin_amdgcn_readlane(cq_, (int)__builtin_ctzll(bl)) : 0;
+                    qur = (tile_modes == 0 || c0 < 0 || __any(live && cq_ != c0)) ? CODE_MIXED : c0;
+                    // every row of the tile beyond the sequence or marked by the dQ kernel as having a zero upstream gradient (delta = -0.0): such a
+                    // tile contributes exactly nothing to dK / dV and is skipped by every wave
+                    if (tile_modes != 0 && !__any(q < S && __float_as_uint(eq) != 0x80000000u)) qur = CODE_DEAD;
+                }
+                if (lane == 0) { Fs[t] = fr; Qu[t] = qur; }
             }
         }
-    };
-    stage(0, 0);
-    side_load(0);
-    if (tid < TK) { Ls[0][tid] = lr; Dl[0][tid] = er; Cs[0][tid] = cr; Us[0][tid] = ur; if (tid == 0) { Fs[0] = fr; Qu[0] = qur; } }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nt = (int)((S + TK - 1) / TK);
     // one query tile; FAST (masked kernels only): every (query, key) pair of the tile and this wave's keys is allowed
     // (staging and the end-of-tile wait stay inside the lambda: split off, the same statements cost registers -- see the dQ kernel)
-    for (int t = 0; t < nt; ++t) {
-        const int b = t & 1;
+    int b = 0;                                   // t % NB
+    for (int t = 0; t < nt; ++t, b = (b == NB - 1) ? 0 : b + 1) {
+        const int b2 = (b == 0) ? NB - 1 : b - 1;                          // (t + 2) % NB: the slot tile t - 1 was read from
+        const int tq = t * TK;                                             // this tile's first position in the sequence-wide scalar arrays
         // masked kernels: wave-uniform branches on the tile's mode inside ONE body (see the dQ kernel)
         int mode = TILE_GENERAL;
         if constexpr (MASKED) {
-            const int qc = __builtin_amdgcn_readfirstlane(Qu[b]);
+            const int qc = __builtin_amdgcn_readfirstlane(Qu[t]);
             mode = qc == CODE_DEAD ? (int)TILE_SKIP : tile_mode(wk_uniform, wk_code, qc);
         }
         const bool FAST = MASKED && mode == TILE_FAST;
-        if (t + 1 < nt) {
-            stage(t + 1, b ^ 1);
-            side_load((int64_t)(t + 1) * TK);
-        }
+        MR_ASTAMP(0);
+        if (t + 2 < nt) stage(t + 2, b2);
+        MR_ASTAMP(1);
         if (!MASKED || mode != TILE_SKIP) {
-        const bool tile_pad = MASKED && !FAST && Fs[b] != 0;
+        const bool tile_pad = MASKED && !FAST && Fs[t] != 0;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             // this half-tile's P and dS (32 queries) go straight into dV^T / dK^T: only one half's fragments are ever live
@@ -925,14 +964,21 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
                     const int qb = 2 * t2 + q2;
-                    const bf16x8 q0f = row_frag_d(Qs[b], qb * 16, 0, lane), q1f = row_frag_d(Qs[b], qb * 16, 1, lane);
-                    const bf16x8 d0f = row_frag_d(Ds[b], qb * 16, 0, lane), d1f = row_frag_d(Ds[b], qb * 16, 1, lane);
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[b][qb * 16 + g * 4]);
-                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[b][qb * 16 + g * 4]);
+                    u32x4 q0r, q1r, d0r, d1r;                      // (asm reads of the ring: see row_frag_d_issue)
+                    row_frag_d_issue(Qs[b], qb * 16, 0, lane, q0r);
+                    row_frag_d_issue(Qs[b], qb * 16, 1, lane, q1r);
+                    row_frag_d_issue(Ds[b], qb * 16, 0, lane, d0r);
+                    row_frag_d_issue(Ds[b], qb * 16, 1, lane, d1r);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[tq + qb * 16 + g * 4]);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(&Dl[tq + qb * 16 + g * 4]);
                     i32x4 c4 = {0, 0, 0, 0};
-                    if (MASKED && !FST) c4 = *reinterpret_cast<const i32x4*>(&Cs[b][qb * 16 + g * 4]);
+                    if (MASKED && !FST) c4 = *reinterpret_cast<const i32x4*>(&Cs[tq + qb * 16 + g * 4]);
                     f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
-                    if (!FST && tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[b][qb * 16 + g * 4]);
+                    if (!FST && tile_pad) u4 = *reinterpret_cast<const f32x4*>(&Us[tq + qb * 16 + g * 4]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 q0f = __builtin_bit_cast(bf16x8, q0r), q1f = __builtin_bit_cast(bf16x8, q1r);
+                    const bf16x8 d0f = __builtin_bit_cast(bf16x8, d0r), d1f = __builtin_bit_cast(bf16x8, d1r);
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
                         f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -995,10 +1041,22 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
             }
         }
         }
-        if (t + 1 < nt && tid < TK) { Ls[b ^ 1][tid] = lr; Dl[b ^ 1][tid] = er; Cs[b ^ 1][tid] = cr; Us[b ^ 1][tid] = ur; if (tid == 0) { Fs[b ^ 1] = fr; Qu[b ^ 1] = qur; } }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
-        __syncthreads();
+        MR_ASTAMP(2);
+        if (t + 2 < nt) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // this wave's pieces of tile t + 1 have landed; the 4 of tile t + 2 stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        MR_ASTAMP(3);
+        // a RAW barrier: __syncthreads() carries a fence that the compiler lowers to s_waitcnt vmcnt(0) -- it would drain the requests of tile t + 2.
+        // What the barrier must order is in LDS: this wave's reads of the slot tile t + 3 will overwrite (all retired: the asm reads were waited for,
+        // the others feed arithmetic that has issued)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        MR_ASTAMP(4);
     }
+    { const int t = 13; MR_ASTAMP(0); }
     // lane holds dK^T / dV^T [d = 16 db + 4 g + r][key i].  dK: the 1/8 folded into kf was on the OTHER operand of S = q . (k/8), so
     // d(score)/dk = q / 8 still has to be applied here.  Both tiles leave as whole rows through the wave's share of the Q / dO buffers (free since the
     // loop's last barrier): store_rows_via_lds.
@@ -1027,12 +1085,14 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
         store_rows_via_lds<KB>(&Qs[0][0] + wave * (KB * 2048), ok_, grow + H, ld, row0, S, lane);
         store_rows_via_lds<KB>(&Ds[0][0] + wave * (KB * 2048), ov_, grow + 2 * H, ld, row0, S, lane);
     }
+    { const int t = 13; MR_ASTAMP(1); }
     if (colsum != nullptr) {      // wave-uniform: partial row (sequence, key block), columns of this head's k and v
         float* prow = colsum + (seq * ((S + 64 * KB - 1) / (64 * KB)) + ab_.blk) * ld;
         block_colsum_store(csk, red, prow + H + h * 64, tid);
         __syncthreads();
         block_colsum_store(csv, red, prow + 2 * H + h * 64, tid);
     }
+    MR_ASTAMP_WG(1);
 }
 
 
@@ -1720,11 +1780,15 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     }
     const bool two = S > attn_qb_threshold();
     const int tm = mr_opts().attn_tile_modes;
+    // the dK / dV kernel keeps a sequence's per-query scalars in dynamic LDS: 16 B per padded position + 8 B per tile (beside 52 KiB of static tiles)
+    const int64_t nt_ = (S + TK - 1) / TK;
+    const size_t dkv_smem = (size_t)(nt_ * TK * 16 + nt_ * 8);
+    MR_CHECK_ARG(dkv_smem <= 100 * 1024, "mr_attention_bwd: S = %ld is beyond what one workgroup's LDS holds (S <= 6336)", (long)S);
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, oo, d, lse, delta, g, \
                            rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, d, lse, delta, g, \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), dkv_smem, s, q, code, d, lse, delta, g, \
                            rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
     } while (0)
     if (two && code) MR_LAUNCH_BWD(2, true);
