@@ -46,7 +46,7 @@ SPILL_ALLOWED = {
     r'gemm256_kernelILi192E': (5, 'as the 256-wide instance'),
     r'gemm5_kernelILi[012]ELi4ELi256ELi3E': (11, 'per-tile item decode + epilogue offsets of the two-per-CU geometry (<= 128 registers per wave by design); no MFMA block touches scratch'),
     r'gemm5_kernelILi4ELi4ELi256ELi3E': (20, 'HOT (4 stores in an MFMA block).  aux mode of the two-per-CU geometry: NOT dispatched by the default policy (aux arrives with column sums, which it refuses); option gemm5=1 only'),
-    r'attn_bwd_dq_kernelILi2ELb1E': (21, 'HOT (3 reloads in an MFMA block).  held to three waves per SIMD on purpose: 168 registers + 14 spilled is faster than 184 at two waves (joint backward 181 -> 175 us, round 2)'),
+    r'attn_bwd_dq_kernelILi2ELb1E': (4, 'HOT (3 reloads in an MFMA block).  held to three waves per SIMD on purpose: 168 registers + 14 spilled is faster than 184 at two waves (joint backward 181 -> 175 us, round 2)'),
     r'attn_bwd1_kernelILb1E': (6, 'HOT (1 reload in an MFMA block).  masked one-pass backward (no stock tower routes to it)'),
     r'attn_bwd1_kernelILb0E': (3, 'one register held from the prologue to the epilogue, reloaded once outside the tile loop (round 5: the per-query scalars of the next tile now stay in registers across a tile)'),
 }

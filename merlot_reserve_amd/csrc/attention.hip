@@ -50,6 +50,9 @@
 // -DMR_ATTN_STAMPS (diagnostic build): s_memtime stamps of the forward kernel's phases for the first tiles of the first workgroups,
 // into a buffer of their own that mr_diag_attn_stamps() copies out; no stamp executes in the product build
 #ifdef MR_ATTN_STAMPS
+#ifndef MR_ATTN_STAMP_K       /* which kernel stamps: 0 = every instrumented one (the last launch wins), 1 forward, 2 dQ, 3 dK / dV, 4 one-pass backward */
+#define MR_ATTN_STAMP_K 0
+#endif
 __device__ unsigned long long g_attn_stamps[512 * 16 * 8];
 #define MR_ASTAMP(slot)                                                                                        \
     do {                                                                                                       \
@@ -57,7 +60,7 @@ __device__ unsigned long long g_attn_stamps[512 * 16 * 8];
         unsigned long long t_;                                                                                 \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (lane == 0 && wave == 0 && blockIdx.x < 512 && t < 16) g_attn_stamps[(blockIdx.x * 16 + t) * 8 + (slot)] = t_; \
+        if ((MR_ATTN_STAMP_K == 0 || MR_ATTN_STAMP_K == stamp_id) && lane == 0 && wave == 0 && blockIdx.x < 512 && t < 16) g_attn_stamps[(blockIdx.x * 16 + t) * 8 + (slot)] = t_; \
     } while (0)
 // workgroup begin / end (tile row 15 of the workgroup's stamps, slots 0 / 1; the loop-top stamp of tile 0 marks the prologue's end)
 #define MR_ASTAMP_WG(slot)                                                                                     \
@@ -66,7 +69,7 @@ __device__ unsigned long long g_attn_stamps[512 * 16 * 8];
         unsigned long long t_;                                                                                 \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (lane == 0 && wave == 0 && blockIdx.x < 512) g_attn_stamps[(blockIdx.x * 16 + 15) * 8 + (slot)] = t_; \
+        if ((MR_ATTN_STAMP_K == 0 || MR_ATTN_STAMP_K == stamp_id) && lane == 0 && wave == 0 && blockIdx.x < 512) g_attn_stamps[(blockIdx.x * 16 + 15) * 8 + (slot)] = t_; \
     } while (0)
 #else
 #define MR_ASTAMP(slot) do {} while (0)
@@ -269,9 +272,10 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
                                                           int64_t S, int64_t nh, const int tile_modes) {
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];          // LDS-DMA images (see dma_src)
     __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];
-    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];          // masked: key codes
-    __shared__ __attribute__((aligned(16))) float Ns[2][TK];            // additive key bias, exp2 domain (see key_meta2)
-    __shared__ int32_t Ku[2];                                           // masked: class of the key tile (tile_class)
+    // key codes (masked), the additive key bias (exp2 domain, see key_meta2) and the tile classes of the WHOLE sequence: dynamic LDS, written once in the
+    // prologue by all four waves (8 bytes per padded position + 4 per tile) -- see the dQ kernel
+    extern __shared__ __attribute__((aligned(16))) float fwd_dyn[];
+    [[maybe_unused]] constexpr int stamp_id = 1;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA bases stay scalar
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
@@ -347,18 +351,31 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
     };
 
-    int cr = 0, kur = 0;
-    float nr = 0.f;
+    const int nt = (int)((S + TK - 1) / TK);
+    int32_t* const Cs = reinterpret_cast<int32_t*>(fwd_dyn);
+    float* const Ns = fwd_dyn + nt * TK;
+    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + nt * TK);
     stage(0, 0);
-    if (tid < TK) {
-        key_meta2(tid, cr, nr);
-        if (MASKED) { Cs[0][tid] = cr; kur = tile_class(cr, TK <= S); if (tid == 0) Ku[0] = kur; }
-        Ns[0][tid] = nr;
+    for (int t0 = wave; t0 < nt; t0 += 12) {      // wave w fills and classifies tiles w, w + 4, ... (lane = key); three tiles' loads in flight at once
+        int c3[3];
+        float n3[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            c3[u] = CODE_NONE; n3[u] = -INFINITY;
+            if (t0 + 4 * u < nt) key_meta2((int64_t)(t0 + 4 * u) * TK + lane, c3[u], n3[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            if (t < nt) {
+                Ns[t * TK + lane] = n3[u];
+                if (MASKED) { Cs[t * TK + lane] = c3[u]; const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nt = (int)((S + TK - 1) / TK);
     // one key tile's scores, softmax update and P V product; FAST (masked kernels only): every (query, key) pair of this wave and tile is
     // allowed, the bias is 0 for all of them
     // (staging and the end-of-tile wait stay inside the lambda: split off, the same statements cost registers -- see the dQ kernel)
@@ -368,17 +385,11 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         // three instantiated bodies cost this kernel its third wave per SIMD (206 registers)
         int mode = TILE_GENERAL;
         if constexpr (MASKED) {
-            mode = tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[b]));
+            mode = tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[t]));
             if (wq_allpad && (int64_t)(t + 1) * TK <= S) mode = TILE_UNIFORM;
         }
         MR_ASTAMP(0);
-        if (t + 1 < nt) {      // next tile: straight into the other buffer (last read one iteration ago, behind that iteration's barrier)
-            stage(t + 1, b ^ 1);
-            if (tid < TK) {
-                key_meta2((int64_t)(t + 1) * TK + tid, cr, nr);
-                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);    // (deferred to the end of the tile this measured 4 us SLOWER on the joint tower)
-            }
-        }
+        if (t + 1 < nt) stage(t + 1, b ^ 1);      // next tile: straight into the other buffer (last read one iteration ago, behind that iteration's barrier)
         MR_ASTAMP(1);
         if (!MASKED || mode != TILE_SKIP) {
         bf16x8 pf[QB][2];
@@ -426,9 +437,9 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         } else {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {         // the staged vectors of one 16-key block at a time: 8 registers live, not 32
-                const f32x4 nbv = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
+                const f32x4 nbv = *reinterpret_cast<const f32x4*>(&Ns[t * TK + kb * 16 + g * 4]);
                 i32x4 ckv = {0, 0, 0, 0};
-                if (MASKED) ckv = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
+                if (MASKED) ckv = *reinterpret_cast<const i32x4*>(&Cs[t * TK + kb * 16 + g * 4]);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -491,7 +502,6 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         }
         MR_ASTAMP(4);
         }
-        if (t + 1 < nt && tid < TK) { if (MASKED) { Cs[b ^ 1][tid] = cr; if (tid == 0) Ku[b ^ 1] = kur; } Ns[b ^ 1][tid] = nr; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
         MR_ASTAMP(5);
         __syncthreads();
@@ -528,9 +538,11 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     __shared__ __attribute__((aligned(16))) float red[4][64];
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE_B];       // LDS-DMA images: row reads (S^T) and tr reads (dQ^T)
     __shared__ __attribute__((aligned(16))) char Vs[2][TILE_B];       // row reads (dP^T)
-    __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
-    __shared__ __attribute__((aligned(16))) float Ns[2][TK];
-    __shared__ int32_t Ku[2];                                         // masked: class of the key tile (tile_class)
+    // the key codes, the per-key bias and the tile classes of the WHOLE sequence: written once, in the prologue, by all four waves (dynamic LDS: 8 bytes per
+    // padded position + 4 per tile).  Staged tile by tile by wave 0, their global loads parked that wave ~700 cycles at the top of every tile (stamps,
+    // scripts/attn_dq_stamps.py) and the other three waited for it at the barrier
+    extern __shared__ __attribute__((aligned(16))) float dq_dyn[];
+    [[maybe_unused]] constexpr int stamp_id = 2;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * QB - 1) / (64 * QB)), (int)nh);
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     const __bf16* base = qkv + seq * S * ld;
     const int32_t* code_seq = MASKED ? code + seq * S : nullptr;
     const float inv_S = 1.0f / (float)S;
+    MR_ASTAMP_WG(0);
     const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
     const bool rot_short = rot_rows < S;
 
@@ -638,18 +651,32 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
     };
-    int cr = 0, kur = 0;
-    float nr = 0.f;
+    const int nt = (int)((S + TK - 1) / TK);
+    int32_t* const Cs = reinterpret_cast<int32_t*>(dq_dyn);
+    float* const Ns = dq_dyn + nt * TK;
+    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + nt * TK);      // masked: class of the key tile (tile_class)
     stage(0, 0);
-    if (tid < TK) {
-        key_meta(tid, S, code_seq, MASKED, cr, nr);
-        Cs[0][tid] = cr; Ns[0][tid] = nr;
-        if (MASKED) { kur = tile_class(cr, TK <= S); if (tid == 0) Ku[0] = kur; }
+    for (int t0 = wave; t0 < nt; t0 += 12) {      // wave w fills and classifies tiles w, w + 4, ... (lane = key); three tiles' loads in flight at once
+        int c3[3];
+        float n3[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            c3[u] = CODE_NONE; n3[u] = -INFINITY;
+            if (t0 + 4 * u < nt) key_meta((int64_t)(t0 + 4 * u) * TK + lane, S, code_seq, MASKED, c3[u], n3[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            if (t < nt) {
+                Cs[t * TK + lane] = c3[u];
+                Ns[t * TK + lane] = n3[u];
+                if (MASKED) { const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nt = (int)((S + TK - 1) / TK);
     const bool ragged = (S & (TK - 1)) != 0;
     // one key tile; NB (compile time) = the scores of this tile need the per-key bias: when masked unless the tile is uniformly allowed
     // for this wave (tile_mode), otherwise only in a ragged LAST tile (keys beyond the sequence) -- which is peeled below so that the hot
@@ -663,13 +690,9 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         const bool need_bias = mode == TILE_GENERAL;         // (masked kernels; the unmasked ones take nb_c)
         const bool skip = MASKED && mode == TILE_SKIP;       // stage, wait and synchronise only: every weight of the tile is 0 for this wave
         const int b = t & 1;
-        if (t + 1 < nt) {
-            stage(t + 1, b ^ 1);
-            if (tid < TK) {
-                key_meta((int64_t)(t + 1) * TK + tid, S, code_seq, MASKED, cr, nr);
-                if (MASKED) kur = tile_class(cr, (int64_t)(t + 2) * TK <= S);
-            }
-        }
+        MR_ASTAMP(0);
+        if (t + 1 < nt) stage(t + 1, b ^ 1);
+        MR_ASTAMP(1);
         if (!skip) {
         bf16x8 dsf[QB][2];
         // scores, P, dS of the tile (the first two products + the per-score arithmetic).  Masked kernels: instantiated twice under ONE wave-uniform
@@ -685,8 +708,8 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
                 i32x4 ck = {0, 0, 0, 0};
                 f32x4 nk = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (NB) {
-                    ck = *reinterpret_cast<const i32x4*>(&Cs[b][kb * 16 + g * 4]);
-                    nk = *reinterpret_cast<const f32x4*>(&Ns[b][kb * 16 + g * 4]);
+                    ck = *reinterpret_cast<const i32x4*>(&Cs[t * TK + kb * 16 + g * 4]);
+                    nk = *reinterpret_cast<const f32x4*>(&Ns[t * TK + kb * 16 + g * 4]);
                 }
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
@@ -714,6 +737,7 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         } else {
             scores(nb_c);
         }
+        MR_ASTAMP(2);
         // K^T fragments (asm reads, explicit waits: see tr_frag_d_issue), one 32-key half at a time: the second half is requested once
         // the first half's MFMAs are issued and lands under them (its 16 registers are the first half's: 3 waves per SIMD)
 #pragma unroll
@@ -733,18 +757,21 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
             }
         }
         }
-        if (t + 1 < nt && tid < TK) { Cs[b ^ 1][tid] = cr; Ns[b ^ 1][tid] = nr; if (MASKED && tid == 0) Ku[b ^ 1] = kur; }
+        MR_ASTAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of tile t + 1 have landed
+        MR_ASTAMP(4);
         __syncthreads();
+        MR_ASTAMP(5);
     };
     if constexpr (MASKED) {
         for (int t = 0; t < nt; ++t)
-            tile_body(t, std::true_type{}, wave_dead ? (int)TILE_SKIP : tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[t & 1])));
+            tile_body(t, std::true_type{}, wave_dead ? (int)TILE_SKIP : tile_mode(wq_uniform, wq_code, __builtin_amdgcn_readfirstlane(Ku[t])));
     } else {
         for (int t = 0; t < nt - 1; ++t) tile_body(t, std::false_type{}, TILE_GENERAL);
         if (ragged) tile_body(nt - 1, std::true_type{}, TILE_GENERAL);
         else tile_body(nt - 1, std::false_type{}, TILE_GENERAL);
     }
+    { const int t = 13; MR_ASTAMP(0); }
     f32x4 cs[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) cs[db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -781,8 +808,10 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
             }
         }
     }
+    { const int t = 13; MR_ASTAMP(1); }
     if (colsum != nullptr)        // wave-uniform: partial row (sequence, query block), columns of this head's q
         block_colsum_store(cs, red, colsum + (seq * ((S + 64 * QB - 1) / (64 * QB)) + ab_.blk) * ld + h * 64, tid);
+    MR_ASTAMP_WG(1);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -808,6 +837,7 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     // by wave 0, their global loads -- ~3 000 cycles under load -- were what the staging wave waited for at the end of every tile, and the other
     // three waited for it at the barrier: ~700 of a tile's 4 300 cycles (stamps).
     extern __shared__ __attribute__((aligned(16))) float dkv_dyn[];
+    [[maybe_unused]] constexpr int stamp_id = 3;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block((int)((S + 64 * KB - 1) / (64 * KB)), (int)nh);
@@ -1123,6 +1153,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     __shared__ __attribute__((aligned(16))) float Ls[2][TK], Dl[2][TK], Us[2][TK];
     __shared__ __attribute__((aligned(16))) int32_t Cs[2][TK];
     __shared__ __attribute__((aligned(16))) float red[8][192];          // column-sum partials: [wave][q | k | v third][64]
+    [[maybe_unused]] constexpr int stamp_id = 4;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const AttnBlock ab_ = attn_block(1, (int)nh);
@@ -1726,11 +1757,14 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     const __bf16* q = static_cast<const __bf16*>(qkv);
     __bf16* o = static_cast<__bf16*>(out);
     const int tm = mr_opts().attn_tile_modes;
+    const int64_t nt_ = (S + TK - 1) / TK;
+    const size_t fwd_smem = (size_t)(nt_ * TK * 8 + nt_ * 4);             // key codes, bias and tile classes of a sequence (dynamic LDS)
+    MR_CHECK_ARG(fwd_smem <= 100 * 1024, "mr_attention_fwd: S = %ld is beyond what one workgroup's LDS holds (S <= 12 700)", (long)S);
     const bool two = S > attn_qb_threshold();        // short sequences (audio 31, span 16): one 16-query block per wave
-    if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
-    else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
-    else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
-    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), attn_grid<1>(S, nh, nseq), dim3(256), 0, s, q, code, o, lse, S, nh, tm);
+    if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), fwd_smem, s, q, code, o, lse, S, nh, tm);
+    else if (two) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), attn_grid<2>(S, nh, nseq), dim3(256), fwd_smem, s, q, code, o, lse, S, nh, tm);
+    else if (code) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), attn_grid<1>(S, nh, nseq), dim3(256), fwd_smem, s, q, code, o, lse, S, nh, tm);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), attn_grid<1>(S, nh, nseq), dim3(256), fwd_smem, s, q, code, o, lse, S, nh, tm);
     MR_CHECK_LAUNCH("mr_attention_fwd");
     return MR_OK;
 }
@@ -1783,10 +1817,11 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     // the dK / dV kernel keeps a sequence's per-query scalars in dynamic LDS: 16 B per padded position + 8 B per tile (beside 52 KiB of static tiles)
     const int64_t nt_ = (S + TK - 1) / TK;
     const size_t dkv_smem = (size_t)(nt_ * TK * 16 + nt_ * 8);
+    const size_t dq_smem = (size_t)(nt_ * TK * 8 + nt_ * 4);              // the dQ kernel: codes, bias and classes of the sequence's keys
     MR_CHECK_ARG(dkv_smem <= 100 * 1024, "mr_attention_bwd: S = %ld is beyond what one workgroup's LDS holds (S <= 6336)", (long)S);
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), 0, s, q, code, oo, d, lse, delta, g, \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), dq_smem, s, q, code, oo, d, lse, delta, g, \
                            rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<QB, M>), attn_grid<QB>(S, nh, nseq), dim3(256), dkv_smem, s, q, code, d, lse, delta, g, \
                            rot_tab, rot_rows, colsum, S, nh, tm);                                                             \
