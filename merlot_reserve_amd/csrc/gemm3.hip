@@ -109,6 +109,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const G256Args ga) {
     auto item_m0 = [&](int q) -> int { return q < 64 ? __builtin_amdgcn_readlane(m0v, q) : -1; };
     auto item_n0 = [&](int q) -> int { return __builtin_amdgcn_readlane(n0v, q & 63); };
     if (item_m0(0) < 0) return;
+#ifdef MR_G3_STAGGER          // experiment (scripts/build_g3_variants.sh): odd workgroups start late, so that their epilogues' store bursts fall into the others' k-loops
+    if (blockIdx.x & 8) for (int i = 0; i < MR_G3_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const mr_gemm_args& p0 = ga.p[0];
     const int nkt = (int)(p0.K >> 6);
     const unsigned lda2 = (unsigned)p0.lda * 2u, ldb2 = (unsigned)p0.ldb * 2u;
