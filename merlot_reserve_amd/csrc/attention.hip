@@ -163,8 +163,9 @@ __device__ __forceinline__ bf16x8 tr_join(const s16x4& lo, const s16x4& hi) {
 
 // per-key metadata of tile position k: its code and the bias a query with a DIFFERENT code adds to the score
 __device__ __forceinline__ void key_meta(int64_t k, int64_t S, const int32_t* __restrict__ code_seq, bool masked, int& c, float& nb) {
-    if (k < S) { c = masked ? code_seq[k] : 0; nb = NEG_BIAS; }
-    else { c = CODE_NONE; nb = -INFINITY; }
+    const int cr = masked ? code_seq[k < S ? k : S - 1] : 0;      // (no branch around the load: a batch of these stays one basic block, all in flight at once)
+    c = k < S ? cr : CODE_NONE;
+    nb = k < S ? NEG_BIAS : -INFINITY;
 }
 
 // fragment * 2^-3: the query / sqrt(depth) of flax's dot_product_attention_weights (exact in bf16)
@@ -284,19 +285,81 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
     const __bf16* base = qkv + seq * S * ld;
     MR_ASTAMP_WG(0);
 
+    // K / V of this (sequence, head): rows beyond S are beyond the descriptors' extent (zero fill); the tile advance is a scalar offset
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Vg = base + 2 * H + h * 64;
+    const int ext = (int)(((S - 1) * ld + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
+    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned tile_step = (unsigned)(TK * ld * 2);
+    // Per-key staging: the additive bias a score gets unless the key is allowed for the query, in the exp2 domain -- the reference's
+    // literal -1e10 for a key inside the sequence (an unmasked tower allows every such key: 0), -inf beyond it -- and, masked only, the
+    // key's code.  A score is then fma(raw, SCALE2, allowed ? 0 : bias): compare + select + FMA (unmasked: the FMA alone).  A PAD
+    // query's code equals no key's, so all its scores round to the same -1e10 log2 e inside the sequence (-inf outside): uniform over
+    // the S keys, as in the reference.  (No branch around the load: see the dQ kernel's prologue.)
+    auto key_meta2 = [&](int64_t k, int& c, float& nb) {
+        const bool in = k < S;
+        const int cr = MASKED ? code[seq * S + (in ? k : S - 1)] : 0;
+        c = (MASKED && in) ? cr : CODE_NONE;
+        nb = in ? (MASKED ? NEG_BIG2 : 0.f) : -INFINITY;
+    };
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b
+        const unsigned so = (unsigned)t * tile_step;
+        char* kd = Ks[b] + wave * 2048;
+        char* vd = Vs[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
+    };
+    // The prologue's requests, all in flight before anything waits (see the dQ kernel): the first batch of the key table, this lane's query fragments
+    // and codes (rows clamped into the sequence, the values discarded afterwards), the first key tile's DMA.  The table is padded to a multiple of
+    // 12 tiles so that a batch's stores are unconditional: under `if (tile < nt)` the compiler sinks the batch's LOADS into the branch, behind everything.
+    const int nt = (int)((S + TK - 1) / TK);
+    const int ntp = (nt + 11) / 12 * 12;
+    int32_t* const Cs = reinterpret_cast<int32_t*>(fwd_dyn);
+    float* const Ns = fwd_dyn + ntp * TK;
+    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + ntp * TK);
+    int c3[3];
+    float n3[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) key_meta2((int64_t)(wave + 4 * u) * TK + lane, c3[u], n3[u]);
+    auto table_put = [&](int t0) {               // wave w fills and classifies tiles w, w + 4, ... (lane = key)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            Ns[t * TK + lane] = n3[u];
+            if (MASKED) { Cs[t * TK + lane] = c3[u]; const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
+        }
+    };
+
     bf16x8 qf[QB][2];
     int64_t qi[QB];
     int cq[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         qi[qb] = q0 + (wave * QB + qb) * 16 + i;
+        const int64_t row = qi[qb] < S ? qi[qb] : S - 1;
 #pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (qi[qb] < S) v = *reinterpret_cast<const u32x4*>(base + qi[qb] * ld + h * 64 + dd * 32 + g * 8);
-            qf[qb][dd] = __builtin_bit_cast(bf16x8, v);
+        for (int dd = 0; dd < 2; ++dd) qf[qb][dd] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + row * ld + h * 64 + dd * 32 + g * 8));
+        cq[qb] = MASKED ? code[seq * S + row] : 0;
+    }
+    stage(0, 0);                                 // (behind the fragment requests: ahead of them the unmasked forward measured 1.2 us slower, scripts/ab_q.sh)
+    __builtin_amdgcn_sched_barrier(0);
+    table_put(wave);
+    for (int t0 = wave + 12; t0 < nt; t0 += 12) {      // (S > 768)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) key_meta2((int64_t)(t0 + 4 * u) * TK + lane, c3[u], n3[u]);
+        table_put(t0);
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        if (qi[qb] >= S) {
+            cq[qb] = 0;
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) qf[qb][dd] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
         }
-        cq[qb] = (MASKED && qi[qb] < S) ? code[seq * S + qi[qb]] : 0;
         if (MASKED && cq[qb] < 0) cq[qb] = CODE_PADQ;            // a PAD query matches no key code (a PAD key's is -1)
     }
     // this wave's queries: one common valid code?  (queries beyond the sequence are never stored: wildcards; a wave without any query inside
@@ -323,56 +386,6 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_fwd_kernel(const __bf16
         for (int db = 0; db < 4; ++db) ot[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // K / V of this (sequence, head): rows beyond S are beyond the descriptors' extent (zero fill); the tile advance is a scalar offset
-    const __bf16* Kg = base + H + h * 64;
-    const __bf16* Vg = base + 2 * H + h * 64;
-    const int ext = (int)(((S - 1) * ld + 64) * 2);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
-    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
-    const unsigned tile_step = (unsigned)(TK * ld * 2);
-    // Per-key staging: the additive bias a score gets unless the key is allowed for the query, in the exp2 domain -- the reference's
-    // literal -1e10 for a key inside the sequence (an unmasked tower allows every such key: 0), -inf beyond it -- and, masked only, the
-    // key's code.  A score is then fma(raw, SCALE2, allowed ? 0 : bias): compare + select + FMA (unmasked: the FMA alone).  A PAD
-    // query's code equals no key's, so all its scores round to the same -1e10 log2 e inside the sequence (-inf outside): uniform over
-    // the S keys, as in the reference.
-    auto key_meta2 = [&](int64_t k, int& c, float& nb) {
-        const bool in = k < S;
-        c = (MASKED && in) ? code[seq * S + k] : CODE_NONE;
-        nb = in ? (MASKED ? NEG_BIG2 : 0.f) : -INFINITY;
-    };
-    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b
-        const unsigned so = (unsigned)t * tile_step;
-        char* kd = Ks[b] + wave * 2048;
-        char* vd = Vs[b] + wave * 2048;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
-    };
-
-    const int nt = (int)((S + TK - 1) / TK);
-    int32_t* const Cs = reinterpret_cast<int32_t*>(fwd_dyn);
-    float* const Ns = fwd_dyn + nt * TK;
-    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + nt * TK);
-    stage(0, 0);
-    for (int t0 = wave; t0 < nt; t0 += 12) {      // wave w fills and classifies tiles w, w + 4, ... (lane = key); three tiles' loads in flight at once
-        int c3[3];
-        float n3[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            c3[u] = CODE_NONE; n3[u] = -INFINITY;
-            if (t0 + 4 * u < nt) key_meta2((int64_t)(t0 + 4 * u) * TK + lane, c3[u], n3[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int t = t0 + 4 * u;
-            if (t < nt) {
-                Ns[t * TK + lane] = n3[u];
-                if (MASKED) { Cs[t * TK + lane] = c3[u]; const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
-            }
-        }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -555,26 +568,88 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
     const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
     const bool rot_short = rot_rows < S;
 
+    // The prologue's requests, ALL in flight before anything waits (round 5, stamps: scripts/attn_dq_stamps.py): the first key tile's DMA, then this
+    // lane's 12 fragment loads, its LSE and code -- from the row clamped into the sequence, the value discarded afterwards, because a load under `if (row < S)`
+    // is a basic block of its own and the compiler waited for each block's three loads before issuing the next: five serial round trips.  Measured: the
+    // dK / dV kernel's prologue 10.9 k -> 8.5 k cycles; this kernel's stays at 16.4 k of a first-round workgroup's 59 k -- it is bound by its BYTES (three
+    // resident workgroups x 64 KB per CU at the ~11 B / clk / CU a launch's first round gets: 17 k cycles), which later rounds hide under their neighbours.
+    const __bf16* Kg = base + H + h * 64;
+    const __bf16* Vg = base + 2 * H + h * 64;
+    const int ext = (int)(((S - 1) * ld + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
+    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned tile_step = (unsigned)(TK * ld * 2);
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b (as in the forward kernel)
+        const unsigned so = (unsigned)t * tile_step;
+        char* kd = Ks[b] + wave * 2048;
+        char* vd = Vs[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
+    };
+    stage(0, 0);
+    const int nt = (int)((S + TK - 1) / TK);
+    const int ntp = (nt + 11) / 12 * 12;
+    int32_t* const Cs = reinterpret_cast<int32_t*>(dq_dyn);
+    float* const Ns = dq_dyn + ntp * TK;
+    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + ntp * TK);     // masked: class of the key tile (tile_class)
+    // the key table: wave w fills and classifies tiles w, w + 4, ... (lane = key), three tiles per batch; the first batch's loads lead the prologue's
+    // requests.  Padded to a multiple of 12 tiles, so that a batch's stores are unconditional: under `if (tile < nt)` the compiler sinks the batch's
+    // LOADS into the branch, behind the fragment loads, and waits there for all of them
+    int c3[3];
+    float n3[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) key_meta((int64_t)(wave + 4 * u) * TK + lane, S, code_seq, MASKED, c3[u], n3[u]);
+    auto table_put = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            Cs[t * TK + lane] = c3[u];
+            Ns[t * TK + lane] = n3[u];
+            if (MASKED) { const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
+        }
+    };
+
     bf16x8 qf[QB][2], dof[QB][2];
     int qi[QB];      // (32-bit: S < 2^31; address arithmetic widens at the use)
     int cq[QB];
     float nlse2[QB], del[QB];
     bool padq[QB];
     bool any_pad = false, any_nz = false;
+    u32x4 raw_q[QB][2], raw_d[QB][2], raw_o[QB][2];
+    int raw_c[QB];
+    float raw_l[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         qi[qb] = (int)q0 + (wave * QB + qb) * 16 + i;
+        const int64_t row = qi[qb] < S ? qi[qb] : S - 1;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            raw_q[qb][dd] = *reinterpret_cast<const u32x4*>(base + row * ld + h * 64 + dd * 32 + g * 8);
+            raw_d[qb][dd] = *reinterpret_cast<const u32x4*>(dout + (seq * S + row) * H + h * 64 + dd * 32 + g * 8);
+            raw_o[qb][dd] = *reinterpret_cast<const u32x4*>(o + (seq * S + row) * H + h * 64 + dd * 32 + g * 8);
+        }
+        raw_c[qb] = MASKED ? code_seq[row] : 0;
+        raw_l[qb] = lse[(seq * nh + h) * S + row];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    table_put(wave);
+    for (int t0 = wave + 12; t0 < nt; t0 += 12) {      // (S > 768)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) key_meta((int64_t)(t0 + 4 * u) * TK + lane, S, code_seq, MASKED, c3[u], n3[u]);
+        table_put(t0);
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
         const bool ok = qi[qb] < S;
         float dsum = 0.f;
         unsigned nz = 0u;                             // any non-zero bit pattern (other than -0) in this lane's part of the dO row
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
-            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u}, x = {0u, 0u, 0u, 0u};
-            if (ok) {
-                v = *reinterpret_cast<const u32x4*>(base + (int64_t)qi[qb] * ld + h * 64 + dd * 32 + g * 8);
-                w = *reinterpret_cast<const u32x4*>(dout + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
-                x = *reinterpret_cast<const u32x4*>(o + (seq * S + qi[qb]) * H + h * 64 + dd * 32 + g * 8);
-            }
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            const u32x4 v = ok ? raw_q[qb][dd] : zero, w = ok ? raw_d[qb][dd] : zero, x = ok ? raw_o[qb][dd] : zero;
             nz |= (w[0] | w[1] | w[2] | w[3]) & 0x7fff7fffu;
             qf[qb][dd] = scale_eighth(v);             // the TRUE q also for PAD rows: the reference differentiates through them
             dof[qb][dd] = __builtin_bit_cast(bf16x8, w);
@@ -594,10 +669,10 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
         // reads their outputs) contributes exactly nothing to dQ, dK or dV (dS = P (0 - 0), dV += P^T 0) whatever its weights are: it is
         // marked with delta = -0.0 (its delta is +0.0 by arithmetic), so that the dK / dV kernel can skip query tiles made of such rows
         if (ok && g == 0) delta[(seq * nh + h) * S + qi[qb]] = (tile_modes != 0 && nz == 0u) ? -0.0f : dsum;
-        int c = ok ? (MASKED ? code_seq[qi[qb]] : 0) : CODE_PADQ;
+        int c = ok ? raw_c[qb] : CODE_PADQ;
         if (c < 0) c = CODE_PADQ;
         cq[qb] = c;
-        float L = ok ? lse[(seq * nh + h) * S + qi[qb]] : INFINITY;   // beyond the sequence: p = exp2(-inf) = 0
+        float L = ok ? raw_l[qb] : INFINITY;                          // beyond the sequence: p = exp2(-inf) = 0
         // a query row with no allowed key (PAD): the softmax is uniform over the S keys and its LSE is not representable:
         // take P = 1/S instead of exp(s - lse) -- unless its upstream gradient is zero (every PAD row of a training step): then
         // dS = P (0 - 0) = 0 whatever P is, and the row is treated like one beyond the sequence (p = 0) instead of costing its wave the uniform-row selects
@@ -635,45 +710,6 @@ __global__ __launch_bounds__(256, (MASKED ? MR_ATTN_OCC_DQ : MR_ATTN_OCC_DQ_UNMA
 #pragma unroll
         for (int db = 0; db < 4; ++db) dq[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* Kg = base + H + h * 64;
-    const __bf16* Vg = base + 2 * H + h * 64;
-    const int ext = (int)(((S - 1) * ld + 64) * 2);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Kg), 0, ext, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Vg), 0, ext, 0x00020000);
-    const unsigned so0 = dma_src(wave * 2, lane, ld), so1 = dma_src(wave * 2 + 1, lane, ld);
-    const unsigned tile_step = (unsigned)(TK * ld * 2);
-    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of key tile t -> buffer b (as in the forward kernel)
-        const unsigned so = (unsigned)t * tile_step;
-        char* kd = Ks[b] + wave * 2048;
-        char* vd = Vs[b] + wave * 2048;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd), 16, so0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, MR_LDS_PTR(void, kd + 1024), 16, so1, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd), 16, so0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, MR_LDS_PTR(void, vd + 1024), 16, so1, so, 0, 0);
-    };
-    const int nt = (int)((S + TK - 1) / TK);
-    int32_t* const Cs = reinterpret_cast<int32_t*>(dq_dyn);
-    float* const Ns = dq_dyn + nt * TK;
-    int32_t* const Ku = reinterpret_cast<int32_t*>(Ns + nt * TK);      // masked: class of the key tile (tile_class)
-    stage(0, 0);
-    for (int t0 = wave; t0 < nt; t0 += 12) {      // wave w fills and classifies tiles w, w + 4, ... (lane = key); three tiles' loads in flight at once
-        int c3[3];
-        float n3[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            c3[u] = CODE_NONE; n3[u] = -INFINITY;
-            if (t0 + 4 * u < nt) key_meta((int64_t)(t0 + 4 * u) * TK + lane, S, code_seq, MASKED, c3[u], n3[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int t = t0 + 4 * u;
-            if (t < nt) {
-                Cs[t * TK + lane] = c3[u];
-                Ns[t * TK + lane] = n3[u];
-                if (MASKED) { const int kur = tile_class(c3[u], (int64_t)(t + 1) * TK <= S); if (lane == 0) Ku[t] = kur; }
-            }
-        }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -850,6 +886,50 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
     const int seq_rot0 = rot_tab != nullptr ? (int)((seq * S) % rot_rows) : 0;      // (uniform; once per workgroup)
     const bool rot_short = rot_rows < S;
 
+    // The prologue's requests, all in flight before anything waits (see the dQ kernel): the first two query tiles' DMA, the first batch of the
+    // per-query table, this lane's K / V fragments and codes (rows clamped into the sequence, the values discarded afterwards)
+    const __bf16* Qg = base + h * 64;
+    const __bf16* Dg = dout + seq * S * H + h * 64;
+    const float* Lg = lse + (seq * nh + h) * S;
+    const float* Eg = delta + (seq * nh + h) * S;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Dg), 0, (int)(((S - 1) * H + 64) * 2), 0x00020000);
+    const unsigned sq0 = dma_src(wave * 2, lane, ld), sq1 = dma_src(wave * 2 + 1, lane, ld);
+    const unsigned sd0 = dma_src(wave * 2, lane, H), sd1 = dma_src(wave * 2 + 1, lane, H);
+    const unsigned q_step = (unsigned)(TK * ld * 2), d_step = (unsigned)(TK * H * 2);
+    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of query tile t (Q rows, dO rows) -> buffer b
+        char* qd = Qs[b] + wave * 2048;
+        char* dd_ = Ds[b] + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd), 16, sq0, (unsigned)t * q_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd + 1024), 16, sq1, (unsigned)t * q_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_), 16, sd0, (unsigned)t * d_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_ + 1024), 16, sd1, (unsigned)t * d_step, 0, 0);
+    };
+    const int nt = (int)((S + TK - 1) / TK);
+    const int ntp = (nt + 11) / 12 * 12;                               // (the table is filled in unconditional batches of 12 tiles: see the dQ kernel)
+    const int Sp = ntp * TK;
+    float* const Ls = dkv_dyn;
+    float* const Dl = Ls + Sp;
+    float* const Us = Dl + Sp;
+    int32_t* const Cs = reinterpret_cast<int32_t*>(Us + Sp);
+    int32_t* const Fs = Cs + Sp;                                       // tile has a LIVE row without allowed key
+    int32_t* const Qu = Fs + ntp;                                      // masked: the tile's common valid code over its live rows, CODE_MIXED or CODE_DEAD
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    float L3[3], e3[3];
+    int c3[3];
+    auto table_get = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = (t0 + 4 * u) * TK + lane;
+            const int qc = q < S ? q : (int)S - 1;
+            L3[u] = Lg[qc];
+            e3[u] = Eg[qc];
+            c3[u] = MASKED ? code_seq[qc] : 0;
+        }
+    };
+    table_get(wave);
+
     bf16x8 kf[KB][2], vf[KB][2];
     int64_t ki[KB];
     int ck[KB];
@@ -857,18 +937,61 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         ki[kb] = kbase + (wave * KB + kb) * 16 + i;
+        const int64_t row = ki[kb] < S ? ki[kb] : S - 1;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            kf[kb][dd] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + row * ld + H + h * 64 + dd * 32 + g * 8));
+            vf[kb][dd] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + row * ld + 2 * H + h * 64 + dd * 32 + g * 8));
+        }
+        ck[kb] = MASKED ? code_seq[row] : 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // wave w fills AND classifies tiles w, w + 4, ... (lane = query): the values are in its registers when it votes, so no barrier sits between the two
+    auto table_put = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = t0 + 4 * u;
+            const int q = t * TK + lane;
+            float L = q < S ? L3[u] : INFINITY;
+            const float eq = q < S ? e3[u] : 0.f;
+            const int cr = q < S ? c3[u] : CODE_PADQ;
+            // a PAD row whose upstream gradient is zero (marked delta = -0.0 by the dQ kernel) weighs nothing in dK / dV: an absent row (p = 0), see there
+            bool pad = MASKED && q < S && L < PAD_LSE;
+            if (pad && tile_modes != 0 && __float_as_uint(eq) == 0x80000000u) { pad = false; L = INFINITY; }
+            const float lrq = -L * LOG2E;
+            const int cq_ = (cr < 0) ? CODE_PADQ : cr;
+            Ls[q] = lrq;
+            Dl[q] = eq;
+            Cs[q] = cq_;
+            Us[q] = pad ? inv_S : 0.f;
+            const int fr = MASKED ? (int)__any(pad) : 0;
+            int qur = CODE_MIXED;
+            if (MASKED) {
+                // the tile's class over its LIVE rows: a row beyond the sequence or a PAD row with a zero upstream gradient has lr = -inf, i.e. p = 0
+                // under any bias -- a wildcard; a live PAD row weighs EVERY key: never uniform
+                const bool live = lrq != -INFINITY;
+                const unsigned long long bl = __ballot(live);
+                const int c0 = bl != 0ull ? __builtin_amdgcn_readlane(cq_, (int)__builtin_ctzll(bl)) : 0;
+                qur = (tile_modes == 0 || c0 < 0 || __any(live && cq_ != c0)) ? CODE_MIXED : c0;
+                // every row of the tile beyond the sequence or marked by the dQ kernel as having a zero upstream gradient (delta = -0.0): such a
+                // tile contributes exactly nothing to dK / dV and is skipped by every wave
+                if (tile_modes != 0 && !__any(q < S && __float_as_uint(eq) != 0x80000000u)) qur = CODE_DEAD;
+            }
+            if (lane == 0) { Fs[t] = fr; Qu[t] = qur; }
+        }
+    };
+    table_put(wave);
+    for (int t0 = wave + 12; t0 < nt; t0 += 12) { table_get(t0); table_put(t0); }      // (S > 768)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
         const bool ok = ki[kb] < S;
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
-            u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
-            if (ok) {
-                v = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + H + h * 64 + dd * 32 + g * 8);
-                w = *reinterpret_cast<const u32x4*>(base + ki[kb] * ld + 2 * H + h * 64 + dd * 32 + g * 8);
-            }
-            kf[kb][dd] = scale_eighth(v);             // (q . k) / 8 = q . (k / 8): exact
-            vf[kb][dd] = __builtin_bit_cast(bf16x8, w);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            kf[kb][dd] = scale_eighth(ok ? __builtin_bit_cast(u32x4, kf[kb][dd]) : zero);             // (q . k) / 8 = q . (k / 8): exact
+            if (!ok) vf[kb][dd] = __builtin_bit_cast(bf16x8, zero);
         }
-        ck[kb] = ok ? (MASKED ? code_seq[ki[kb]] : 0) : CODE_NONE;
+        ck[kb] = ok ? ck[kb] : CODE_NONE;
         nkl[kb] = ok ? NEG_BIAS : -INFINITY;
         unil[kb] = ok ? 1.0f : 0.0f;
     }
@@ -888,79 +1011,6 @@ __global__ __launch_bounds__(256, MR_ATTN_OCC) void attn_bwd_dkv_kernel(const __
 #pragma unroll
         for (int db = 0; db < 4; ++db) { dk[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const __bf16* Qg = base + h * 64;
-    const __bf16* Dg = dout + seq * S * H + h * 64;
-    const float* Lg = lse + (seq * nh + h) * S;
-    const float* Eg = delta + (seq * nh + h) * S;
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qg), 0, (int)(((S - 1) * ld + 64) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Dg), 0, (int)(((S - 1) * H + 64) * 2), 0x00020000);
-    const unsigned sq0 = dma_src(wave * 2, lane, ld), sq1 = dma_src(wave * 2 + 1, lane, ld);
-    const unsigned sd0 = dma_src(wave * 2, lane, H), sd1 = dma_src(wave * 2 + 1, lane, H);
-    const unsigned q_step = (unsigned)(TK * ld * 2), d_step = (unsigned)(TK * H * 2);
-    auto stage = [&](int t, int b) {             // this wave's 2 + 2 pieces of query tile t (Q rows, dO rows) -> buffer b
-        char* qd = Qs[b] + wave * 2048;
-        char* dd_ = Ds[b] + wave * 2048;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd), 16, sq0, (unsigned)t * q_step, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, MR_LDS_PTR(void, qd + 1024), 16, sq1, (unsigned)t * q_step, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_), 16, sd0, (unsigned)t * d_step, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, MR_LDS_PTR(void, dd_ + 1024), 16, sd1, (unsigned)t * d_step, 0, 0);
-    };
-    const int nt = (int)((S + TK - 1) / TK);
-    const int Sp = nt * TK;
-    float* const Ls = dkv_dyn;
-    float* const Dl = Ls + Sp;
-    float* const Us = Dl + Sp;
-    int32_t* const Cs = reinterpret_cast<int32_t*>(Us + Sp);
-    int32_t* const Fs = Cs + Sp;                                       // tile has a LIVE row without allowed key
-    int32_t* const Qu = Fs + nt;                                       // masked: the tile's common valid code over its live rows, CODE_MIXED or CODE_DEAD
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    // wave w fills AND classifies tiles w, w + 4, ... (lane = query): the values are in its registers when it votes, so no barrier sits between the two;
-    // three tiles per batch, every load of a batch in flight at once
-    for (int t0 = wave; t0 < nt; t0 += 12) {
-        float L3[3], e3[3];
-        int c3[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int q = (t0 + 4 * u) * TK + lane;
-            const bool ok = t0 + 4 * u < nt && q < S;
-            L3[u] = ok ? Lg[q] : INFINITY;
-            e3[u] = ok ? Eg[q] : 0.f;
-            c3[u] = ok ? (MASKED ? code_seq[q] : 0) : CODE_PADQ;
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int t = t0 + 4 * u;
-            if (t < nt) {                        // (wave-uniform)
-                const int q = t * TK + lane;
-                float L = L3[u];
-                const float eq = e3[u];
-                // a PAD row whose upstream gradient is zero (marked delta = -0.0 by the dQ kernel) weighs nothing in dK / dV: an absent row (p = 0), see there
-                bool pad = MASKED && q < S && L < PAD_LSE;
-                if (pad && tile_modes != 0 && __float_as_uint(eq) == 0x80000000u) { pad = false; L = INFINITY; }
-                const float lrq = -L * LOG2E;
-                const int cq_ = (c3[u] < 0) ? CODE_PADQ : c3[u];
-                Ls[q] = lrq;
-                Dl[q] = eq;
-                Cs[q] = cq_;
-                Us[q] = pad ? inv_S : 0.f;
-                const int fr = MASKED ? (int)__any(pad) : 0;
-                int qur = CODE_MIXED;
-                if (MASKED) {
-                    // the tile's class over its LIVE rows: a row beyond the sequence or a PAD row with a zero upstream gradient has lr = -inf, i.e. p = 0
-                    // under any bias -- a wildcard; a live PAD row weighs EVERY key: never uniform
-                    const bool live = lrq != -INFINITY;
-                    const unsigned long long bl = __ballot(live);
-                    const int c0 = bl != 0ull ? __builtin_amdgcn_readlane(cq_, (int)__builtin_ctzll(bl)) : 0;
-                    qur = (tile_modes == 0 || c0 < 0 || __any(live && cq_ != c0)) ? CODE_MIXED : c0;
-                    // every row of the tile beyond the sequence or marked by the dQ kernel as having a zero upstream gradient (delta = -0.0): such a
-                    // tile contributes exactly nothing to dK / dV and is skipped by every wave
-                    if (tile_modes != 0 && !__any(q < S && __float_as_uint(eq) != 0x80000000u)) qur = CODE_DEAD;
-                }
-                if (lane == 0) { Fs[t] = fr; Qu[t] = qur; }
-            }
-        }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1758,7 +1808,8 @@ extern "C" int mr_attention_fwd(const void* qkv, const int32_t* code, void* out,
     __bf16* o = static_cast<__bf16*>(out);
     const int tm = mr_opts().attn_tile_modes;
     const int64_t nt_ = (S + TK - 1) / TK;
-    const size_t fwd_smem = (size_t)(nt_ * TK * 8 + nt_ * 4);             // key codes, bias and tile classes of a sequence (dynamic LDS)
+    const int64_t ntp_ = (nt_ + 11) / 12 * 12;                            // (the kernels fill their tables in unconditional batches of 12 tiles)
+    const size_t fwd_smem = (size_t)(ntp_ * TK * 8 + ntp_ * 4);             // key codes, bias and tile classes of a sequence (dynamic LDS)
     MR_CHECK_ARG(fwd_smem <= 100 * 1024, "mr_attention_fwd: S = %ld is beyond what one workgroup's LDS holds (S <= 12 700)", (long)S);
     const bool two = S > attn_qb_threshold();        // short sequences (audio 31, span 16): one 16-query block per wave
     if (two && code) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), attn_grid<2>(S, nh, nseq), dim3(256), fwd_smem, s, q, code, o, lse, S, nh, tm);
@@ -1816,8 +1867,9 @@ extern "C" int mr_attention_bwd(const void* qkv, const int32_t* code, const void
     const int tm = mr_opts().attn_tile_modes;
     // the dK / dV kernel keeps a sequence's per-query scalars in dynamic LDS: 16 B per padded position + 8 B per tile (beside 52 KiB of static tiles)
     const int64_t nt_ = (S + TK - 1) / TK;
-    const size_t dkv_smem = (size_t)(nt_ * TK * 16 + nt_ * 8);
-    const size_t dq_smem = (size_t)(nt_ * TK * 8 + nt_ * 4);              // the dQ kernel: codes, bias and classes of the sequence's keys
+    const int64_t ntp_ = (nt_ + 11) / 12 * 12;                            // (the kernels fill their tables in unconditional batches of 12 tiles)
+    const size_t dkv_smem = (size_t)(ntp_ * TK * 16 + ntp_ * 8);
+    const size_t dq_smem = (size_t)(ntp_ * TK * 8 + ntp_ * 4);              // the dQ kernel: codes, bias and classes of the sequence's keys
     MR_CHECK_ARG(dkv_smem <= 100 * 1024, "mr_attention_bwd: S = %ld is beyond what one workgroup's LDS holds (S <= 6336)", (long)S);
 #define MR_LAUNCH_BWD(QB, M)                                                                                                  \
     do {                                                                                                                      \
