@@ -54,6 +54,12 @@ class Comm:
     def allreduce_mean_f32(self, t):
         return self.allreduce_mean(t)
 
+    def allgather_flat(self, src, dst):
+        """dst [world * n] = every rank's src [n], rank-major (any dtype): the parameter chunks of zero.MomentShards."""
+        assert dst.numel() == self.world * src.numel() and dst.dtype == src.dtype
+        dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group)
+        return dst
+
     def close(self):
         pass
 
@@ -180,6 +186,13 @@ class NativeComm:
         assert flat.dtype == torch.bfloat16
         self._lib.check(self._lib.load().mr_allreduce_mean_bf16(self._h, flat.data_ptr(), flat.numel(), self._stream()), 'mr_allreduce_mean_bf16')
         return flat
+
+    def allgather_flat(self, src, dst):
+        assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == src.dtype and dst.numel() == self.world * src.numel()
+        assert src.element_size() % 2 == 0
+        n16 = src.numel() * (src.element_size() // 2)      # an all-gather moves bytes: counted in 16-bit elements
+        self._lib.check(self._lib.load().mr_allgather(self._h, src.data_ptr(), dst.data_ptr(), n16, self._stream()), 'mr_allgather')
+        return dst
 
     def allreduce_mean_f32(self, t):
         assert t.is_contiguous() and t.dtype == torch.float32

@@ -212,9 +212,12 @@ class VCREngine(TowerEngine):
 class MerlotReserveVCR:
     """F:144-170"""
 
-    def __init__(self, config, device='cuda:0', rank=0, world=1, comm=None, seed=0):
+    def __init__(self, config, device='cuda:0', rank=0, world=1, comm=None, seed=0, shard_optimizer=False):
+        """shard_optimizer = True: the Adam moments are partitioned over the ranks of `comm` (FO:148-171; zero.py)."""
         self.config, self.device, self.rank, self.world, self.comm, self.seed = config, torch.device(device), rank, world, comm, seed
         self.params_store, self.engine, self._last_tree = None, None, None
+        self.shard_optimizer, self.shards = shard_optimizer, None
+        assert not shard_optimizer or comm is not None, 'shard_optimizer needs a communicator (its world may be 1)'
 
     @classmethod
     def from_config(cls, config, **kwargs):
@@ -226,8 +229,11 @@ class MerlotReserveVCR:
         B = int(batch['image'].shape[0])
         if self.engine is None:
             self.params_store = ParamStore(self.config, self.device, seed=self.seed, specs=vcr_param_specs(self.config),
-                                           decay_rule=decay_finetune, with_orig=True)
+                                           decay_rule=decay_finetune, with_orig=True, with_optimizer=not self.shard_optimizer)
             self.engine = VCREngine(self.config, B, self.params_store, self.device)
+            if self.shard_optimizer:
+                from .zero import MomentShards
+                self.shards = MomentShards(self.params_store, self.engine.gradient_buckets()[0], self.comm)
         elif self.engine.d.B != B:
             raise ValueError(f'this model was initialised for {self.engine.d.B} examples per device, got {B}')
         return self.engine
@@ -277,6 +283,12 @@ class FinetuneTrainState:
     def apply_gradients(self):
         """FO:77-90 + apply_updates, one fused launch over the flat buffers."""
         oc, p = self.opt_config, self._model.params_store
+        if self._model.shards is not None:        # partitioned moments: bucket by bucket, each rank its chunk; a COLLECTIVE
+            self.prepare_step()
+            for key in self._model.shards.table:
+                self._model.shards.update(key, self.apply_shard)
+            self.step += 1
+            return self
         sched, neg_lr, bc1, bc2 = self._scalars()
         ops.adam_bf16_update_finetune(p.master, p.work, p.grad, p.mu, p.nu, p.orig, p.decay_flags, oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                                       oc.get('eps', 1e-6), oc['weight_decay_rate'], sched, neg_lr, bc1, bc2)
@@ -304,12 +316,16 @@ class FinetuneTrainState:
             self._hyper_ev[i] = torch.cuda.Event()
             self._hyper_ev[i].record()
 
-    def apply_range(self, lo, hi):
+    def apply_range(self, lo, hi, mu=None, nu=None, transposed=True):
         oc, p = self.opt_config, self._model.params_store
-        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], p.orig[lo:hi],
-                                 p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98), oc.get('eps', 1e-6),
+        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], p.grad[lo:hi], p.mu[lo:hi] if mu is None else mu, p.nu[lo:hi] if nu is None else nu,
+                                 p.orig[lo:hi], p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98), oc.get('eps', 1e-6),
                                  oc['weight_decay_rate'], self.hyper)
-        p.update_transposed(lo, hi)
+        if transposed:
+            p.update_transposed(lo, hi)
+
+    def apply_shard(self, lo, hi, mu, nu):
+        self.apply_range(lo, hi, mu=mu, nu=nu, transposed=False)
 
 
 def construct_finetuning_train_state(opt_config, model, params=None, only_state=False):
@@ -353,7 +369,10 @@ def _backward_reduce_update(state):
             if comm is not None:
                 ops.nan_to_num_(p.grad[lo:hi])
                 comm.allreduce_mean(p.grad[lo:hi])
-            state.apply_range(lo, hi)
+            if model.shards is not None:
+                model.shards.update(key, state.apply_shard)
+            else:
+                state.apply_range(lo, hi)
     eng.backward_stage_joint()
     finish('joint')
     with ops.gemm_cus(comm.world if comm is not None else 1):      # a bucket's all-reduce runs beside the vision tower's GEMMs
@@ -411,7 +430,11 @@ def _finetune_train_step_scanned(state, batch):
         ops.nan_to_num_(p.grad)
         comm.allreduce_mean(p.grad)
     state.prepare_step()
-    state.apply_range(0, p.total)
+    if model.shards is not None:
+        for key in model.shards.table:
+            model.shards.update(key, state.apply_shard)
+    else:
+        state.apply_range(0, p.total)
     state.step += 1
     info = {k: float(np.mean([l[k] for l in losses])) for k in losses[0]}
     if comm is not None and comm.world > 1:

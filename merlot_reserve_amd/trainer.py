@@ -41,6 +41,7 @@ class TrainState:
         self.opt_config = dict(opt_config)
         self.step = 0
         self.f32_grads = False          # use_bfloat16_grads = False: the chain reads params.grad32 (set by Trainer(bf16_grads=False))
+        self.shards = None              # zero.MomentShards: mu / nu partitioned over the ranks (Trainer(shard_optimizer=True))
 
     def _scalars(self):
         """(sched, neg_lr, bias_corr1, bias_corr2) of the current step: scale_by_schedule uses its own count, evaluated
@@ -58,6 +59,12 @@ class TrainState:
     def apply_gradients(self):
         """optax chain of optimization.py:180-190 + apply_updates, one fused launch over the flat buffers."""
         oc, p = self.opt_config, self.params
+        if self.shards is not None:      # partitioned moments: bucket by bucket, each rank its chunk (zero.py); a COLLECTIVE
+            self.prepare_step()
+            for key in self.shards.table:
+                self.shards.update(key, self.apply_shard)
+            self.finish_step()
+            return
         if self.f32_grads:               # fp32 gradients: the device-scalar form of the same chain over the whole buffer
             self.prepare_step()
             self.apply_range(0, p.total)
@@ -90,14 +97,20 @@ class TrainState:
             self._hyper_ev[i] = torch.cuda.Event()
             self._hyper_ev[i].record()
 
-    def apply_range(self, lo, hi):
+    def apply_range(self, lo, hi, mu=None, nu=None, transposed=True):
+        """mu / nu: the moments of [lo, hi) when they do not live at p.mu[lo:hi] (zero.MomentShards)."""
         oc, p = self.opt_config, self.params
         assert lo % 2048 == 0 and hi % 2048 == 0
         grad = p.grad32 if self.f32_grads else p.grad
-        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], grad[lo:hi], p.mu[lo:hi], p.nu[lo:hi], None,
+        ops.adam_bf16_update_dev(p.master[lo:hi], p.work[lo:hi], grad[lo:hi], p.mu[lo:hi] if mu is None else mu,
+                                 p.nu[lo:hi] if nu is None else nu, None,
                                  p.decay_flags[lo // 2048:hi // 2048], oc.get('beta_1', 0.9), oc.get('beta_2', 0.98),
                                  oc.get('eps', 1e-8), oc['weight_decay_rate'], self.hyper)
-        p.update_transposed(lo, hi)
+        if transposed:
+            p.update_transposed(lo, hi)
+
+    def apply_shard(self, lo, hi, mu, nu):
+        self.apply_range(lo, hi, mu=mu, nu=nu, transposed=False)      # (MomentShards.update rewrites the bucket's transposed copies)
 
     def finish_step(self):
         self.step += 1
@@ -107,8 +120,9 @@ class TrainState:
     # serialised as dicts keyed '0'..'3' (merlot_reserve_amd/checkpoint.py writes / reads the msgpack file)
     def state_dict(self):
         p = self.params
+        mu, nu = (p.mu, p.nu) if self.shards is None else self.shards.full_moments()      # (partitioned: a collective)
         return {'step': self.step, 'params': p.master_tree(),
-                'opt_state': {'0': {'count': torch.tensor(self.step, dtype=torch.int32), 'mu': p._to_tree(p.mu), 'nu': p._to_tree(p.nu)},
+                'opt_state': {'0': {'count': torch.tensor(self.step, dtype=torch.int32), 'mu': p._to_tree(mu), 'nu': p._to_tree(nu)},
                               '1': {}, '2': {'count': torch.tensor(self.step, dtype=torch.int32)}, '3': {}}}
 
     def load_state_dict(self, sd, reset_schedule=False):
@@ -120,7 +134,8 @@ class TrainState:
         opt = sd.get('opt_state')
         if opt:
             adam = opt['0']
-            for flat, tree in ((p.mu, adam['mu']), (p.nu, adam['nu'])):
+            hosts = []
+            for tree in (adam['mu'], adam['nu']):
                 host = torch.zeros(p.total, dtype=torch.bfloat16)
                 for name, fshape, *_ in p.specs:
                     o, n = p.offsets[name]
@@ -128,7 +143,12 @@ class TrainState:
                     for k in name.split('/'):
                         leaf = leaf[k]
                     host[o:o + n] = leaf.reshape(-1).to(torch.bfloat16)
-                flat.copy_(host)
+                hosts.append(host)
+            if self.shards is None:
+                p.mu.copy_(hosts[0])
+                p.nu.copy_(hosts[1])
+            else:
+                self.shards.store_moments(hosts[0], hosts[1])
             self.step = int(adam.get('count', self.step))
         if reset_schedule:
             self.step = 0
@@ -141,16 +161,17 @@ def construct_train_state(opt_config, params):
 class Trainer:
     f32 = False          # (instances built by __init__ set it from bf16_grads)
 
-    def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None, bf16_grads=True):
+    def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None, bf16_grads=True, shard_optimizer=False):
         """bf16_grads = False is the reference's use_bfloat16_grads = False step (pretrain/pretrain_model.py:323-333; train.py:61-67): the
         fp32 master parameters are differentiated, the gradients stay fp32 through nan_to_num / pmean and enter the Adam chain as
         fp32 -- the fp32 program of the engine (mr_f32_* kernels, eager, several times slower than the bf16 step: the correctness
         path, not the benchmarked one).  Data parallel through either communicator (fp32 all-gather / reduce-scatter of the contrastive
-        embeddings, fp32 all-reduce of the gradient buckets)."""
+        embeddings, fp32 all-reduce of the gradient buckets).
+        shard_optimizer = True: the Adam moments are partitioned over the ranks of `comm` (pretrain/train_fixres.py:178-199; zero.py)."""
         self.config, self.B, self.rank, self.world = config, B, rank, world
         self.device = torch.device(device)
         self.f32 = not bf16_grads
-        self.params = ParamStore(config, self.device, seed=seed)          # same seed on every rank: replicated init
+        self.params = ParamStore(config, self.device, seed=seed, with_optimizer=not shard_optimizer)          # same seed on every rank: replicated init
         self.state = construct_train_state(config['optimizer'], self.params)
         self.state.f32_grads = self.f32
         self.engine = PretrainEngine(config, B, self.params, self.device, rank=rank, world=world,
@@ -163,6 +184,11 @@ class Trainer:
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self.graph = None
         self._make_buckets()
+        self.shards = None
+        if shard_optimizer:
+            assert self.use_comm, 'shard_optimizer needs a communicator (its world may be 1)'
+            from .zero import MomentShards
+            self.shards = self.state.shards = MomentShards(self.params, self.buckets, comm)
         if self.use_comm:
             assert comm.world == world and comm.rank == rank
             R, H = self.engine.R, self.engine.d.H
@@ -237,7 +263,9 @@ class Trainer:
                 ops.nan_to_num_(g)
                 self.comm.allreduce_mean(g)
             e_reduced = ev()
-            if update:
+            if update and self.shards is not None:
+                self.shards.update(key, self.state.apply_shard)
+            elif update:
                 self.state.apply_range(lo, hi)
             e_updated = ev()
         if tl is not None:

@@ -369,3 +369,82 @@ def test_two_rank_vcr_finetune_step_on_one_gpu(dev):
     assert r0['infos'] == r1['infos'], 'loss_info must be averaged over ranks'
     assert abs(r0['infos'][-1]['loss'] - 0.5 * (r0['local_last'] + r1['local_last'])) < 1e-6
     assert r0['local_last'] != r1['local_last']
+
+
+# ---- partitioned Adam moments (zero.py; pretrain/train_fixres.py:178-199, finetune/optimization.py:148-171) ----
+def _sharded_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from merlot_reserve_amd import finetune as F
+    from merlot_reserve_amd.dist import Comm
+    from merlot_reserve_amd.synthetic import make_batch
+    from merlot_reserve_amd.trainer import Trainer
+    from tests.test_vcr_gpu import vcr_cfg
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    cfg = _cfg()
+    B = 2
+    comm = Comm()
+    rep = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=comm)
+    sh = Trainer(cfg, B, dev, rank=rank, world=world, seed=0, comm=comm, shard_optimizer=True)
+    assert sh.params.mu is None and sh.shards.owned < sh.params.total
+    batches = [make_batch(cfg, B, seed=300 + rank + 10 * i, device=dev) for i in range(3)]
+    for b in batches:
+        rep.train_step(b, plan=rep.plan(b))
+        sh.train_step(b, plan=sh.plan(b))
+    torch.cuda.synchronize()
+    mu, nu = sh.shards.full_moments()
+    out = dict(master=torch.equal(sh.params.master, rep.params.master), work=torch.equal(sh.params.work, rep.params.work),
+               mu=torch.equal(mu, rep.params.mu.cpu()), nu=torch.equal(nu, rep.params.nu.cpu()), moved=bool((rep.params.mu != 0).any()),
+               owned=sh.shards.owned, total=sh.params.total)
+    if rep.params.workT is not None:
+        out['workT'] = torch.equal(sh.params.workT, rep.params.workT)
+    # checkpoint form: the sharded state's dict is the replicated one's, and loads back into either
+    sd_sh, sd_rep = sh.state.state_dict(), rep.state.state_dict()
+    flat = lambda t: torch.cat([v.reshape(-1).float() for _k, v in sorted(_leaves(t))])
+    out['state_dict'] = torch.equal(flat(sd_sh['opt_state']['0']['mu']), flat(sd_rep['opt_state']['0']['mu'])) and \
+        torch.equal(flat(sd_sh['opt_state']['0']['nu']), flat(sd_rep['opt_state']['0']['nu']))
+    sh2 = Trainer(cfg, B, dev, rank=rank, world=world, seed=1, comm=comm, shard_optimizer=True)
+    sh2.state.load_state_dict(sd_rep)
+    out['reload'] = torch.equal(sh2.shards.mu, sh.shards.mu) and torch.equal(sh2.shards.nu, sh.shards.nu) and torch.equal(sh2.params.master, rep.params.master)
+    # the finetuning step (four buckets, subtract_old_weights decay): same comparison
+    vcfg = vcr_cfg()
+    models = [F.MerlotReserveVCR.from_config(vcfg, device=dev, rank=rank, world=world, comm=comm, seed=0, shard_optimizer=s) for s in (False, True)]
+    vb = [F.make_vcr_batch(vcfg, 2, seed=70 + rank + 10 * i, device=dev) for i in range(2)]
+    states = []
+    for m in models:
+        m.init_from_dummy_batch(vb[0])
+        states.append(F.construct_finetuning_train_state(vcfg['optimizer'], m)[0])
+    for b in vb:
+        for st in states:
+            F.finetune_train_step(st, b, loss_fn=F.train_loss_fn)
+    torch.cuda.synchronize()
+    vmu, vnu = models[1].shards.full_moments()
+    p0, p1 = models[0].params_store, models[1].params_store
+    out['vcr'] = torch.equal(p0.master, p1.master) and torch.equal(p0.work, p1.work) and torch.equal(vmu, p0.mu.cpu()) and torch.equal(vnu, p0.nu.cpu()) \
+        and bool((p0.mu != 0).any())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def _leaves(tree, prefix=''):
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            yield from _leaves(v, prefix + k + '/')
+        else:
+            yield prefix + k, v
+
+
+def test_two_rank_sharded_adam_equals_replicated(dev):
+    """Adam moments partitioned over two ranks (each rank updates its chunk of every bucket, the fp32 parameters are all-gathered): bit for bit the
+    replicated optimizer, after three pretraining steps and two finetuning steps; the checkpoint forms are interchangeable."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, 30500 + (os.getpid() % 1000), ret), nprocs=world, join=True)
+    for r in range(world):
+        bad = [k for k, v in ret[r].items() if v is False]
+        assert not bad, (r, bad)
+        assert ret[r]['moved']
+    assert ret[0]['owned'] + ret[1]['owned'] == ret[0]['total']
