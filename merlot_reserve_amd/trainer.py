@@ -160,6 +160,7 @@ def construct_train_state(opt_config, params):
 
 class Trainer:
     f32 = False          # (instances built by __init__ set it from bf16_grads)
+    shards = None        # (zero.MomentShards when built with shard_optimizer=True)
 
     def __init__(self, config, B, device, rank=0, world=1, seed=0, comm=None, bf16_grads=True, shard_optimizer=False):
         """bf16_grads = False is the reference's use_bfloat16_grads = False step (pretrain/pretrain_model.py:323-333; train.py:61-67): the
