@@ -248,6 +248,12 @@ int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* log_scale, co
  */
 int mr_contrastive_lse(float* logits, int64_t ldl, int64_t L, int64_t V, int64_t own_off, float coef,
                        const int32_t* src, float* loss_out, float* diag, float* row_scratch, void* stream);
+/* ---- mask-LM branch of the loss (pretrain/pretrain_model.py:265-274: `text_preds`; no forward of the reference emits it) ----
+ * logits [n, V] fp32 (leading dimension ldl), labels [n] int32 in [0, V); rows with label 0 are masked out.
+ * out2[0] = -sum_r mask_r log_softmax(logits[r])[labels[r]] / sum_r mask_r;  out2[1] = sum_r mask_r.
+ * dlogits (nullable, [n, V] fp32, ldl) = d out2[0] / d logits.  row_scratch: 3 n floats.  Sums in a fixed order (no atomics). */
+int mr_masked_lm_xent(const float* logits, int64_t ldl, int64_t n, int64_t V, const int32_t* labels, float* out2,
+                      float* dlogits, float* row_scratch, void* stream);
 /* bf16 copy of an fp32 array */
 int mr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* hi = bf16(x), lo = bf16(x - hi): 16-bit-mantissa split of dL/dlogits, so that the two bf16 MFMA GEMMs on hi and lo

@@ -70,6 +70,7 @@ PROTOTYPES = {
     'mr_unit_norm_scale_fwd': (i32, [vp, i64, vp, vp, i64, vp, i64, i64, vp]),
     'mr_unit_norm_scale_bwd': (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i32, vp, i64, i64, vp]),
     'mr_contrastive_lse': (i32, [vp, i64, i64, i64, i64, f32, vp, vp, vp, vp, vp]),
+    'mr_masked_lm_xent': (i32, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     'mr_split_f32_to_bf16_hilo_rows': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_cast_f32_to_bf16': (i32, [vp, vp, i64, vp]),
     'mr_split_f32_to_bf16_hilo': (i32, [vp, vp, vp, i64, vp]),

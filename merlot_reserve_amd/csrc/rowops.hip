@@ -398,6 +398,60 @@ __global__ __launch_bounds__(256) void contrastive_lse_kernel(float* __restrict_
     if (lane == 0) row_out[row] = lse - numer;
 }
 
+// The mask-LM branch of loss_fn_given_preds (pretrain_model.py:265-274; no forward of the reference emits 'text_preds', the branch is kept for the
+// API's completeness): one wave per row.  scratch[r] = -log_softmax(logits[r])[label_r] for a row whose label is not 0, else 0; scratch[n + r] = 1 / 0
+// (the mask); scratch[2 n + r] = the row's log-sum-exp.
+__global__ __launch_bounds__(256) void masked_lm_rows_kernel(const float* __restrict__ logits, int64_t ldl, int64_t n, int64_t V,
+                                                             const int32_t* __restrict__ labels, float* __restrict__ scratch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = logits + row * ldl;
+    float mx = -INFINITY;
+    for (int64_t c = lane; c < V; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int64_t c = lane; c < V; c += 64) den += expf(x[c] - mx);
+    den = wave_sum(den);
+    const float lse = mx + logf(den);
+    const int lab = labels[row];
+    if (lane == 0) {
+        const bool on = lab != 0;
+        scratch[row] = on ? lse - x[lab] : 0.f;
+        scratch[n + row] = on ? 1.f : 0.f;
+        scratch[2 * n + row] = lse;
+    }
+}
+
+// out[0] = sum(nll) / sum(mask), out[1] = sum(mask): fixed-order tree, bitwise reproducible
+__global__ __launch_bounds__(256) void masked_lm_reduce_kernel(const float* __restrict__ scratch, int64_t n, float* __restrict__ out) {
+    __shared__ float red[2][256];
+    float a = 0.f, b = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { a += scratch[i]; b += scratch[n + i]; }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0] / red[1][0]; out[1] = red[1][0]; }
+}
+
+// dL/dlogits[r, c] = mask_r (softmax(logits[r])[c] - [c == label_r]) / sum(mask)
+__global__ __launch_bounds__(256) void masked_lm_grad_kernel(const float* __restrict__ logits, int64_t ldl, int64_t n, int64_t V,
+                                                             const int32_t* __restrict__ labels, const float* __restrict__ scratch,
+                                                             const float* __restrict__ out, float* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = logits + row * ldl;
+    float* d = dlogits + row * ldl;
+    const int lab = labels[row];
+    const float w = scratch[n + row] / out[1], lse = scratch[2 * n + row];
+    for (int64_t c = lane; c < V; c += 64) d[c] = w * (expf(x[c] - lse) - (c == lab ? 1.0f : 0.0f));
+}
+
 // loss_out[0] += coef * sum_l row[l];  diag[s] = sum over rows with source s of row[l], diag[3 + s] = their count (P:296-300)
 __global__ __launch_bounds__(256) void contrastive_reduce_kernel(const float* __restrict__ row, int64_t L, float coef,
                                                                  const int32_t* __restrict__ src, float* __restrict__ loss_out,
@@ -641,6 +695,19 @@ extern "C" int mr_unit_norm_scale_bwd(const void* x, int64_t ldx, const void* lo
                        static_cast<const __bf16*>(dy), lddy, static_cast<__bf16*>(dx), lddx, partials, rows, (int)H);
     hipLaunchKernelGGL(reduce_f32_ordered_kernel, dim3(1), dim3(256), 0, st, partials, nblk, 1.0f, dlog_scale, (int)accumulate);
     MR_CHECK_LAUNCH("mr_unit_norm_scale_bwd");
+    return MR_OK;
+}
+
+extern "C" int mr_masked_lm_xent(const float* logits, int64_t ldl, int64_t n, int64_t V, const int32_t* labels, float* out2,
+                                 float* dlogits, float* row_scratch, void* stream) {
+    MR_CHECK_ARG(logits && labels && out2 && row_scratch && n > 0 && V > 0 && ldl >= V, "mr_masked_lm_xent: bad args");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n + 3) / 4));
+    hipLaunchKernelGGL(masked_lm_rows_kernel, grid, dim3(256), 0, st, logits, ldl, n, V, labels, row_scratch);
+    hipLaunchKernelGGL(masked_lm_reduce_kernel, dim3(1), dim3(256), 0, st, row_scratch, n, out2);
+    if (dlogits != nullptr)
+        hipLaunchKernelGGL(masked_lm_grad_kernel, grid, dim3(256), 0, st, logits, ldl, n, V, labels, row_scratch, out2, dlogits);
+    MR_CHECK_LAUNCH("mr_masked_lm_xent");
     return MR_OK;
 }
 

@@ -560,6 +560,17 @@ def transpose_leaves(work, workT, leaves_dev, nleaf, tile_lo, tile_hi):
           'mr_transpose_leaves')
 
 
+def masked_lm_xent(logits, labels, out2, dlogits=None, scratch=None):
+    """P:265-274 (`text_preds`): logits [n, V] fp32, labels [n] int32; out2 = [masked mean NLL, number of unmasked rows]."""
+    n, V = logits.shape
+    assert logits.dtype == F32 and logits.stride(1) == 1 and labels.dtype == torch.int32 and labels.numel() == n
+    assert dlogits is None or (dlogits.dtype == F32 and dlogits.stride() == logits.stride())
+    scratch = torch.empty(3 * n, dtype=F32, device=logits.device) if scratch is None else scratch
+    check(_lib.load().mr_masked_lm_xent(logits.data_ptr(), logits.stride(0), n, V, labels.data_ptr(), out2.data_ptr(), _ptr(dlogits),
+                                        scratch.data_ptr(), _stream()), 'mr_masked_lm_xent')
+    return out2
+
+
 @_timed('optimizer')
 def cast_params(master, work):
     check(_lib.load().mr_cast_f32_to_bf16_params(master.data_ptr(), work.data_ptr(), master.numel(), _stream()),

@@ -18,7 +18,7 @@ them.  Everything numerical runs in the HIP library: there is no CPU path here, 
 """
 import torch
 
-from . import trainer as _trainer
+from . import ops, trainer as _trainer
 from .trainer import Trainer
 
 
@@ -99,6 +99,7 @@ def loss_fn_given_preds(preds):
     if not isinstance(preds, _Preds) or preds.engine is None:
         raise TypeError('loss_fn_given_preds expects the dict returned by MerlotReservePretrainer.apply')
     tr = preds.trainer
+    text_preds = preds.pop('text_preds', None)
     if tr.use_comm:
         tr.comm.gather_embeddings(preds.engine.E, tr.E_all)
         preds.engine.loss_and_grad_outputs(tr.E_all, tr.dE_all)
@@ -106,6 +107,17 @@ def loss_fn_given_preds(preds):
         preds.engine.loss_and_grad_outputs()
     info = preds.engine.loss_info()
     loss = info.pop('loss')
+    if text_preds is not None:
+        # P:265-274, the mask-LM special case: {'logits' [n, V], 'labels' [n]}, rows with label 0 masked out.  No forward of the reference (nor this
+        # one) emits the entry; a caller that adds it gets the reference's value under the reference's key, and d loss / d logits in
+        # text_preds['dlogits'] (fp32) -- the entry is outside the model's graph, so nothing flows back into the towers.
+        logits = text_preds['logits'].to(torch.float32).contiguous()
+        labels = torch.as_tensor(text_preds['labels']).to(device=logits.device, dtype=torch.int32).contiguous()
+        out2 = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        text_preds['dlogits'] = torch.empty_like(logits)
+        ops.masked_lm_xent(logits, labels, out2, dlogits=text_preds['dlogits'])
+        info['audio2text'] = float(out2[0])
+        loss = loss + info['audio2text']
     return loss, info
 
 

@@ -500,8 +500,15 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
 def loss_fn_given_preds(preds_per_device, rank=0):
     """P:262-303 for device ``rank`` of a virtual pmap: all_gather(y) is the rank-major concat over
     ``preds_per_device`` (P:290).  Pass a 1-element list for the single-device case."""
-    preds = preds_per_device[rank]
+    preds = dict(preds_per_device[rank])
     loss_info = {}
+    if 'text_preds' in preds:                                # P:265-274: the mask-LM special case (no forward of the reference emits it)
+        tp = preds.pop('text_preds')
+        logits, labels = tp['logits'], tp['labels'].long()
+        onehot = torch.nn.functional.one_hot(labels, logits.shape[1]).to(logits.dtype)
+        logprobs = torch.log_softmax(logits, dim=-1)
+        mask = (labels != 0).to(logits.dtype)
+        loss_info['audio2text'] = -((logprobs * onehot).sum(-1) * mask).sum() / mask.sum()
     for c_type, c_dict in preds.items():
         numer = (c_dict['x'] * c_dict['y']).sum(-1)
         loss_info[c_type] = 0.0

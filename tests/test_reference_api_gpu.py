@@ -42,6 +42,26 @@ def test_train_py_call_sequence(dev):
     assert set(loss_info) == set(oinfo)
     assert abs(loss - float(oloss)) <= 2e-2 * abs(float(oloss))
 
+    # the mask-LM special case of the loss (pretrain_model.py:265-274): a caller-supplied 'text_preds' entry adds the masked token cross-entropy under the key
+    # 'audio2text' -- against the oracle's restatement and against autograd for d loss / d logits
+    gtp = torch.Generator().manual_seed(3)
+    n, V = 37, 32768
+    logits = (torch.randn(n, V, generator=gtp) * 3).to(dev)
+    labels = torch.randint(1, V, (n,), generator=gtp)
+    labels[::5] = 0                                                # masked rows
+    preds2 = state.apply_fn({'params': params}, dummy_batch, split_from_here=splits, gumbel_z=z)
+    tp = {'logits': logits, 'labels': labels}
+    preds2['text_preds'] = tp                                      # (popped by the loss function, like the reference's preds.pop)
+    loss2, info2 = loss_fn_given_preds(preds2)
+    lg = logits.detach().cpu().double().requires_grad_(True)
+    oloss2, oinfo2 = R.loss_fn_given_preds([dict(opreds, text_preds={'logits': lg, 'labels': labels})])
+    assert set(info2) == set(oinfo2) == set(oinfo) | {'audio2text'}
+    assert abs(info2['audio2text'] - float(oinfo2['audio2text'].detach())) <= 1e-5 * abs(float(oinfo2['audio2text'].detach()))
+    assert abs(loss2 - (loss + info2['audio2text'])) <= 1e-6 * abs(loss2)
+    oinfo2['audio2text'].backward()
+    assert 'text_preds' not in preds2 and relerr(tp['dlogits'], lg.grad) <= 1e-5
+    assert float(tp['dlogits'][::5].abs().max()) == 0.0
+
     # two optimizer steps through train_step; step 0 has schedule 0 (first update is zero, optimization.py:117-137)
     before = state.params
     state, info0 = train_step(state, dummy_batch)
