@@ -397,6 +397,15 @@ int mr_reducescatter_sum(mr_comm* comm, const void* send, void* recv, int64_t n_
  * 2 * n_per_rank) */
 int mr_reducescatter_sum_f32(mr_comm* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
 
+/* ---- host-side record I/O of the real-data input path (pretrain/dataloader.py:884 `tf.data.TFRecordDataset`; no GPU involved) ----
+ * CRC-32C (Castagnoli), crc = running value (0 to start); the masked form TFRecord files store is rotr(crc, 15) + 0xa282ead8. */
+uint32_t mr_crc32c(const void* data, int64_t n, uint32_t crc);
+uint32_t mr_crc32c_masked(const void* data, int64_t n);
+/* Walks a TFRecord byte image (uint64 length | masked crc of the length | data | masked crc of the data, little endian): returns the number of
+ * records and writes the first `cap` (offset of the data, its length) pairs; verify != 0 checks both checksums of every record.
+ * < 0 (MR_EINVAL, text in mr_last_error) for a truncated or corrupted image. */
+int64_t mr_tfrecord_scan(const void* buf, int64_t n, int64_t* offsets, int64_t* lengths, int64_t cap, int32_t verify);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,9 @@ PROTOTYPES = {
     'mr_allgather': (i32, [vp, vp, vp, i64, vp]),
     'mr_reducescatter_sum': (i32, [vp, vp, vp, i64, vp]),
     'mr_reducescatter_sum_f32': (i32, [vp, vp, vp, i64, vp]),
+    'mr_crc32c': (C.c_uint32, [vp, i64, C.c_uint32]),
+    'mr_crc32c_masked': (C.c_uint32, [vp, i64]),
+    'mr_tfrecord_scan': (i64, [vp, i64, vp, vp, i64, i32]),
 }
 
 _lib = None

@@ -29,7 +29,7 @@ EXTRA_FLAGS = {'attention.hip': ['-fno-slp-vectorize'], 'layernorm.hip': ['-fno-
 # object is kept under build/ (a by-product of the object's own compile, --save-temps) and build() fails if such an instruction appears.
 SLP_FILES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip']        # the files that keep the SLP vectoriser (packed epilogues)
 HAZARD_RE = r'^\s*v_pk_(add|mul|fma|min|max)_f32\b.*\bop_sel:\['
-SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'f32bwd.hip', 'mr_error.cpp', 'comm.cpp']
+SOURCES = ['gemm.hip', 'gemm256.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'attention.hip', 'layernorm.hip', 'rowops.hip', 'adam.hip', 'f32path.hip', 'f32bwd.hip', 'mr_error.cpp', 'comm.cpp', 'hostio.cpp']
 HIP_FILES = [f for f in SOURCES if f.endswith('.hip')]
 # Register spills (metadata .vgpr_spill_count / .sgpr_spill_count of every kernel in the device assembly): a spill inside a k-loop costs more than any
 # schedule gains (gemm4<256,0> with 183 spilled registers: 299 vs 91 us), so build() FAILS on a kernel with spilled vector registers unless it is

@@ -1,0 +1,187 @@
+"""The real-data input path without TensorFlow (merlot_reserve_amd/records.py + csrc/hostio.cpp; pretrain/dataloader.py:449-789): the container
+formats against known answers and round trips, the masking rules on hand-derived cases, the invariants a parsed record must satisfy, and
+acceptance of a record-fed batch by the planner.  (The reference holds no recorded batch: structure is all there is to pin.)"""
+import struct
+
+import numpy as np
+import pytest
+
+from merlot_reserve_amd import records as R
+from merlot_reserve_amd.config import Dims, load_config, tiny_config
+from merlot_reserve_amd.synthetic import AUDIOSPAN, LTOVPOOL, MASK, MASKAUDIO, make_batch
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 B.4 test vectors; the masked form of TFRecord files."""
+    lib = R._lib()
+    assert lib.mr_crc32c(b'123456789', 9, 0) == 0xE3069283
+    assert lib.mr_crc32c(bytes(32), 32, 0) == 0x8A9136AA
+    assert lib.mr_crc32c(bytes([0xff] * 32), 32, 0) == 0x62A8AB43
+    assert lib.mr_crc32c(bytes(range(32)), 32, 0) == 0x46DD794E
+    assert lib.mr_crc32c(bytes(range(31, -1, -1)), 32, 0) == 0x113FDB5C
+    a = bytes(range(200)) * 7 + b'xyz'                                  # unaligned start, odd length, running value
+    assert lib.mr_crc32c(a[5:], len(a) - 5, lib.mr_crc32c(a[:5], 5, 0)) == lib.mr_crc32c(a, len(a), 0)
+    c = lib.mr_crc32c(b'123456789', 9, 0)
+    assert lib.mr_crc32c_masked(b'123456789', 9) == ((((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff)
+
+
+def test_tfrecord_framing_round_trip_and_corruption(tmp_path):
+    recs = [b'', b'a', bytes(range(256)) * 33, b'tail']
+    fn = tmp_path / 'x.tfrecord'
+    R.write_tfrecord(fn, recs)
+    assert R.read_tfrecord(fn) == recs
+    raw = bytearray(fn.read_bytes())
+    assert struct.unpack('<Q', raw[:8])[0] == 0 and len(raw) == sum(16 + len(r) for r in recs)
+    bad = bytearray(raw)
+    bad[16 + 16 + 1 + 12 + 100] ^= 1                                     # one bit inside the third record's data
+    with pytest.raises(ValueError, match='record 2'):
+        R.read_tfrecord(bytes(bad))
+    assert R.read_tfrecord(bytes(bad), verify=False)[3] == b'tail'
+    with pytest.raises(ValueError, match='past the end|truncated'):
+        R.read_tfrecord(bytes(raw[:-3]))
+    bad = bytearray(raw)
+    bad[16] ^= 4                                                         # the second record's length field
+    with pytest.raises(ValueError, match='record 1'):
+        R.read_tfrecord(bytes(bad))
+
+
+def test_example_round_trip_and_unpacked_lists():
+    feats = {'a/bytes': b'\x00\xffjpeg', 'b/ints': np.array([0, 1, -1, 2 ** 40, -2 ** 62]), 'c/floats': np.array([0.5, -3.25, 1e-8], np.float32),
+             'd/empty': [], 'e/two': [b'x', b'yz'], 'f/scalar': 7}
+    ex = R.parse_example(R.make_example(feats))
+    assert ex['a/bytes'] == [b'\x00\xffjpeg'] and ex['e/two'] == [b'x', b'yz']
+    assert ex['b/ints'].tolist() == [0, 1, -1, 2 ** 40, -2 ** 62] and ex['f/scalar'].tolist() == [7]
+    assert np.array_equal(ex['c/floats'], feats['c/floats']) and len(ex['d/empty']) == 0
+    # a writer that does not pack: one varint / one fixed32 per value
+    ld = R._ld
+    ints = ld(3, b''.join(b'\x08' + R._enc_varint(v) for v in (5, -2)))
+    floats = ld(2, b''.join(b'\x0d' + struct.pack('<f', v) for v in (1.5, 2.5)))
+    msg = ld(1, ld(1, ld(1, b'i') + ld(2, ints)) + ld(1, ld(1, b'f') + ld(2, floats)))
+    ex = R.parse_example(msg)
+    assert ex['i'].tolist() == [5, -2] and ex['f'].tolist() == [1.5, 2.5]
+
+
+def test_ragged_shifts_by_hand():
+    t = R.Ragged(np.arange(10, 20), [3, 0, 4, 3])                        # rows: [10 11 12] [] [13 14 15 16] [17 18 19]
+    a = R.shift_ragged_tokens_at_positions(t, [2], right_to_left=True)   # row 2 hands its FIRST token to row 1
+    assert [r.tolist() for r in a.rows()] == [[10, 11, 12], [13], [14, 15, 16], [17, 18, 19]]
+    b = R.shift_ragged_tokens_at_positions(t, [0, 1], right_to_left=False)   # row 0 hands its LAST token to row 1; row 1 is empty: nothing to give
+    assert [r.tolist() for r in b.rows()] == [[10, 11], [12], [13, 14, 15, 16], [17, 18, 19]]
+    # an empty masked row takes from an unmasked neighbour with >= 2 tokens, never from a masked one or from a row of one
+    rng = np.random.default_rng(0)
+    c = R.reassign_empty_tokens(rng, t, mask_idx=[1])
+    assert c.row_lengths[1] == 1 and c.row_lengths.sum() == 10 and (c.row_lengths[[0, 2]].tolist() in ([2, 4], [3, 3]))
+    d = R.reassign_empty_tokens(rng, R.Ragged(np.arange(4), [1, 0, 3]), mask_idx=[1, 2])
+    assert d.row_lengths.tolist() == [1, 0, 3]
+    # increase_textmask: row 1 (masked, audio window 1.0 .. 2.0) takes the token at 2.05 s from its right neighbour but not the one at 0.2 s on the left
+    t2 = R.Ragged(np.arange(6), [2, 1, 3])
+    cent = np.array([0.2, 0.2, 1.5, 2.05, 2.6, 2.9], np.float32)
+    se = np.array([[0, 1], [1, 2], [2, 3]], np.float32)
+    e = R.increase_textmask(np.random.default_rng(1), t2, [1], cent, se, delta_thresh=0.125)
+    assert e.row_lengths.tolist() == [2, 2, 2]
+
+
+def test_mask_tokens_and_select_tokens():
+    rng = np.random.default_rng(0)
+    t = R.Ragged(np.arange(100, 112), [2, 3, 1, 2, 0, 4])
+    spans, groups = R.mask_tokens(rng, t, [3, 1], do_audio_span=np.array([1, 1, 0, 1, 1, 1], bool), audio_token_length=2, text_span_start_counter=7,
+                                  num_groups=2, padded_seq_len=8, do_audio_mask=False)
+    assert [s.tolist() for s in spans] == [[102, 103, 104], [106, 107]]  # the ORIGINAL rows at the sorted indices 1, 3
+    g0, g1 = groups
+    assert g0.tolist() == [[AUDIOSPAN, 0, -1], [AUDIOSPAN, 0, -1], [MASK, 1, 7], [105, 2, -1]] + [[0, -1, -1]] * 4
+    assert g1.tolist() == [[MASK, 3, 8], [AUDIOSPAN, 4, -1], [AUDIOSPAN, 4, -1], [AUDIOSPAN, 5, -1], [AUDIOSPAN, 5, -1]] + [[0, -1, -1]] * 3
+    _, (g,) = R.mask_tokens(rng, t, [0], do_audio_mask=True)
+    assert g[:2].tolist() == [[MASK, 0, 0], [MASKAUDIO, 0, 0]] and len(g) == 2 + 10
+    # an over-long stream keeps every MASK and exactly the budget
+    long = R.Ragged(rng.integers(11, 999, size=400), [10] * 40)
+    _, (s,) = R.mask_tokens(rng, long, np.arange(0, 40, 4), num_groups=1, padded_seq_len=64)
+    assert s.shape == (64, 3) and (s[:, 0] == MASK).sum() == 10 and (np.diff(s[:, 1]) >= 0).all()
+
+
+def _check_record(f, cfg, d):
+    ntrg, budget = d.ntrg, d.budget
+    nseg, nsub = d.nseg, d.nas
+    assert f['images'].shape == (nseg, d.hw, d.pp3) and f['images'].dtype == np.float32 and 0.0 <= f['images'].min() and f['images'].max() <= 1.0
+    assert f['audio_clips'].shape == (nseg, nsub, d.a_raw, 65) and (f['audio_clips'][..., 64] == 1.0).all()
+    t2a, a2t = f['text2audio'], f['audio2text']
+    assert t2a.shape == a2t.shape == (d.ngroups, d.lang, 3)
+    flat = t2a.reshape(-1, 3)
+    m = flat[flat[:, 0] == MASK]
+    assert len(m) == ntrg and sorted(m[:, 2].tolist()) == list(range(ntrg)) and (np.diff(m[:, 1]) > 0).all()
+    ma = flat[flat[:, 0] == MASKAUDIO]
+    assert set(map(tuple, ma[:, 1:].tolist())) <= set(map(tuple, m[:, 1:].tolist()))
+    flat = a2t.reshape(-1, 3)
+    m2 = flat[flat[:, 0] == MASK]
+    assert len(m2) == ntrg and sorted(m2[:, 2].tolist()) == list(range(ntrg, 2 * ntrg))
+    assert not set(m[:, 1].tolist()) & set(m2[:, 1].tolist()), 'the two directions mask different audio spans'
+    for g in range(d.ngroups):
+        for s in (t2a[g], a2t[g]):
+            live = s[s[:, 1] >= 0]
+            per = (nseg * nsub) // d.ngroups
+            assert (np.diff(live[:, 1]) >= 0).all() and live[:, 1].min() >= g * per and live[:, 1].max() < (g + 1) * per
+            assert (s[len(live):] == [0, -1, -1]).all()
+    mt = f['audio_text_matching']
+    assert mt.shape == (d.seq_len, 3) and (mt[:, 2] == -1).all()
+    pools = mt[mt[:, 0] == LTOVPOOL]
+    assert 0 < len(pools) <= nseg and pools[:, 1].tolist() == [i * nsub for i in range(len(pools))]
+    rt = f['random_text']
+    assert rt.shape == (1, d.seq_len, 3)
+    mr = rt[0][rt[0][:, 0] == MASK]
+    assert len(mr) == budget and mr[:, 2].tolist() == list(range(2 * ntrg, 2 * ntrg + budget))
+    assert f['text_spans'].shape == (2 * ntrg + budget, d.span_len)
+    assert f['video_src_index'].shape == (nseg,)
+
+
+@pytest.mark.parametrize('name', ['tiny', 'base'])
+def test_dataset_parser_invariants(name):
+    cfg = tiny_config() if name == 'tiny' else load_config('base')
+    d = Dims(cfg, 1)
+    rng = np.random.default_rng(3)
+    for k in range(2 if name == 'base' else 6):
+        rec = R.make_synthetic_record(cfg, rng)
+        f = R.dataset_parser(rec, cfg, rng=np.random.default_rng(100 + k))
+        _check_record(f, cfg, d)
+        g = R.dataset_parser(rec, cfg, rng=np.random.default_rng(100 + k))
+        assert all(np.array_equal(f[k2], g[k2]) for k2 in f if isinstance(f[k2], np.ndarray)), 'same seed, same record'
+    # token conservation in the text -> audio direction (when nothing had to be cut): unmasked tokens + masked spans = every token of the record
+    ex = R.parse_example(rec)
+    all_tok = np.concatenate([np.asarray(ex.get(f'c{i:02d}/tok_ids', []), dtype=np.int64) for i in range(d.nseg)])
+    flat = f['text2audio'].reshape(-1, 3)
+    kept = flat[(flat[:, 1] >= 0) & (flat[:, 0] != MASK) & (flat[:, 0] != MASKAUDIO), 0]
+    spans = f['text_spans'][:d.ntrg]
+    assert set(kept.tolist()) <= set(all_tok.tolist())
+    if (f['text2audio'][:, -1, 1] == -1).all() and (spans[:, -1] == 0).all():     # no stream was cut by select_tokens, no span by the 15-token limit
+        assert len(kept) + int((spans != 0).sum()) == len(all_tok)
+
+
+def test_batch_matches_the_synthetic_layout_and_feeds_the_planner(tmp_path):
+    from merlot_reserve_amd.planner import build_plan
+    from merlot_reserve_amd.synthetic import make_draws
+    cfg = tiny_config()
+    cfg['device'] = dict(cfg.get('device', {}), shuffle_buffer_size=4, batch_size=2, n_fns_per_cycle=2)
+    rng = np.random.default_rng(5)
+    fns = []
+    for s in range(2):
+        fn = tmp_path / f'train{s:05d}of00002.tfrecord'
+        R.write_tfrecord(fn, [R.make_synthetic_record(cfg, rng) for _ in range(3 + s)])
+        fns.append(str(fn))
+    B = 2
+    batches = list(R.make_dataset(cfg, fns, B, is_training=True, seed=11))
+    assert len(batches) == 3                                    # 7 records, remainder dropped
+    ref = make_batch(cfg, B, seed=0)
+    for b in batches:
+        assert set(b) == set(ref)
+        for k in ref:
+            assert tuple(b[k].shape) == tuple(ref[k].shape) and b[k].dtype == ref[k].dtype, k
+        d = Dims(cfg, B)
+        splits, z = make_draws(cfg, B, seed=1)
+        plan = build_plan(b, d, splits, z)           # the planner's own assertions on pointers and counts run here
+        assert plan is not None
+    again = list(R.make_dataset(cfg, fns, B, is_training=True, seed=11))
+    assert all(np.array_equal(x['text2audio'], y['text2audio']) for x, y in zip(batches, again))
+    threaded = list(R.make_dataset(cfg, fns, B, is_training=True, seed=11, workers=2))
+    assert all(np.array_equal(x['audio2text'], y['audio2text']) and bool((x['images'] == y['images']).all()) for x, y in zip(batches, threaded))
+    # the driver-level iterator: this rank's shards, one epoch
+    cfg['data'] = dict(cfg['data'], train_fns=str(tmp_path / 'train{:05d}of00002.tfrecord'), num_train_files=2)
+    assert len(list(R.input_fn_builder(cfg, rank=0, world=1, seed=2, epochs=1))) == 3
+    assert len(list(R.input_fn_builder(cfg, rank=1, world=2, seed=2, epochs=1))) == 4      # file 1 alone, batches of batch_size // world = 1
