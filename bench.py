@@ -31,10 +31,10 @@ def algorithmic_flops_per_record(config, train=True):
 
     def enc(n, S, L):
         return n * S * L * (24 * H * H + 4 * S * H)
-    fwd = enc(d.nseg, d.Sv, d.Lv) + enc(d.nspans, d.Sa, d.La) + enc(2 * d.ngroups + 2, d.Sj, d.Lj) + enc(d.n_inc, d.Ss, d.Ls)
+    fwd = enc(d.nseg, d.Sv, d.Lv) + enc(d.nspans, d.Sa, d.La) + enc(d.Nj // d.B, d.Sj, d.Lj) + enc(d.n_inc, d.Ss, d.Ls)
     fwd += d.nseg * d.hw * 2 * d.pp3 * H + d.nspans * d.a_len * 2 * 130 * H
     fwd += d.nseg * d.hw4 * 20 * H * H + d.nspans * d.a_tok * 24 * H * H
-    fwd += (d.nseg + d.nspans + d.n_inc) * 2 * H * H + (2 * d.ngroups + 2) * d.Sj * 2 * H * H
+    fwd += (d.nseg + d.nspans + d.n_inc) * 2 * H * H + (d.Nj // d.B) * d.Sj * 2 * H * H
     return fwd * (3 if train else 1)
 
 

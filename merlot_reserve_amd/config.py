@@ -66,12 +66,10 @@ class Dims:
         # Flags of the reference's pretrainer that change the program.  Built: no_vision (pretrain/pretrain_model.py:61-63: the pooled
         # vision sequence is multiplied by 0 on its way into the joint tower).  Not built -- a config that sets them would train a
         # different model, so it is refused instead of ignored: do_rotary = False (:146-148 drops the joint coordinates, which sends
-        # TransformerEncoder to its learned `pe`, mreserve/modeling.py:335-341), more than one audio2text / text2audio sequence per
-        # segment group (:99-110, :124-135 tile the inputs), heads of another width than 64 (mreserve/modeling.py:598).
+        # TransformerEncoder to its learned `pe`, mreserve/modeling.py:335-341), heads of another width than 64 (mreserve/modeling.py:598).
+        # Built since round 5: more than one audio2text / text2audio / random-text sequence per record (:99-110, :124-135 tile the inputs).
         if not m.get('do_rotary', True):
             raise NotImplementedError("model.do_rotary = False (learned position embeddings, mreserve/modeling.py:335-341) is not implemented")
-        if d.get('num_audio2text_seqs', 1) != 1 or d.get('num_text2audio_seqs', 1) != 1:
-            raise NotImplementedError('data.num_audio2text_seqs / num_text2audio_seqs other than 1 (pretrain/pretrain_model.py:99, 124) are not implemented')
         if m.get('size_per_head', 64) != 64:
             raise NotImplementedError('model.size_per_head other than 64 is not implemented (the attention kernels are written for 64)')
         self.no_vision = bool(m.get('no_vision', False))
@@ -87,7 +85,11 @@ class Dims:
         self.nspg = self.nseg // self.ngroups
         self.nas = d['num_audio_subsegments']
         self.nspans = self.nseg * self.nas
-        self.ntrg = int(self.nspans * d['mask_rate']) * d.get('num_text2audio_seqs', 1)
+        # sequences per record and kind (pretrain_model.py:99, 124; dataloader.py:500-501, 649): the stock configs use one of each
+        self.n_a2t, self.n_t2a, self.n_text = d.get('num_audio2text_seqs', 1), d.get('num_text2audio_seqs', 1), d.get('num_text_seqs', 1)
+        assert self.n_a2t >= 1 and self.n_t2a >= 1 and self.n_text >= 1, 'every stream of the joint batch needs at least one sequence per record'
+        self.ntrg1 = int(self.nspans * d['mask_rate'])          # masked audio spans per sequence
+        self.ntrg = self.ntrg1 * self.n_t2a                     # text -> audio targets per record (pretrain_model.py:178)
         self.lang = d['lang_seq_len']
         self.seq_len = d['seq_len']
         self.vis_len = self.nspg * self.hw4
@@ -100,14 +102,15 @@ class Dims:
         self.span_len = m['text_span_length']
         self.n_inc = d['num_text_spans_to_include']
         self.budget = d['text_span_budget']
-        self.ntext_spans = self.ntrg * 2 + self.budget        # rows of text_spans per record (62 for base)
+        self.ntext_spans = self.ntrg1 * (self.n_t2a + self.n_a2t) + self.budget * self.n_text      # rows of text_spans per record (62 for base)
         self.Lv, self.La, self.Lj, self.Ls = m['vit_num_layers'], m['audio_num_layers'], m['joint_num_layers'], m['span_num_layers']
         # sequence counts
         self.Nv = B * self.nseg                # images
         self.Sv = self.hw + 1
         self.Na = B * self.nspans              # audio clips
         self.Sa = self.a_len + 1
-        self.Nj = B * (2 * self.ngroups + 2)   # joint sequences: a2t(groups) + matching + random + t2a(groups)
+        self.rows_a2t, self.rows_t2a = self.ngroups * self.n_a2t, self.ngroups * self.n_t2a      # per record: sequence-major, group-minor (tile)
+        self.Nj = B * (self.rows_a2t + 1 + self.n_text + self.rows_t2a)   # joint sequences: a2t + matching + random + t2a
         self.Sj = self.seq_len
         self.Ns = B * self.n_inc               # selected spans
         self.Ss = self.span_len + 1

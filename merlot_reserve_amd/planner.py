@@ -121,19 +121,25 @@ def build_plan(batch, d, split_from_here, gumbel_z):
         code = VOCAB + (rec[:, None] * d.nspans + ptr) * d.a_tok + subpos
         return is_audio, code
 
-    def fill_grouped(row0, name, split, with_audio):
-        tokens = batch[name].astype(np.int64).reshape(BG, lang)
-        ap = batch[name + '/audio_ptr'].astype(np.int64).reshape(BG, lang)
-        rows = np.arange(BG)
-        sl = slice(row0, row0 + BG)
+    def fill_grouped(row0, name, split, with_audio, nseq):
+        # nseq sequences of this kind per record, each in G groups: rows (record, sequence, group) -- the reference tiles the vision input and
+        # video_src_index nseq times along the group axis (pretrain_model.py:104, 109-110: row j of a record reads group j mod G) and repeats the
+        # record's audio spans for every row (:106)
+        per = G * nseq
+        n = B * per
+        tokens = batch[name].astype(np.int64).reshape(n, lang)
+        ap = batch[name + '/audio_ptr'].astype(np.int64).reshape(n, lang)
+        rows = np.arange(n)
+        vrow = (rows // per) * G + (rows % per) % G                          # the row of the [B G, vis_len] pooled vision input this sequence reads
+        sl = slice(row0, row0 + n)
         code = tokens.copy()
         if with_audio:
-            is_audio, acode = audio_codes(tokens, ap, rows // G)             # audio_spans repeated per group (:106)
+            is_audio, acode = audio_codes(tokens, ap, rows // per)
             code = np.where(is_audio, acode, tokens)
         gcode[sl, :lang] = code
-        gcode[sl, lang:lang + d.vis_len] = vis_base + rows[:, None] * d.vis_len + np.arange(d.vis_len)[None]
+        gcode[sl, lang:lang + d.vis_len] = vis_base + vrow[:, None] * d.vis_len + np.arange(d.vis_len)[None]
         seg = (ap // d.nas) % d.nspg                                         # pretrain_model.py:102 (floor semantics)
-        vsrc = augment_video_src_idx(vsi, split.astype(np.int64))
+        vsrc = augment_video_src_idx(vsi[vrow], split.astype(np.int64))
         valid = tokens != PADDING
         mcode[sl, :lang] = np.where(valid, vsrc[rows[:, None], seg], -1)     # modeling.py:743-756
         mcode[sl, lang:lang + d.vis_len] = vsrc[rows[:, None], vis_seg[None]]
@@ -144,9 +150,10 @@ def build_plan(batch, d, split_from_here, gumbel_z):
         coords[sl, lang:lang + d.vis_len, 2] = vis_seg[None] / 16.0
         return tokens
 
-    r_a2t, r_match, r_rand, r_t2a = 0, BG, BG + B, BG + 2 * B                # sorted-key order, pretrain_model.py:140-144
-    tok_a2t = fill_grouped(r_a2t, 'audio2text', split_from_here[0], True)
-    tok_t2a = fill_grouped(r_t2a, 'text2audio', split_from_here[1], False)
+    n_a2t, n_t2a, n_rand = B * d.rows_a2t, B * d.rows_t2a, B * d.n_text
+    r_a2t, r_match, r_rand, r_t2a = 0, n_a2t, n_a2t + B, n_a2t + B + n_rand  # sorted-key order, pretrain_model.py:140-144
+    tok_a2t = fill_grouped(r_a2t, 'audio2text', split_from_here[0], True, d.n_a2t)
+    tok_t2a = fill_grouped(r_t2a, 'text2audio', split_from_here[1], False, d.n_t2a)
 
     tok_m = batch['audio_text_matching'].astype(np.int64).reshape(B, Sj)
     ap_m = batch['audio_text_matching/audio_ptr'].astype(np.int64).reshape(B, Sj)
@@ -158,10 +165,10 @@ def build_plan(batch, d, split_from_here, gumbel_z):
     coords[r_match:r_match + B, :, 2] = seg_m / 16.0
     coords[r_match:r_match + B, :, 3] = tok_pos[None] / 1024.0
 
-    tok_r = batch['random_text'].astype(np.int64).reshape(B, Sj)
-    gcode[r_rand:r_rand + B] = tok_r
-    mcode[r_rand:r_rand + B] = np.where(tok_r != PADDING, 0, -1)
-    coords[r_rand:r_rand + B, :, 3] = tok_pos[None] / 1024.0
+    tok_r = batch['random_text'].astype(np.int64).reshape(n_rand, Sj)
+    gcode[r_rand:r_rand + n_rand] = tok_r
+    mcode[r_rand:r_rand + n_rand] = np.where(tok_r != PADDING, 0, -1)
+    coords[r_rand:r_rand + n_rand, :, 3] = tok_pos[None] / 1024.0
 
     plan = {}
     plan['joint_gather_indptr'], plan['joint_gather_idx'] = csr_gather(gcode)
@@ -182,16 +189,16 @@ def build_plan(batch, d, split_from_here, gumbel_z):
     off_t2a = B * d.nseg
 
     # text -> audio: MASKAUDIO rows by audio_ptr, the record's groups merged (real_bsize)   (:170-190)
-    ap_t2a = batch['text2audio/audio_ptr'].astype(np.int64).reshape(BG, lang)
+    ap_t2a = batch['text2audio/audio_ptr'].astype(np.int64).reshape(n_t2a, lang)
     ok = (tok_t2a == MASKAUDIO) & (ap_t2a >= 0) & (ap_t2a < d.nspans)
-    rec = (np.arange(BG) // G)[:, None].repeat(lang, 1)
+    rec = (np.arange(n_t2a) // d.rows_t2a)[:, None].repeat(lang, 1)
     count = np.zeros((B, d.nspans), dtype=np.int64)
     np.add.at(count, (rec[ok], ap_t2a[ok]), 1)
     idx_sort = np.argsort(-count, axis=-1, kind='stable')                    # jnp.argsort is stable (:181)
     rank_of_span = np.argsort(idx_sort, axis=-1, kind='stable')              # inverse permutation
     rk = rank_of_span[rec[ok], ap_t2a[ok]]
     keep = rk < d.ntrg
-    rows_t = flat_rows(r_t2a, BG, lang)
+    rows_t = flat_rows(r_t2a, n_t2a, lang)
     dst.append(off_t2a + rec[ok][keep] * d.ntrg + rk[keep])
     src.append(rows_t[ok][keep])
     off_sp = off_t2a + B * d.ntrg
@@ -200,9 +207,9 @@ def build_plan(batch, d, split_from_here, gumbel_z):
     nts = d.ntext_spans
     counts = {}
     mask_rows = {}
-    for name, tokens, row0, nrow, L, per_rec in (('audio2text', tok_a2t, r_a2t, BG, lang, G),
-                                                 ('text2audio', tok_t2a, r_t2a, BG, lang, G),
-                                                 ('random_text', tok_r, r_rand, B, Sj, 1)):
+    for name, tokens, row0, nrow, L, per_rec in (('audio2text', tok_a2t, r_a2t, n_a2t, lang, d.rows_a2t),
+                                                 ('text2audio', tok_t2a, r_t2a, n_t2a, lang, d.rows_t2a),
+                                                 ('random_text', tok_r, r_rand, n_rand, Sj, d.n_text)):
         tp = batch[name + '/text_ptr'].astype(np.int64).reshape(nrow, L)
         ok = (tokens == MASK) & (tp >= 0) & (tp < nts)
         rec = (np.arange(nrow) // per_rec)[:, None].repeat(L, 1)

@@ -25,32 +25,39 @@ def _pad_stream(rows, length):
 
 
 def _record_text(d, rng):
-    nspans, ntrg = d.nspans, d.ntrg
+    nspans, ntrg = d.nspans, d.ntrg1
     per_group = nspans // d.ngroups
-    trg = rng.permutation(nspans)[:2 * ntrg]
-    t2a_idx, a2t_idx = np.sort(trg[:ntrg]), np.sort(trg[ntrg:])
-    t2a_rank = {int(s): k for k, s in enumerate(t2a_idx)}
-    a2t_rank = {int(s): k + ntrg for k, s in enumerate(a2t_idx)}
+    # every sequence of either kind masks its own ntrg spans (dataloader.py:537-545: one draw without replacement, cut into the sequences); text
+    # pointers count through the text -> audio sequences first, then the audio -> text ones (:563, :593)
+    trg = rng.permutation(nspans)[:(d.n_t2a + d.n_a2t) * ntrg]
+    t2a_ranks = [{int(s): k + q * ntrg for k, s in enumerate(np.sort(trg[q * ntrg:(q + 1) * ntrg]))} for q in range(d.n_t2a)]
+    a2t_ranks = [{int(s): k + (d.n_t2a + q) * ntrg for k, s in enumerate(np.sort(trg[(d.n_t2a + q) * ntrg:(d.n_t2a + q + 1) * ntrg]))}
+                 for q in range(d.n_a2t)]
 
     def tok(n):
         return rng.integers(10, VOCAB, size=n)
 
     t2a, a2t = [], []
-    for g in range(d.ngroups):
-        rows_t, rows_a = [], []
-        for s in range(g * per_group, (g + 1) * per_group):
-            if s in t2a_rank:
-                rows_t += [(MASK, s, t2a_rank[s]), (MASKAUDIO, s, t2a_rank[s])]
-            else:
-                rows_t += [(int(t), s, -1) for t in tok(rng.integers(1, 5))]
-            if s in a2t_rank:
-                rows_a += [(MASK, s, a2t_rank[s])]
-            elif rng.random() < 0.8:
-                rows_a += [(AUDIOSPAN, s, -1)] * d.a_tok
-            else:
-                rows_a += [(int(t), s, -1) for t in tok(rng.integers(1, 5))]
-        t2a.append(_pad_stream(rows_t, d.lang))
-        a2t.append(_pad_stream(rows_a, d.lang))
+    for t2a_rank in t2a_ranks:                                 # rows (sequence, group): what `tokens_all.extend(output_groups)` builds
+        for g in range(d.ngroups):
+            rows_t = []
+            for s in range(g * per_group, (g + 1) * per_group):
+                if s in t2a_rank:
+                    rows_t += [(MASK, s, t2a_rank[s]), (MASKAUDIO, s, t2a_rank[s])]
+                else:
+                    rows_t += [(int(t), s, -1) for t in tok(rng.integers(1, 5))]
+            t2a.append(_pad_stream(rows_t, d.lang))
+    for a2t_rank in a2t_ranks:
+        for g in range(d.ngroups):
+            rows_a = []
+            for s in range(g * per_group, (g + 1) * per_group):
+                if s in a2t_rank:
+                    rows_a += [(MASK, s, a2t_rank[s])]
+                elif rng.random() < 0.8:
+                    rows_a += [(AUDIOSPAN, s, -1)] * d.a_tok
+                else:
+                    rows_a += [(int(t), s, -1) for t in tok(rng.integers(1, 5))]
+            a2t.append(_pad_stream(rows_a, d.lang))
 
     rows_m = []
     use_audio = rng.random() < 0.5
@@ -66,18 +73,20 @@ def _record_text(d, rng):
     aux = [(int(t), -1, -1) for t in tok(n_aux)]
     matching = _pad_stream(aux + rows_m, d.seq_len)
 
-    rows_r, seg = [], 0
-    n_fill = int(d.seq_len * rng.uniform(0.7, 1.0))
-    mask_at = set(np.sort(rng.permutation(max(n_fill, d.budget))[:d.budget]).tolist())
-    k = 0
-    for pos in range(max(n_fill, d.budget)):
-        if pos in mask_at:
-            rows_r.append((MASK, seg, 2 * ntrg + k))
-            k += 1
-            seg += 1
-        else:
-            rows_r.append((int(tok(1)[0]), seg, -1))
-    random_text = _pad_stream(rows_r, d.seq_len)
+    random_text = []
+    for q in range(d.n_text):
+        rows_r, seg = [], 0
+        n_fill = int(d.seq_len * rng.uniform(0.7, 1.0))
+        mask_at = set(np.sort(rng.permutation(max(n_fill, d.budget))[:d.budget]).tolist())
+        k = 0
+        for pos in range(max(n_fill, d.budget)):
+            if pos in mask_at:
+                rows_r.append((MASK, seg, (d.n_t2a + d.n_a2t) * ntrg + q * d.budget + k))
+                k += 1
+                seg += 1
+            else:
+                rows_r.append((int(tok(1)[0]), seg, -1))
+        random_text.append(_pad_stream(rows_r, d.seq_len))
 
     spans = np.zeros((d.ntext_spans, d.span_len), dtype=np.int32)
     for i in range(d.ntext_spans):
@@ -86,7 +95,7 @@ def _record_text(d, rng):
     vsrc = np.zeros(d.nseg, dtype=np.int32)
     if rng.random() < 0.1:
         vsrc[int(rng.integers(1, d.nseg)):] = 1
-    return np.stack(t2a), np.stack(a2t), matching[None], random_text[None], spans, vsrc
+    return np.stack(t2a), np.stack(a2t), matching[None], np.stack(random_text), spans, vsrc
 
 
 def make_batch(config, B, seed=1234, device='cpu', float_dtype=torch.bfloat16):
@@ -121,7 +130,7 @@ def make_draws(config, B, seed=1234):
     L = d.nspg
     p = config['model'].get('_augment_video_src_idx_prob', 0.1)
     probs = np.array([p / (L - 1)] * (L - 1) + [1 - p]) if L > 1 else np.array([1.0])
-    splits = [1 + rng.choice(L, size=B * d.ngroups, p=probs).astype(np.int32) for _ in range(2)]
+    splits = [1 + rng.choice(L, size=B * rows, p=probs).astype(np.int32) for rows in (d.rows_a2t, d.rows_t2a)]
     u = rng.uniform(1e-9, 1.0, size=(B, d.ntext_spans)).astype(np.float32)
     z = (-np.log(-np.log(u))).astype(np.float32)
     return splits, z

@@ -393,17 +393,18 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
         return torch.div(a, b, rounding_mode='floor')
 
     n_a2t, n_t2a = d['num_audio2text_seqs'], d['num_text2audio_seqs']
-    assert n_a2t == 1 and n_t2a == 1, "restated for the stock configs (one sequence per kind)"
     mm = {}
-    vsi = batch['video_src_index'].reshape(batch_size, num_segment_groups, nspg).reshape(-1, nspg)
+    vsi3 = batch['video_src_index'].reshape(batch_size, num_segment_groups, nspg)
+    tile_vis = lambda n: imgs_seq.repeat(1, n, 1, 1).reshape(-1, vis_seq_length, H)          # jnp.tile(imgs_seq, [1, n, 1, 1]) (P:104, 129)
+    tile_vsi = lambda n: vsi3.repeat(1, n, 1).reshape(-1, nspg)                               # jnp.tile(..., [1, n, 1])         (P:109-110, 133-134)
     mm['audio2text'] = prepare_multimodal_inputs(
         params, cfg, tokens=batch['audio2text'],
         token_segment_idx=floordiv(batch['audio2text/audio_ptr'], nas) % nspg,
         token_embs=txt_embs['audio2text'],
-        vision_input=imgs_seq.reshape(-1, vis_seq_length, H),
+        vision_input=tile_vis(n_a2t),
         audio_spans=audio_seq.repeat_interleave(num_segment_groups * n_a2t, dim=0),
         audio_pointers=batch['audio2text/audio_ptr'], padding_len=seq_len,
-        video_src_idx=augment_video_src_idx(vsi, split_from_here[0]))
+        video_src_idx=augment_video_src_idx(tile_vsi(n_a2t), split_from_here[0]))
     mm['audio_text_matching'] = prepare_multimodal_inputs(
         params, cfg, tokens=batch['audio_text_matching'],
         token_segment_idx=torch.cumsum((batch['audio_text_matching'] == LTOVPOOL).to(torch.int64), -1),
@@ -413,9 +414,9 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
         params, cfg, tokens=batch['text2audio'],
         token_segment_idx=floordiv(batch['text2audio/audio_ptr'], nas) % nspg,
         token_embs=txt_embs['text2audio'],
-        vision_input=imgs_seq.reshape(-1, vis_seq_length, H),
+        vision_input=tile_vis(n_t2a),
         audio_pointers=batch['text2audio/audio_ptr'], padding_len=seq_len,
-        video_src_idx=augment_video_src_idx(vsi, split_from_here[1]))
+        video_src_idx=augment_video_src_idx(tile_vsi(n_t2a), split_from_here[1]))
     mm['random_text'] = prepare_multimodal_inputs(params, cfg, tokens=batch['random_text'], padding_len=seq_len,
                                                   token_embs=txt_embs['random_text'])
     # NOTE P:138 passes no token_embs for random_text, so the reference re-embeds the same tokens: same values.

@@ -1,6 +1,7 @@
 """Host logic: the planner's integer decisions against the oracle's literal restatement of the reference's index code
 (CPU only).  Everything here is bit-exact: gather codes, attention mask, selections, pooling targets."""
 import numpy as np
+import pytest
 import torch
 
 from merlot_reserve_amd.config import Dims
@@ -17,9 +18,13 @@ def _segsum(table, indptr, idx):
     return out
 
 
-def test_plan_matches_oracle_indexing():
+MULTI = dict(num_audio2text_seqs=2, num_text2audio_seqs=3, num_text_seqs=2)       # pretrain_model.py:99-137 with more than one sequence per kind
+
+
+@pytest.mark.parametrize('data_flags', [None, MULTI], ids=['stock', 'multi_seq'])
+def test_plan_matches_oracle_indexing(data_flags):
     for seed in (3, 4, 5):
-        cfg, store, batch, splits, z = tiny_setup(B=2, seed=seed)
+        cfg, store, batch, splits, z = tiny_setup(B=2, seed=seed, data_flags=data_flags)
         d = Dims(cfg, 2)
         plan = build_plan(batch, d, splits, z)
         params = tree_to(store.master_tree(), torch.float64)

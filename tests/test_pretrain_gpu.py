@@ -16,11 +16,11 @@ from tests.util import oracle_batch, oracle_draws, relerr, tiny_setup, tree_to
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, B=2, seed=3, hidden_size=128, model_flags=None):
+def _setup(dev, B=2, seed=3, hidden_size=128, model_flags=None, data_flags=None):
     from merlot_reserve_amd.config import Dims
     from merlot_reserve_amd.engine import PretrainEngine
     from merlot_reserve_amd.planner import build_plan
-    cfg, store, batch, splits, z = tiny_setup(B=B, seed=seed, device=dev, hidden_size=hidden_size, model_flags=model_flags)
+    cfg, store, batch, splits, z = tiny_setup(B=B, seed=seed, device=dev, hidden_size=hidden_size, model_flags=model_flags, data_flags=data_flags)
     eng = PretrainEngine(cfg, B, store, dev)
     plan = build_plan(batch, Dims(cfg, B), splits, z)
     eng.forward(batch, plan=plan)
@@ -33,10 +33,14 @@ SECTIONS = (('imgs_to_audio', 'x', 'i2a_x'), ('imgs_to_audio', 'y', 'i2a_y'), ('
             ('stuff_to_span', 'y', 's2s_y'))
 
 
-@pytest.mark.parametrize('flags', [{}, {'no_vision': True}], ids=['stock', 'no_vision'])     # no_vision: pretrain/pretrain_model.py:61-63
+# more than one sequence per kind and record (pretrain/pretrain_model.py:99-137: the vision input, the video-source table and the audio spans are tiled)
+MULTI_SEQ = {'data': dict(num_audio2text_seqs=2, num_text2audio_seqs=3, num_text_seqs=2)}
+
+
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ], ids=['stock', 'no_vision', 'multi_seq'])     # no_vision: pretrain/pretrain_model.py:61-63
 def test_tiny_forward_and_loss_parity(dev, flags):
     from oracle import ref_torch as R
-    cfg, store, eng, batch, splits, z = _setup(dev, model_flags=flags)
+    cfg, store, eng, batch, splits, z = _setup(dev, model_flags={k: v for k, v in flags.items() if k != 'data'}, data_flags=flags.get('data'))
     eng.loss_and_grad_outputs()
     torch.cuda.synchronize()
     params = tree_to(store.work_tree(), torch.float32)
@@ -88,12 +92,12 @@ def test_loss_gradient_wrt_outputs(dev):
         assert e <= 1e-2, (name, e)
 
 
-@pytest.mark.parametrize('flags', [{}, {'no_vision': True}], ids=['stock', 'no_vision'])
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ], ids=['stock', 'no_vision', 'multi_seq'])
 def test_tiny_backward_parity(dev, flags):
     """Backward of the whole forward graph for a GIVEN upstream gradient dE (so the check is independent of the
     conditioning of the loss at random init): every parameter gradient against autograd of the oracle."""
     from oracle import ref_torch as R
-    cfg, store, eng, batch, splits, z = _setup(dev, model_flags=flags)
+    cfg, store, eng, batch, splits, z = _setup(dev, model_flags={k: v for k, v in flags.items() if k != 'data'}, data_flags=flags.get('data'))
     g = torch.Generator().manual_seed(1)
     dE = (torch.randn(eng.R, eng.d.H, generator=g) * 1e-2).to(torch.bfloat16)
     eng.dE.copy_(dE.to(dev))

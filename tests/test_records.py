@@ -185,3 +185,26 @@ def test_batch_matches_the_synthetic_layout_and_feeds_the_planner(tmp_path):
     cfg['data'] = dict(cfg['data'], train_fns=str(tmp_path / 'train{:05d}of00002.tfrecord'), num_train_files=2)
     assert len(list(R.input_fn_builder(cfg, rank=0, world=1, seed=2, epochs=1))) == 3
     assert len(list(R.input_fn_builder(cfg, rank=1, world=2, seed=2, epochs=1))) == 4      # file 1 alone, batches of batch_size // world = 1
+
+
+def test_more_than_one_sequence_per_kind():
+    """num_text2audio_seqs / num_audio2text_seqs / num_text_seqs > 1 (dataloader.py:500-501, 547-597, 649): every sequence masks its own spans, the
+    text pointers count through the sequences, and the planner accepts the batch."""
+    from merlot_reserve_amd.planner import build_plan
+    from merlot_reserve_amd.synthetic import make_draws
+    cfg = tiny_config()
+    cfg['data'].update(num_audio2text_seqs=2, num_text2audio_seqs=2, num_text_seqs=2, num_text_seqs_in_record=3)
+    d = Dims(cfg, 2)
+    rng = np.random.default_rng(8)
+    recs = [R.dataset_parser(R.make_synthetic_record(cfg, rng), cfg, rng=np.random.default_rng(k)) for k in range(2)]
+    f = recs[0]
+    assert f['text2audio'].shape == (d.rows_t2a, d.lang, 3) and f['audio2text'].shape == (d.rows_a2t, d.lang, 3)
+    assert f['random_text'].shape == (2, d.seq_len, 3) and f['text_spans'].shape == (d.ntext_spans, d.span_len)
+    masks = [s[s[:, 0] == MASK] for s in (f['text2audio'].reshape(-1, 3), f['audio2text'].reshape(-1, 3), f['random_text'].reshape(-1, 3))]
+    ptrs = np.concatenate([m[:, 2] for m in masks])
+    assert sorted(ptrs.tolist()) == list(range(d.ntext_spans)), 'every text span is pointed at exactly once'
+    spans_masked = np.concatenate([masks[0][:, 1], masks[1][:, 1]])
+    assert len(set(spans_masked.tolist())) == 4 * d.ntrg1, 'the four sequences mask disjoint audio spans'
+    batch = R.handle_batch(recs)
+    splits, z = make_draws(cfg, 2, seed=1)
+    assert build_plan(batch, d, splits, z)['n_pool'] > 0

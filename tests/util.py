@@ -30,9 +30,10 @@ def tree_to(tree, dtype):
     return tree.to(dtype)
 
 
-def tiny_setup(B=2, seed=3, device='cpu', hidden_size=128, model_flags=None):
+def tiny_setup(B=2, seed=3, device='cpu', hidden_size=128, model_flags=None, data_flags=None):
     cfg = tiny_config(hidden_size=hidden_size, seq_len=80, lang_seq_len=40)
     cfg['model'].update(model_flags or {})
+    cfg['data'].update(data_flags or {})
     store = ParamStore(cfg, device, seed=seed)
     batch = make_batch(cfg, B, seed=seed, device=device)
     splits, z = make_draws(cfg, B, seed=seed)
