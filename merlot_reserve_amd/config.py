@@ -64,15 +64,14 @@ class Dims:
         d, m = config['data'], config['model']
         self.B = B
         # Flags of the reference's pretrainer that change the program.  Built: no_vision (pretrain/pretrain_model.py:61-63: the pooled
-        # vision sequence is multiplied by 0 on its way into the joint tower).  Not built -- a config that sets them would train a
-        # different model, so it is refused instead of ignored: do_rotary = False (:146-148 drops the joint coordinates, which sends
-        # TransformerEncoder to its learned `pe`, mreserve/modeling.py:335-341), heads of another width than 64 (mreserve/modeling.py:598).
-        # Built since round 5: more than one audio2text / text2audio / random-text sequence per record (:99-110, :124-135 tile the inputs).
-        if not m.get('do_rotary', True):
-            raise NotImplementedError("model.do_rotary = False (learned position embeddings, mreserve/modeling.py:335-341) is not implemented")
+        # vision sequence is multiplied by 0 on its way into the joint tower); since round 5 do_rotary = False (:146-148 drops the joint
+        # coordinates, which sends TransformerEncoder to its learned `pe`, mreserve/modeling.py:335-341) and more than one audio2text /
+        # text2audio / random-text sequence per record (:99-110, :124-135 tile the inputs).  Not built -- a config that sets it would train a
+        # different model, so it is refused instead of ignored: heads of another width than 64 (mreserve/modeling.py:598).
         if m.get('size_per_head', 64) != 64:
             raise NotImplementedError('model.size_per_head other than 64 is not implemented (the attention kernels are written for 64)')
         self.no_vision = bool(m.get('no_vision', False))
+        self.do_rotary = bool(m.get('do_rotary', True))       # False: the joint tower gets no coordinates and learns `pe` instead (pretrain_model.py:146-148)
         self.H = m['hidden_size']
         self.nh = self.H // 64
         self.gh, self.gw = m['output_grid']

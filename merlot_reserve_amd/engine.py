@@ -219,6 +219,10 @@ class TowerEngine:
     def _pl(self, k):
         return self._plan_views[k]
 
+    def _joint_rot(self):
+        """The joint tower's "rotary" table of the current plan, or None when the config drops the coordinates (do_rotary = False)."""
+        return self._pl('joint_rot') if self.d.do_rotary else None
+
     def _idx_capacity(self):
         """Upper bound on the length of any index list of the plan (so the buffers never move after capture)."""
         return self.tj.M + self.ts.M + 64
@@ -432,6 +436,9 @@ class PretrainEngine(TowerEngine):
         self.tv = TowerState(d.Nv * d.Sv, H, d.Lv, d.Nv, d.Sv, dev, dtype, hp)
         self.ta = TowerState(d.Na * d.Sa, H, d.La, d.Na, d.Sa, dev, dtype, hp)
         self.tj = TowerState(d.Nj * d.Sj, H, d.Lj, d.Nj, d.Sj, dev, dtype, hp)
+        if not d.do_rotary:                 # d pe: position p sums rows p, Sj + p, 2 Sj + p, ... of the tower-input gradient (a static segment list)
+            idx = (np.arange(d.Nj)[None, :] * d.Sj + np.arange(d.Sj)[:, None]).reshape(-1).astype(np.int32)
+            self.pe_lists = (torch.as_tensor(np.arange(d.Sj + 1, dtype=np.int32) * d.Nj).to(dev), torch.as_tensor(idx).to(dev))
         self.ts = TowerState(d.Ns * d.Ss, H, d.Ls, d.Ns, d.Ss, dev, dtype, hp)
         Mmax = max(t.M for t in (self.tv, self.ta, self.tj, self.ts))
 
@@ -592,7 +599,11 @@ class PretrainEngine(TowerEngine):
         self._on_side(span_fwd)
         # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
-        self.encoder_forward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'))
+        if not d.do_rotary:                # pretrain_model.py:146-148 + modeling.py:335-341: no coordinates, x += pe (every position, padding included)
+            pe = W['joint_transformer/pe']
+            for n_ in range(d.Nj):
+                ops.add_(tj.xin[n_ * d.Sj:(n_ + 1) * d.Sj], pe)
+        self.encoder_forward(tj, 'joint_transformer', self._joint_rot(), self._pl('joint_code'))
         self.fgemm(tj.xf, 'head/kernel', self.hj, bias=W['head/bias'])
         ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)
         ops.segment_sum([self.a_cls], self._pl('acls_indptr'), self._pl('acls_idx'), self.acls_g)
@@ -733,9 +744,11 @@ class PretrainEngine(TowerEngine):
         self._t_colsum(trj, self.d_hj, G['head/bias'])
         Dj = self.Dj
         self.gemm(self.d_hj, W['head/kernel'], Dj, transB=True)
-        Dj = self.encoder_backward(tj, 'joint_transformer', self._pl('joint_rot'), self._pl('joint_code'), Dj, tr=trj,
+        Dj = self.encoder_backward(tj, 'joint_transformer', self._joint_rot(), self._pl('joint_code'), Dj, tr=trj,
                                    extra_wgrads=[(tj.xf, self.d_hj, G['head/kernel'])])
         self._flush_tower_reductions(trj)
+        if not d.do_rotary:                # d pe[p] = sum over the joint sequences of the tower-input gradient at position p
+            ops.segment_sum([Dj], self.pe_lists[0], self.pe_lists[1], G['joint_transformer/pe'])
         main.wait_stream(self.side_stream)
         # scatter-adds of the joint / span inputs, as segment sums over the planner's inverted lists
         ops.segment_sum([Dj, Ds], self._pl('embT_indptr'), self._pl('embT_idx'), G['token_encoder/Embed_0/embedding'])

@@ -58,6 +58,8 @@ def param_specs(config):
     specs = [('contrastive_scales', (3,), (3,), 'ones', None)]
     specs += [('head/kernel', (H, H), (H, H), 'kernel', H), ('head/bias', (H,), (H,), 'zeros', None)]
     specs += _encoder_specs('span_encoder/transformer', H, m['span_num_layers'], True)
+    if not m.get('do_rotary', True):        # pretrain_model.py:146-148 drops the joint coordinates: the joint tower learns `pe` [seq_len, H] (modeling.py:335-341)
+        specs += [('joint_transformer/pe', (config['data']['seq_len'], H), (config['data']['seq_len'], H), 'normal02', None)]
     specs += _encoder_specs('joint_transformer', H, m['joint_num_layers'], False)
     specs += [('token_encoder/Embed_0/embedding', (VOCAB, H), (VOCAB, H), 'embed', None)]
     specs += [('audio_encoder/embedding/kernel', (m['audio_patch_size'], 65, H), (m['audio_patch_size'] * 65, H), 'kernel', 130),

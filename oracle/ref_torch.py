@@ -427,6 +427,8 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
     attnmask = torch.cat([mm[k]['attention_mask'] for k in keys], 0)
     real_bsizes = [mm[k]['x'].shape[0] for k in keys]
 
+    if not config['model'].get('do_rotary', True):       # P:146-148: no coordinates -> the encoder's learned `pe` (M:335-341)
+        coords = None
     joint_enc = transformer_encoder(params['joint_transformer'], x, cfg.joint_num_layers, rotary_coords=coords,
                                     attention_mask=attnmask)['seq']
     joint_enc = dense(joint_enc, params['head'])

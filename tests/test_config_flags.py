@@ -19,12 +19,22 @@ def test_no_vision_is_a_flag_of_the_step():
     assert Dims(cfg, 2).no_vision is True
 
 
-@pytest.mark.parametrize('section,key,value', [('model', 'do_rotary', False), ('model', 'size_per_head', 32)])
+@pytest.mark.parametrize('section,key,value', [('model', 'size_per_head', 32)])
 def test_unbuilt_flags_are_refused(section, key, value):
     cfg = copy.deepcopy(tiny_config())
     cfg[section][key] = value
     with pytest.raises(NotImplementedError):
         Dims(cfg, 2)
+
+
+def test_do_rotary_false_adds_the_learned_position_table():
+    """pretrain_model.py:146-148 -> modeling.py:335-341: the joint tower of a config without rotary learns `pe` [seq_len, H]."""
+    from merlot_reserve_amd.params import param_specs
+    cfg = copy.deepcopy(tiny_config())
+    assert 'joint_transformer/pe' not in [s[0] for s in param_specs(cfg)] and Dims(cfg, 2).do_rotary
+    cfg['model']['do_rotary'] = False
+    spec = [s for s in param_specs(cfg) if s[0] == 'joint_transformer/pe']
+    assert len(spec) == 1 and spec[0][1] == (cfg['data']['seq_len'], cfg['model']['hidden_size']) and not Dims(cfg, 2).do_rotary
 
 
 def test_sequences_per_kind_change_the_joint_batch():
@@ -42,6 +52,6 @@ def test_trainer_and_model_entry_points_refuse_too():
     """The flags are checked where every program starts (Dims), so the reference-API entry points cannot miss them."""
     from merlot_reserve_amd import pretrain_model as PM
     cfg = copy.deepcopy(tiny_config())
-    cfg['model']['do_rotary'] = False
+    cfg['model']['size_per_head'] = 32
     with pytest.raises(NotImplementedError):
         PM.MerlotReservePretrainer.from_config(cfg, device='cpu')

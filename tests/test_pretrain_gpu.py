@@ -37,7 +37,8 @@ SECTIONS = (('imgs_to_audio', 'x', 'i2a_x'), ('imgs_to_audio', 'y', 'i2a_y'), ('
 MULTI_SEQ = {'data': dict(num_audio2text_seqs=2, num_text2audio_seqs=3, num_text_seqs=2)}
 
 
-@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ], ids=['stock', 'no_vision', 'multi_seq'])     # no_vision: pretrain/pretrain_model.py:61-63
+# do_rotary = False: pretrain/pretrain_model.py:146-148 (no joint coordinates -> the learned `pe` of mreserve/modeling.py:335-341)
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ, {'do_rotary': False}], ids=['stock', 'no_vision', 'multi_seq', 'learned_pe'])     # no_vision: pretrain/pretrain_model.py:61-63
 def test_tiny_forward_and_loss_parity(dev, flags):
     from oracle import ref_torch as R
     cfg, store, eng, batch, splits, z = _setup(dev, model_flags={k: v for k, v in flags.items() if k != 'data'}, data_flags=flags.get('data'))
@@ -92,7 +93,7 @@ def test_loss_gradient_wrt_outputs(dev):
         assert e <= 1e-2, (name, e)
 
 
-@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ], ids=['stock', 'no_vision', 'multi_seq'])
+@pytest.mark.parametrize('flags', [{}, {'no_vision': True}, MULTI_SEQ, {'do_rotary': False}], ids=['stock', 'no_vision', 'multi_seq', 'learned_pe'])
 def test_tiny_backward_parity(dev, flags):
     """Backward of the whole forward graph for a GIVEN upstream gradient dE (so the check is independent of the
     conditioning of the loss at random init): every parameter gradient against autograd of the oracle."""
