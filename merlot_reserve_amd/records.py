@@ -26,7 +26,8 @@ import struct
 
 import numpy as np
 
-from .synthetic import AUDIOSPAN, END, LTOVPOOL, MASK, MASKAUDIO, PADDING, START
+# special token ids (mreserve/lowercase_encoder.py; the same constants as synthetic.py -- restated so that a parser worker process imports neither torch nor the library)
+PADDING, START, END, MASK, MASKAUDIO, AUDIOSPAN, LTOVPOOL = 0, 1, 2, 3, 4, 5, 6
 
 # encoder.encode('title:' / 'description:' / 'tags:').ids (dataloader.py:633-636; recorded from the reference tokenizer: tests/golden/tokenizer_ids.json)
 TITLE_IDS, DESCRIPTION_IDS, TAGS_IDS = [3388, 35], [2026, 35], [10884, 35]
@@ -685,18 +686,29 @@ def dataset_parser(record, config, rng=None, token_is_valid=None):
     return feats
 
 
+def bf16_bits(x):
+    """float32 array -> uint16 array holding the bfloat16 (round to nearest even) of every value: what `.to(torch.bfloat16)` produces, computed where
+    the record is parsed so that half the bytes cross the process boundary."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
 def handle_batch(records, use_bfloat16=True, device='cpu'):
     """dataloader.py:732-789 for ONE device (`records`: a list of dataset_parser outputs): the batch dict of synthetic.make_batch -- images
     [B, nseg hw, P P 3] and audio_clips [B, nseg nsub T, 65] as torch tensors (bf16 when use_bfloat16), the token streams split into the id /
     audio_ptr / text_ptr planes [B, n, L] (numpy int32: the planner reads them on the host), text_spans [B, nspans, span_len], video_src_index."""
     import torch
     B = len(records)
-    img = np.stack([r['images'] for r in records])
-    aud = np.stack([r['audio_clips'] for r in records])
     batch = {}
     dt = torch.bfloat16 if use_bfloat16 else torch.float32
-    batch['images'] = torch.from_numpy(np.ascontiguousarray(img.reshape(B, -1, img.shape[-1]))).to(dt).to(device)
-    batch['audio_clips'] = torch.from_numpy(np.ascontiguousarray(aud.reshape(B, -1, aud.shape[-1]))).to(dt).to(device)
+    for k in ('images', 'audio_clips'):
+        x = np.stack([r[k] for r in records])
+        x = np.ascontiguousarray(x.reshape(B, -1, x.shape[-1]))
+        if x.dtype == np.uint16:                                # bf16 bit patterns from a parser worker (bf16_bits)
+            t = torch.from_numpy(x.view(np.int16)).view(torch.bfloat16)
+            batch[k] = (t if use_bfloat16 else t.to(torch.float32)).to(device)
+        else:
+            batch[k] = torch.from_numpy(x).to(dt).to(device)
     batch['text_spans'] = np.stack([r['text_spans'] for r in records]).astype(np.int32)
     batch['video_src_index'] = np.stack([r['video_src_index'] for r in records]).astype(np.int32)
     for k in ('text2audio', 'audio2text', 'audio_text_matching', 'random_text'):
@@ -711,10 +723,26 @@ def handle_batch(records, use_bfloat16=True, device='cpu'):
 
 
 # ------------------------------------------------------------------------------------------------ shards -> batches (dataloader.py:864-955)
-def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_valid=None, workers=0, device='cpu'):
+def _parse_job(args):
+    """One record in a parser worker (module level: picklable).  Floats leave as bf16 bit patterns when the batch will be bf16 anyway."""
+    rec, seed, merged, token_is_valid, as_bf16 = args
+    try:
+        f = dataset_parser(rec, merged, rng=np.random.default_rng(seed), token_is_valid=token_is_valid)
+    except ValueError as e:                                       # (the reference's iterator logs a failing record and goes on: dataloader.py:948-951)
+        print(f'records: skipping a record: {e}', flush=True)
+        return None
+    if as_bf16:
+        f['images'], f['audio_clips'] = bf16_bits(f['images']), bf16_bits(f['audio_clips'])
+    return f
+
+
+def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_valid=None, workers=0, device='cpu', processes=False):
     """Generator of per-device batches from the shards `fns`: records of the shards interleaved round-robin (tf.data's parallel reads), passed through
-    a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed (`workers` > 0: a thread pool -- PIL releases the GIL
-    while it decodes and resamples), grouped into batches of batch_size with the remainder dropped."""
+    a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
+    dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
+    -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU (one record costs ~120-160 ms
+    of one core at the base grid: a base step at 4 records / 30 ms wants ~20 cores per GPU; tf.data's 48-thread pool in the reference is the same order).
+    The record -> random-stream assignment does not depend on the pool, so every mode yields the same batches for the same seed."""
     merged = merged_data_config(config)
     rng = np.random.default_rng(seed)
     token_is_valid = make_token_is_valid() if token_is_valid is None else token_is_valid
@@ -731,29 +759,26 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
         while buf:
             yield buf.pop(int(rng.integers(0, len(buf))) if is_training else 0)
 
-    def parse(args):
-        rec, s = args
-        try:
-            return dataset_parser(rec, merged, rng=np.random.default_rng(s), token_is_valid=token_is_valid)
-        except ValueError as e:                                   # (the reference's iterator logs a failing record and goes on: dataloader.py:948-951)
-            print(f'records: skipping a record: {e}', flush=True)
-            return None
-
-    pool = None
-    if workers > 0:
+    use_bf16 = merged.get('use_bfloat16', True)
+    pool, chunk_size = None, batch_size
+    if workers > 0 and processes:
+        import multiprocessing as mp
+        pool = mp.get_context('spawn').Pool(workers)              # spawn, not fork: the parent usually holds an initialised GPU runtime
+        chunk_size = max(batch_size, 2 * workers)                  # keep every worker busy between two flushes
+    elif workers > 0:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=workers)
-    use_bf16 = merged.get('use_bfloat16', True)
     try:
         done, chunk = [], []
 
         def flush():
-            parsed = pool.map(parse, chunk) if pool is not None else map(parse, chunk)
+            jobs = [(rec, s, merged, token_is_valid, use_bf16) for rec, s in chunk]
+            parsed = pool.map(_parse_job, jobs) if pool is not None else map(_parse_job, jobs)
             done.extend(r for r in parsed if r is not None)
             chunk.clear()
         for rec in shuffled():
             chunk.append((rec, int(rng.integers(0, 2 ** 63))))
-            if len(chunk) == batch_size:
+            if len(chunk) == chunk_size:
                 flush()
                 while len(done) >= batch_size:
                     yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
@@ -764,7 +789,10 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
             yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
             del done[:batch_size]
     finally:
-        if pool is not None:
+        if pool is not None and processes:
+            pool.terminate()
+            pool.join()
+        elif pool is not None:
             pool.shutdown(wait=False)
 
 

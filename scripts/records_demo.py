@@ -1,0 +1,39 @@
+"""The real-data reader on synthetic shards: writes a few TFRecord shards with the reference's record layout (records.make_synthetic_record: frames stored
+at 360 x 640 like the corpus' JPEGs), reads them back through records.make_dataset at several worker counts and prints records / s -- what one GPU's step
+consumes is B / ms_per_step (base, B = 4: ~133 records / s).  CPU only.   python scripts/records_demo.py [n_records] [tmpdir]"""
+import os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from merlot_reserve_amd import records as R
+from merlot_reserve_amd.config import load_config
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    tmp = sys.argv[2] if len(sys.argv) > 2 else tempfile.mkdtemp(prefix='mr_records_')
+    cfg = load_config('base')
+    cfg['device'] = dict(cfg.get('device', {}), shuffle_buffer_size=8)
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    fns = []
+    for s in range(2):
+        fn = os.path.join(tmp, f'train{s:05d}of00002.tfrecord')
+        R.write_tfrecord(fn, [R.make_synthetic_record(cfg, rng, frame_hw=(360, 640)) for _ in range(n // 2)])
+        fns.append(fn)
+    size = sum(os.path.getsize(f) for f in fns)
+    print(f'wrote {n} records, {size / 1e6:.1f} MB ({size / n / 1e3:.0f} KB / record) in {time.time() - t0:.1f} s')
+    t0 = time.time()
+    recs = [r for f in fns for r in R.read_tfrecord(f)]
+    print(f'container: {len(recs)} records scanned + checksummed in {(time.time() - t0) * 1e3:.1f} ms ({size / 1e6 / (time.time() - t0):.0f} MB/s)')
+    t0 = time.time()
+    ex = [R.parse_example(r) for r in recs]
+    print(f'tf.train.Example parse: {(time.time() - t0) / len(recs) * 1e3:.2f} ms / record')
+    for workers, procs in ((0, False), (4, False), (8, False), (4, True), (8, True), (16, True)):
+        t0 = time.time()
+        nb = sum(1 for _ in R.make_dataset(cfg, fns, 4, is_training=True, seed=1, workers=workers, processes=procs))
+        dt = time.time() - t0
+        print(f'workers={workers} {"processes" if procs else "threads"}: {nb} batches of 4 in {dt:.2f} s = {nb * 4 / dt:.1f} records / s (incl. pool start-up)')
+
+
+if __name__ == '__main__':        # (spawned parser workers re-import this file: nothing may run at import)
+    main()

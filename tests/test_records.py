@@ -181,6 +181,9 @@ def test_batch_matches_the_synthetic_layout_and_feeds_the_planner(tmp_path):
     assert all(np.array_equal(x['text2audio'], y['text2audio']) for x, y in zip(batches, again))
     threaded = list(R.make_dataset(cfg, fns, B, is_training=True, seed=11, workers=2))
     assert all(np.array_equal(x['audio2text'], y['audio2text']) and bool((x['images'] == y['images']).all()) for x, y in zip(batches, threaded))
+    spawned = list(R.make_dataset(cfg, fns, B, is_training=True, seed=11, workers=2, processes=True))     # worker processes: no torch, no GPU, bf16 on the wire
+    assert len(spawned) == 3 and all(np.array_equal(x['text_spans'], y['text_spans']) and bool((x['images'] == y['images']).all()) and
+                                     bool((x['audio_clips'] == y['audio_clips']).all()) for x, y in zip(batches, spawned))
     # the driver-level iterator: this rank's shards, one epoch
     cfg['data'] = dict(cfg['data'], train_fns=str(tmp_path / 'train{:05d}of00002.tfrecord'), num_train_files=2)
     assert len(list(R.input_fn_builder(cfg, rank=0, world=1, seed=2, epochs=1))) == 3
