@@ -23,7 +23,9 @@ extern "C" const char* mr_last_error(void) { return g_err; }
 // 3: mr_transpose_leaves, mr_set_option("gemm3") (round 3)
 // 4: handles (mr_create / mr_destroy / mr_make_current / mr_handle_set_option / mr_handle_get_option), mr_get_option,
 //    mr_last_gemm_kernel, options "gemm5" / "gemm5_stagger" / "gemm_trace"; environment knobs only in MR_DEBUG_ENV builds (round 4)
-extern "C" int mr_version(void) { return 4; }
+// 5: mr_attention_fwd_dense_mask, mr_masked_lm_xent, mr_crc32c / mr_crc32c_masked / mr_tfrecord_scan, option "attn_tile_modes"; mr_destroy refuses a handle
+//    another thread holds (round 5)
+extern "C" int mr_version(void) { return 5; }
 
 // ---- option sets: one per handle + the process-wide defaults ----
 static MrOptions g_default_opts;

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle runs on the host cores.  A GPU box shows 256 logical CPUs but a job owns a share of ~16 (gpurun): torch's default of one thread per
+    # physical core oversubscribes that share four to eight times (bench.py's thread sweep: one oracle record 5.6 s at 16 threads, 21.8 s at 128).
+    nthr = max(1, min(16, os.cpu_count() or 1))
+    os.environ.setdefault('OMP_NUM_THREADS', str(nthr))      # (inherited by the spawned ranks of the multi-process tests)
+    try:
+        import torch
+        torch.set_num_threads(nthr)
+    except Exception:                                    # noqa: BLE001 -- torch missing / already threaded: leave the default
+        pass
 
 
 @pytest.fixture(scope='session')
