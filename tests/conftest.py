@@ -10,15 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    # The oracle runs on the host cores.  A GPU box shows 256 logical CPUs but a job owns a share of ~16 (gpurun): torch's default of one thread per
-    # physical core oversubscribes that share four to eight times (bench.py's thread sweep: one oracle record 5.6 s at 16 threads, 21.8 s at 128).
-    nthr = max(1, min(16, os.cpu_count() or 1))
-    os.environ.setdefault('OMP_NUM_THREADS', str(nthr))      # (inherited by the spawned ranks of the multi-process tests)
+    # The spawned ranks of the multi-process tests each run the oracle on the host cores: with torch's default of one thread per physical core, two
+    # ranks oversubscribe the job's CPU share many times over (a two-rank oracle test: 40-60 s; with 16 threads per rank: 3 s).  The variable is set
+    # AFTER this process has initialised torch, so only the children are capped -- the single-process oracle tests measured slower with the cap
+    # (large B = 4: 127 s against 108 s).
     try:
         import torch
-        torch.set_num_threads(nthr)
-    except Exception:                                    # noqa: BLE001 -- torch missing / already threaded: leave the default
+        torch.get_num_threads()
+    except Exception:                                    # noqa: BLE001
         pass
+    os.environ.setdefault('OMP_NUM_THREADS', str(max(1, min(16, os.cpu_count() or 1))))
 
 
 @pytest.fixture(scope='session')
