@@ -226,8 +226,12 @@ _PIL_METHODS = None
 
 
 def _resize_f32(img, height, width, method):
-    """[H, W, C] float32 -> [height, width, C] with PIL's antialiased filters on float planes (no 8-bit round trip)."""
+    """[H, W, C] float32 -> [height, width, C] with PIL's antialiased filters on float planes (no 8-bit round trip).  A uint8 image takes PIL's 8-bit path
+    (its SIMD resampler, ~4x faster) and comes back as float32 / 255: the `fast_image_resize` option, for batches that are rounded to bf16 anyway (one
+    8-bit step is 1 / 255, a bf16 step between 0.5 and 1 is 1 / 256)."""
     from PIL import Image
+    if img.dtype == np.uint8:
+        return np.asarray(Image.fromarray(img).resize((width, height), method), dtype=np.float32) / np.float32(255.0)
     planes = [np.asarray(Image.fromarray(np.ascontiguousarray(img[:, :, c]), mode='F').resize((width, height), method), dtype=np.float32)
               for c in range(img.shape[2])]
     return np.stack(planes, -1)
@@ -238,7 +242,7 @@ def flip_if_vertical(image):
     columns of 0.5 on either side."""
     h, w = image.shape[:2]
     if h >= 4.0 * w / 3.0:
-        image = np.pad(np.rot90(image), [(0, 0), (4, 4), (0, 0)], mode='constant', constant_values=0.5)
+        image = np.pad(np.rot90(image), [(0, 0), (4, 4), (0, 0)], mode='constant', constant_values=128 if image.dtype == np.uint8 else 0.5)
     return image
 
 
@@ -271,7 +275,7 @@ def resize_and_pad(image, desired_output_size, rng, random_scale_min=0.1, random
         method = [R.BOX, R.BICUBIC, R.BILINEAR, R.HAMMING, R.LANCZOS, R.LANCZOS, R.BICUBIC, R.NEAREST][int(rng.integers(0, 8))]
     else:
         method = Image.Resampling.BILINEAR
-    image = _resize_f32(np.asarray(image, dtype=np.float32), max(scaled_height, 1), max(scaled_width, 1), method)
+    image = _resize_f32(image if image.dtype == np.uint8 else np.asarray(image, dtype=np.float32), max(scaled_height, 1), max(scaled_width, 1), method)
     image = np.clip(image, 0.0, 1.0)
     image = image[offset_y:offset_y + dh, offset_x:offset_x + dw]
     out = np.zeros((dh, dw, image.shape[2]), dtype=np.float32)          # pad_to_bounding_box(image, 0, 0, dh, dw)
@@ -286,7 +290,9 @@ def load_and_resize_img(encoded_jpg, config, rng):
     from PIL import Image
     P = config['vit_patch_size']
     h1, w1 = config['output_grid']
-    img = np.asarray(Image.open(io.BytesIO(encoded_jpg)).convert('RGB'), dtype=np.float32) / np.float32(255.0)
+    img = np.asarray(Image.open(io.BytesIO(encoded_jpg)).convert('RGB'))
+    if not config.get('fast_image_resize', False):           # the reference resamples floats (convert_image_dtype before resize_and_pad)
+        img = img.astype(np.float32) / np.float32(255.0)
     img, _info = resize_and_pad(img, (h1 * P, w1 * P), rng, do_random_scale=config.get('do_random_scale', True),
                                 random_scale_max=config.get('random_scale_max', 1.1), random_scale_min=config.get('random_scale_min', 1.05),
                                 shrink_both_sides=config.get('shrink_both_sides', True), do_flip_if_vertical=config.get('do_flip_if_vertical', True),
@@ -740,8 +746,10 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     """Generator of per-device batches from the shards `fns`: records of the shards interleaved round-robin (tf.data's parallel reads), passed through
     a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
     dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
-    -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU (one record costs ~120-160 ms
-    of one core at the base grid: a base step at 4 records / 30 ms wants ~20 cores per GPU; tf.data's 48-thread pool in the reference is the same order).
+    -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU.  Measured (scripts/records_demo.py,
+    360 x 640 stored frames, base grid): one record costs ~120 ms of one core (~75 ms with data.fast_image_resize: 8-bit resampling), 8 processes on 8
+    cores parse ~30 records / s; a base step consumes 4 records / 29 ms = 137 records / s per GPU, i.e. ~16-20 cores per GPU -- the order of tf.data's
+    48-thread pool per host in the reference.
     The record -> random-stream assignment does not depend on the pool, so every mode yields the same batches for the same seed."""
     merged = merged_data_config(config)
     rng = np.random.default_rng(seed)

