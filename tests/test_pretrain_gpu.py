@@ -412,3 +412,28 @@ def test_odd_batch_sizes_step(dev, B):
     for _ in range(2):
         tr.train_step_graph(batch, plan)
     assert np.isfinite(tr.loss_info()['loss']) and tr.state.step == 3
+
+
+@pytest.mark.parametrize('flags', [{'model': {'do_rotary': False}}, MULTI_SEQ], ids=['learned_pe', 'multi_seq'])
+def test_config_branches_step_through_the_captured_trainer(dev, flags):
+    """The two config branches built in round 5 through the whole trainer -- optimizer step, hipGraph capture, replay: bit for bit the eager steps."""
+    from merlot_reserve_amd.config import tiny_config
+    from merlot_reserve_amd.synthetic import make_batch
+    from merlot_reserve_amd.trainer import Trainer
+    cfg = tiny_config()
+    for k, v in flags.items():
+        cfg[k].update(v)
+    cfg['optimizer'].update(num_warmup_steps=1, learning_rate=1e-3)
+    B = 2
+    bs = [make_batch(cfg, B, seed=10 + i, device=dev) for i in range(4)]
+    tr, ref = Trainer(cfg, B, dev, seed=0), Trainer(cfg, B, dev, seed=0)
+    for b in bs[:2]:
+        tr.train_step(b, plan=tr.plan(b))
+        ref.train_step(b, plan=ref.plan(b))
+    tr.capture(bs[2])
+    for b in bs[2:]:
+        tr.train_step_graph(b, tr.plan(b))
+        ref.train_step(b, plan=ref.plan(b))
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params.master, ref.params.master) and tr.loss_info()['loss'] == ref.loss_info()['loss']
+    assert np.isfinite(tr.loss_info()['loss']) and tr.state.step == 4
