@@ -224,3 +224,22 @@ def test_more_than_one_sequence_per_kind():
     batch = R.handle_batch(recs)
     splits, z = make_draws(cfg, 2, seed=1)
     assert build_plan(batch, d, splits, z)['n_pool'] > 0
+
+
+@pytest.mark.parametrize('tokens_per_segment', [(0, 0), (40, 60)], ids=['silent_video', 'dense_speech'])
+def test_parser_edge_cases(tokens_per_segment):
+    """A video without a single token (every masked row stays empty: nothing to donate) and one whose streams overflow lang_seq_len (select_tokens cuts
+    them: every MASK survives, rows keep their order, the stream is exactly full)."""
+    cfg = tiny_config()
+    d = Dims(cfg, 1)
+    rng = np.random.default_rng(13)
+    for k in range(3):
+        rec = R.make_synthetic_record(cfg, rng, tokens_per_segment=tokens_per_segment)
+        f = R.dataset_parser(rec, cfg, rng=np.random.default_rng(k))
+        _check_record(f, cfg, d)
+        t2a = f['text2audio'].reshape(-1, 3)
+        if tokens_per_segment[1] == 0:
+            assert not (f['text_spans'][:2 * d.ntrg1] != 0).any(), 'no token exists: the audio-stream spans are empty'
+            assert set(t2a[t2a[:, 1] >= 0, 0].tolist()) <= {MASK, MASKAUDIO}
+        else:
+            assert (f['text2audio'][:, -1, 1] >= 0).all(), 'the dense streams fill lang_seq_len'
