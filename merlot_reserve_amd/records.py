@@ -17,8 +17,9 @@ for Mitchell -- augmentation noise, not arithmetic the model is checked against.
 (dataloader.py:381-386: which vocabulary entries decode to [ A-Za-z0-9']*) needs the tokenizer's vocabulary file, a data asset of the
 reference release: pass `token_is_valid` (or an encoder) -- without it every id > 10 counts as valid.
 
-Parity note: the reference holds no recorded batch, so this file is pinned by structure only (tests/test_records.py: round trips of
-the container, the invariants mask_tokens guarantees, acceptance by the planner and a training step); DESIGN.md section 4.
+Parity note: the reference holds no recorded batch, so the parser is pinned by structure only (tests/test_records.py: the invariants mask_tokens
+guarantees, hand-derived cases, acceptance by the planner and a training step).  The CONTAINER is pinned independently: CRC-32C by the RFC 3720 vectors,
+the tf.train.Example codec in both directions against the protobuf runtime (the published .proto rebuilt from descriptors); DESIGN.md section 4.
 """
 import io
 import os
