@@ -138,7 +138,9 @@ def transformer_encoder(p, x, num_layers, coords=None, mask=None, is_valid=None,
         if coords is not None:
             coords = np.concatenate([np.zeros((1, coords.shape[1]), F), coords], 0)   # M:324-326
     sinus = rotary_sinusoids(coords) if coords is not None else None
-    assert sinus is not None, 'learned position embeddings (M:335-341) are not used by this path'
+    if sinus is None:                                                                  # M:335-341: no coordinates -> learned position embeddings
+        assert p['pe'].shape == x.shape
+        x = x + p['pe']
     if is_valid is not None:
         assert mask is None
         mask = np.outer(is_valid, is_valid)                                            # M:343-345
@@ -329,32 +331,39 @@ def pretrain_forward(params, cfg, batch, split_from_here, gumbel_z):
 
     # the four kinds of joint sequences, concatenated in sorted-key order (P:140-144)
     seqs, kinds = [], []
+    # more than one sequence per kind (P:99-110, 124-135): jnp.tile(x, [1, n, 1, 1]) repeats the GROUP axis n times, so row j of a record reads
+    # group j mod ngr of the vision input and of video_src_index; the record's audio spans serve every row
+    rows_a2t, rows_t2a, n_text = ngr * d['num_audio2text_seqs'], ngr * d['num_text2audio_seqs'], d.get('num_text_seqs', 1)
+    use_coords = m.get('do_rotary', True)                     # P:146-148
     for b in range(B):
-        for g in range(ngr):
-            tok, ap = batch['audio2text'][b, g], batch['audio2text/audio_ptr'][b, g]
+        for j in range(rows_a2t):
+            g = j % ngr
+            tok, ap = batch['audio2text'][b, j], batch['audio2text/audio_ptr'][b, j]
             seg = (ap // nas) % nspg                          # floor semantics: ptr = -1 -> segment nspg - 1 (P:102)
             seqs.append(prepare_multimodal_inputs(emb, cfg, tok, seg, emb[tok], vision_of(b, g), spans_of(b), ap, seq_len,
-                                                  augmented_src(b, g, split_from_here[0][b * ngr + g])))
-            kinds.append(('audio2text', b, g))
+                                                  augmented_src(b, g, split_from_here[0][b * rows_a2t + j])))
+            kinds.append(('audio2text', b, j))
     for b in range(B):
         tok, ap = batch['audio_text_matching'][b, 0], batch['audio_text_matching/audio_ptr'][b, 0]
         seg = np.cumsum(tok == LTOVPOOL)                      # inclusive cumsum (P:117)
         seqs.append(prepare_multimodal_inputs(emb, cfg, tok, seg, emb[tok], None, spans_of(b), ap, seq_len, None))
         kinds.append(('audio_text_matching', b, 0))
     for b in range(B):
-        tok = batch['random_text'][b, 0]
-        seqs.append(prepare_multimodal_inputs(emb, cfg, tok, None, None, None, None, None, seq_len, None))
-        kinds.append(('random_text', b, 0))
+        for j in range(n_text):
+            tok = batch['random_text'][b, j]
+            seqs.append(prepare_multimodal_inputs(emb, cfg, tok, None, None, None, None, None, seq_len, None))
+            kinds.append(('random_text', b, j))
     for b in range(B):
-        for g in range(ngr):
-            tok, ap = batch['text2audio'][b, g], batch['text2audio/audio_ptr'][b, g]
+        for j in range(rows_t2a):
+            g = j % ngr
+            tok, ap = batch['text2audio'][b, j], batch['text2audio/audio_ptr'][b, j]
             seg = (ap // nas) % nspg
             seqs.append(prepare_multimodal_inputs(emb, cfg, tok, seg, emb[tok], vision_of(b, g), None, ap, seq_len,
-                                                  augmented_src(b, g, split_from_here[1][b * ngr + g])))
-            kinds.append(('text2audio', b, g))
+                                                  augmented_src(b, g, split_from_here[1][b * rows_t2a + j])))
+            kinds.append(('text2audio', b, j))
     outs = {}
     for (x, coords, mask), key in zip(seqs, kinds):
-        enc = transformer_encoder(params['joint_transformer'], x, m['joint_num_layers'], coords=coords, mask=mask)['seq']
+        enc = transformer_encoder(params['joint_transformer'], x, m['joint_num_layers'], coords=coords if use_coords else None, mask=mask)['seq']
         outs[key] = dense(enc, params['head'])                # P:150-151
 
     # vision -> audio: rows at LTOVPOOL positions, slot = cumsum - 1 (P:160-165)
@@ -370,7 +379,7 @@ def pretrain_forward(params, cfg, batch, split_from_here, gumbel_z):
     t2a_sel, a2t_sel, a2t_extra = [], [], []
     for b in range(B):
         x, cnt = np.zeros((nspans, H), F), np.zeros(nspans, F)
-        for g in range(ngr):
+        for g in range(rows_t2a):
             tok = batch['text2audio'][b, g]
             xg, cg = one_hot_pool(tok == MASKAUDIO, batch['text2audio/audio_ptr'][b, g], outs[('text2audio', b, g)][:lang], nspans)
             x, cnt = x + xg, cnt + cg
@@ -386,7 +395,7 @@ def pretrain_forward(params, cfg, batch, split_from_here, gumbel_z):
     for k in ('audio2text', 'text2audio', 'random_text'):
         for b in range(B):
             x, cnt = np.zeros((nts, H), F), np.zeros(nts, F)
-            groups = range(ngr) if k != 'random_text' else [0]
+            groups = range({'audio2text': rows_a2t, 'text2audio': rows_t2a, 'random_text': n_text}[k])
             for g in groups:
                 tok, tp = batch[k][b, g], batch[f'{k}/text_ptr'][b, g]
                 v = outs[(k, b, g)]
@@ -420,8 +429,17 @@ def pretrain_forward(params, cfg, batch, split_from_here, gumbel_z):
 
 def loss_fn_given_preds(preds_per_device, rank=0):
     """P:262-303 for device `rank` of a virtual pmap (all_gather = rank-major concatenation, P:290)."""
-    preds = preds_per_device[rank]
+    preds = dict(preds_per_device[rank])
     info = {}
+    if 'text_preds' in preds:                                # P:265-274: masked token cross-entropy, rows with label 0 left out
+        tp = preds.pop('text_preds')
+        tot, cnt = 0.0, 0
+        for row, lab in zip(np.asarray(tp['logits'], dtype=F), np.asarray(tp['labels'])):
+            if lab != 0:
+                mx = row.max()
+                tot += (mx + math.log(np.exp(row - mx).sum())) - row[int(lab)]
+                cnt += 1
+        info['audio2text'] = tot / cnt
     for ctype, cd in preds.items():
         info[ctype] = 0.0
         if '_sources' in cd:

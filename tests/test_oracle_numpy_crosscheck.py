@@ -8,6 +8,7 @@ unpinned by the reference.  What can be done without it, and is d
   of its own float64 loss along random directions of >= 20 parameter leaves.
 """
 import numpy as np
+import pytest
 import torch
 
 from merlot_reserve_amd.config import tiny_config
@@ -18,8 +19,14 @@ from oracle import ref_torch as R
 from tests.util import oracle_batch, oracle_draws, tree_to
 
 
-def _setup(seed, B=1):
+# the config branches built in round 5: more than one sequence per kind (P:99-137) with the learned position table instead of rotary (P:146-148)
+BRANCHES = {'data': dict(num_audio2text_seqs=2, num_text2audio_seqs=2, num_text_seqs=2), 'model': dict(do_rotary=False)}
+
+
+def _setup(seed, B=1, flags=None):
     cfg = tiny_config(hidden_size=128, seq_len=80, lang_seq_len=40)
+    for k, v in (flags or {}).items():
+        cfg[k].update(v)
     store = ParamStore(cfg, 'cpu', seed=seed, with_optimizer=False)
     g = torch.Generator().manual_seed(seed + 100)
     tree = store.master_tree()
@@ -43,10 +50,11 @@ def _np_batch(batch):
     return {k: (v if isinstance(v, np.ndarray) else v.numpy().astype(np.float64)) for k, v in batch.items()}
 
 
-def test_numpy_and_torch_restatements_agree():
+@pytest.mark.parametrize('flags', [None, BRANCHES], ids=['stock', 'multi_seq_learned_pe'])
+def test_numpy_and_torch_restatements_agree(flags):
     per_dev_t, per_dev_n = [], []
     for dev_i, seed in enumerate((5, 6)):
-        cfg, tree, batch, splits, z = _setup(seed if dev_i == 0 else 5, B=1)
+        cfg, tree, batch, splits, z = _setup(seed if dev_i == 0 else 5, B=1, flags=flags)
         if dev_i == 1:                                      # second virtual device: same parameters, another batch
             batch = make_batch(cfg, 1, seed=seed, device='cpu', float_dtype=torch.float32)
             splits, z = make_draws(cfg, 1, seed=seed)
@@ -71,6 +79,12 @@ def test_numpy_and_torch_restatements_agree():
         assert set(it) == set(inn)
         for k in it:
             assert abs(float(it[k]) - inn[k]) < 1e-9 * max(abs(inn[k]), 1.0), (k, float(it[k]), inn[k])
+    # the mask-LM special case of the loss (P:265-274)
+    g = torch.Generator().manual_seed(1)
+    logits, labels = torch.randn(9, 50, generator=g, dtype=torch.float64) * 3, torch.tensor([0, 3, 49, 0, 7, 7, 1, 0, 12])
+    lt, it = R.loss_fn_given_preds([dict(per_dev_t[0], text_preds={'logits': logits, 'labels': labels})])
+    ln, inn = N.loss_fn_given_preds([dict(per_dev_n[0], text_preds={'logits': logits.numpy(), 'labels': labels.numpy()})])
+    assert abs(float(it['audio2text']) - inn['audio2text']) < 1e-12 * abs(inn['audio2text']) and abs(float(lt) - ln) < 1e-10 * abs(ln)
 
 
 def test_known_answers_of_the_numpy_restatement():
