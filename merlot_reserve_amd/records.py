@@ -72,6 +72,31 @@ def read_tfrecord(path_or_bytes, verify=True):
     return [buf[o:o + l].tobytes() for o, l in zip(offs[:n].tolist(), lens[:n].tolist())]
 
 
+def iter_tfrecord(path, verify=True):
+    """The records of one shard ONE AT A TIME (a shard of the corpus holds ~2 400 records of ~1.3 MB: make_dataset keeps several shards open and must not
+    hold them whole).  Same checks as read_tfrecord, record by record."""
+    lib = _lib()
+    with open(path, 'rb') as f:
+        n = 0
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) < 12:
+                raise ValueError(f'{path}: truncated header of record {n}')
+            length, lcrc = struct.unpack('<QI', head)
+            if verify and lib.mr_crc32c_masked(head[:8], 8) != lcrc:
+                raise ValueError(f'{path}: record {n}: corrupted length field')
+            body = f.read(length + 4)
+            if len(body) < length + 4:
+                raise ValueError(f'{path}: record {n}: {length} data bytes run past the end of the file')
+            data = body[:length]
+            if verify and lib.mr_crc32c_masked(data, length) != struct.unpack('<I', body[length:])[0]:
+                raise ValueError(f'{path}: record {n}: data checksum mismatch')
+            yield data
+            n += 1
+
+
 def write_tfrecord(path, records):
     """The inverse (fixtures, re-sharding): length | masked crc | data | masked crc per record."""
     lib = _lib()
@@ -755,8 +780,8 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     merged = merged_data_config(config)
     rng = np.random.default_rng(seed)
     token_is_valid = make_token_is_valid() if token_is_valid is None else token_is_valid
-    shards = [read_tfrecord(fn) for fn in ([fns] if isinstance(fns, (str, os.PathLike)) else list(fns))]
-    order = [rec for group in zip_longest_skip(shards) for rec in group]
+    shards = [iter_tfrecord(fn) for fn in ([fns] if isinstance(fns, (str, os.PathLike)) else list(fns))]      # streamed: one record per shard in memory
+    order = (rec for group in zip_longest_skip(shards) for rec in group)
     buf_size = config.get('device', {}).get('shuffle_buffer_size', 256) if is_training else 1
 
     def shuffled():

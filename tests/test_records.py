@@ -29,7 +29,7 @@ def test_tfrecord_framing_round_trip_and_corruption(tmp_path):
     recs = [b'', b'a', bytes(range(256)) * 33, b'tail']
     fn = tmp_path / 'x.tfrecord'
     R.write_tfrecord(fn, recs)
-    assert R.read_tfrecord(fn) == recs
+    assert R.read_tfrecord(fn) == recs and list(R.iter_tfrecord(fn)) == recs          # whole-file scanner (native) and the streaming reader
     raw = bytearray(fn.read_bytes())
     assert struct.unpack('<Q', raw[:8])[0] == 0 and len(raw) == sum(16 + len(r) for r in recs)
     bad = bytearray(raw)
@@ -43,6 +43,13 @@ def test_tfrecord_framing_round_trip_and_corruption(tmp_path):
     bad[16] ^= 4                                                         # the second record's length field
     with pytest.raises(ValueError, match='record 1'):
         R.read_tfrecord(bytes(bad))
+    fn2 = tmp_path / 'bad.tfrecord'
+    fn2.write_bytes(bytes(bad))
+    with pytest.raises(ValueError, match='record 1'):
+        list(R.iter_tfrecord(fn2))
+    fn2.write_bytes(bytes(raw[:-3]))
+    with pytest.raises(ValueError, match='record 3'):
+        list(R.iter_tfrecord(fn2))
 
 
 def test_example_round_trip_and_unpacked_lists():
