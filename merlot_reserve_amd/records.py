@@ -17,6 +17,8 @@ for Mitchell -- augmentation noise, not arithmetic the model is checked against.
 (dataloader.py:381-386: which vocabulary entries decode to [ A-Za-z0-9']*) needs the tokenizer's vocabulary file, a data asset of the
 reference release: pass `token_is_valid` (or an encoder) -- without it every id > 10 counts as valid.
 
+Shard paths are local files (the reference's configs name gs:// objects, which TensorFlow's file-system layer resolves: mount or copy them).
+
 Parity note: the reference holds no recorded batch, so the parser is pinned by structure only (tests/test_records.py: the invariants mask_tokens
 guarantees, hand-derived cases, acceptance by the planner and a training step).  The CONTAINER is pinned independently: CRC-32C by the RFC 3720 vectors,
 the tf.train.Example codec in both directions against the protobuf runtime (the published .proto rebuilt from descriptors); DESIGN.md section 4.
