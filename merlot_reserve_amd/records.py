@@ -774,10 +774,10 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     """Generator of per-device batches from the shards `fns`: records of the shards interleaved round-robin (tf.data's parallel reads), passed through
     a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
     dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
-    -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU.  Measured (scripts/records_demo.py,
-    360 x 640 stored frames, base grid): one record costs ~120 ms of one core (~75 ms with data.fast_image_resize: 8-bit resampling), 8 processes on 8
-    cores parse ~30 records / s; a base step consumes 4 records / 29 ms = 137 records / s per GPU, i.e. ~16-20 cores per GPU -- the order of tf.data's
-    48-thread pool per host in the reference.
+    -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU; the pool parses chunk k + 1 while
+    this process assembles the batches of chunk k.  Measured on the GPU box's host (EPYC 9575F, a job's share of ~16 cores; scripts/records_demo.py,
+    360 x 640 stored frames, base grid; profiles/r05_reader_throughput.txt): 21.5 records / s on one core, 45 with 8 threads, 119 with 8 processes,
+    136 with 16 (139 with data.fast_image_resize: 8-bit resampling) -- a base step consumes 4 records / 29 ms = 137 records / s per GPU.
     The record -> random-stream assignment does not depend on the pool, so every mode yields the same batches for the same seed."""
     merged = merged_data_config(config)
     rng = np.random.default_rng(seed)
@@ -805,25 +805,42 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=workers)
     try:
-        done, chunk = [], []
+        done, chunk, pending = [], [], None
 
-        def flush():
+        def submit():
+            """Hand the chunk to the pool and return a handle whose results are collected one chunk LATER: the workers parse chunk k + 1 while this
+            process assembles the batches of chunk k (a blocking map left both sides idle half of the time: 16 workers gave what 8 did)."""
             jobs = [(rec, s, merged, token_is_valid, use_bf16) for rec, s in chunk]
-            parsed = pool.map(_parse_job, jobs) if pool is not None else map(_parse_job, jobs)
-            done.extend(r for r in parsed if r is not None)
             chunk.clear()
+            if pool is None:
+                return map(_parse_job, jobs)
+            return pool.map_async(_parse_job, jobs) if processes else pool.map(_parse_job, jobs)
+
+        def collect(handle):
+            parsed = handle.get() if (pool is not None and processes) else handle
+            done.extend(r for r in parsed if r is not None)
+
+        def ready():
+            while len(done) >= batch_size:
+                yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
+                del done[:batch_size]
         for rec in shuffled():
             chunk.append((rec, int(rng.integers(0, 2 ** 63))))
             if len(chunk) == chunk_size:
-                flush()
-                while len(done) >= batch_size:
-                    yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
-                    del done[:batch_size]
+                nxt = submit()
+                if pending is not None:
+                    collect(pending)
+                    yield from ready()
+                pending = nxt
         if chunk:
-            flush()
-        while len(done) >= batch_size:                             # (drop_remainder=True)
-            yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
-            del done[:batch_size]
+            nxt = submit()
+            if pending is not None:
+                collect(pending)
+                yield from ready()
+            pending = nxt
+        if pending is not None:
+            collect(pending)
+        yield from ready()                                         # (drop_remainder=True)
     finally:
         if pool is not None and processes:
             pool.terminate()

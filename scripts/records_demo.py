@@ -28,11 +28,12 @@ def main():
     t0 = time.time()
     ex = [R.parse_example(r) for r in recs]
     print(f'tf.train.Example parse: {(time.time() - t0) / len(recs) * 1e3:.2f} ms / record')
-    for workers, procs in ((0, False), (4, False), (8, False), (4, True), (8, True), (16, True)):
+    for workers, procs, fast in ((0, False, False), (8, False, False), (8, True, False), (16, True, False), (0, False, True), (8, True, True), (16, True, True)):
+        cfg['data']['fast_image_resize'] = fast
         t0 = time.time()
         nb = sum(1 for _ in R.make_dataset(cfg, fns, 4, is_training=True, seed=1, workers=workers, processes=procs))
         dt = time.time() - t0
-        print(f'workers={workers} {"processes" if procs else "threads"}: {nb} batches of 4 in {dt:.2f} s = {nb * 4 / dt:.1f} records / s (incl. pool start-up)')
+        print(f'workers={workers} {"processes" if procs else "threads"}{" fast_image_resize" if fast else ""}: {nb} batches of 4 in {dt:.2f} s = {nb * 4 / dt:.1f} records / s (incl. pool start-up)')
 
 
 if __name__ == '__main__':        # (spawned parser workers re-import this file: nothing may run at import)
