@@ -727,15 +727,31 @@ def bf16_bits(x):
     return ((u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
 
 
-def handle_batch(records, use_bfloat16=True, device='cpu'):
+def handle_batch(records, use_bfloat16=True, device='cpu', as_numpy=False, out=None):
     """dataloader.py:732-789 for ONE device (`records`: a list of dataset_parser outputs): the batch dict of synthetic.make_batch -- images
     [B, nseg hw, P P 3] and audio_clips [B, nseg nsub T, 65] as torch tensors (bf16 when use_bfloat16), the token streams split into the id /
-    audio_ptr / text_ptr planes [B, n, L] (numpy int32: the planner reads them on the host), text_spans [B, nspans, span_len], video_src_index."""
-    import torch
+    audio_ptr / text_ptr planes [B, n, L] (numpy int32: the planner reads them on the host), text_spans [B, nspans, span_len], video_src_index.
+    as_numpy (the feeder process: no torch there): the two float arrays stay numpy -- uint16 bf16 bit patterns when use_bfloat16, float32 otherwise --
+    written straight into `out[k]` (views of a shared-memory slot) when given."""
     B = len(records)
     batch = {}
-    dt = torch.bfloat16 if use_bfloat16 else torch.float32
-    for k in ('images', 'audio_clips'):
+    if as_numpy:
+        for k in ('images', 'audio_clips'):
+            dst = None if out is None else out[k]
+            for i, r in enumerate(records):
+                x = r[k].reshape(-1, r[k].shape[-1])
+                if use_bfloat16 and x.dtype != np.uint16:
+                    x = bf16_bits(x)
+                elif not use_bfloat16 and x.dtype == np.uint16:
+                    x = (x.astype(np.uint32) << np.uint32(16)).view(np.float32)
+                if dst is None:
+                    dst = np.empty((B,) + x.shape, dtype=x.dtype)
+                dst[i] = x
+            batch[k] = dst
+    else:
+        import torch
+        dt = torch.bfloat16 if use_bfloat16 else torch.float32
+    for k in ('images', 'audio_clips') if not as_numpy else ():
         x = np.stack([r[k] for r in records])
         x = np.ascontiguousarray(x.reshape(B, -1, x.shape[-1]))
         if x.dtype == np.uint16:                                # bf16 bit patterns from a parser worker (bf16_bits)
@@ -770,7 +786,28 @@ def _parse_job(args):
     return f
 
 
-def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_valid=None, workers=0, device='cpu', processes=False):
+def _make_pool(workers, processes):
+    if workers <= 0:
+        return None
+    if processes:
+        import multiprocessing as mp
+        return mp.get_context('spawn').Pool(workers)              # spawn, not fork: the parent usually holds an initialised GPU runtime
+    from concurrent.futures import ThreadPoolExecutor
+    return ThreadPoolExecutor(max_workers=workers)
+
+
+def _close_pool(pool, processes):
+    if pool is None:
+        return
+    if processes:
+        pool.terminate()
+        pool.join()
+    else:
+        pool.shutdown(wait=False)
+
+
+def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_valid=None, workers=0, device='cpu', processes=False, as_numpy=False,
+                 slot_of=None, pool=None):
     """Generator of per-device batches from the shards `fns`: records of the shards interleaved round-robin (tf.data's parallel reads), passed through
     a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
     dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
@@ -796,14 +833,10 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
             yield buf.pop(int(rng.integers(0, len(buf))) if is_training else 0)
 
     use_bf16 = merged.get('use_bfloat16', True)
-    pool, chunk_size = None, batch_size
-    if workers > 0 and processes:
-        import multiprocessing as mp
-        pool = mp.get_context('spawn').Pool(workers)              # spawn, not fork: the parent usually holds an initialised GPU runtime
-        chunk_size = max(batch_size, 2 * workers)                  # keep every worker busy between two flushes
-    elif workers > 0:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=workers)
+    own_pool = pool is None                                        # (input_fn_builder keeps ONE pool over its cycles: spawning 16 workers costs ~1-2 s)
+    if own_pool:
+        pool = _make_pool(workers, processes)
+    chunk_size = max(batch_size, 2 * workers) if (pool is not None and processes) else batch_size      # keep every worker busy between two flushes
     try:
         done, chunk, pending = [], [], None
 
@@ -822,7 +855,11 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
 
         def ready():
             while len(done) >= batch_size:
-                yield handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device)
+                out = None if slot_of is None else slot_of()      # (ShardFeeder: a free shared-memory slot; blocks until the consumer released one)
+                b = handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device, as_numpy=as_numpy, out=None if out is None else out[1])
+                if out is not None:
+                    b['_slot'] = out[0]
+                yield b
                 del done[:batch_size]
         for rec in shuffled():
             chunk.append((rec, int(rng.integers(0, 2 ** 63))))
@@ -842,11 +879,8 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
             collect(pending)
         yield from ready()                                         # (drop_remainder=True)
     finally:
-        if pool is not None and processes:
-            pool.terminate()
-            pool.join()
-        elif pool is not None:
-            pool.shutdown(wait=False)
+        if own_pool:
+            _close_pool(pool, processes)
 
 
 def input_fn_builder(config, rank=0, world=1, seed=None, epochs=None, **kw):
@@ -863,14 +897,19 @@ def input_fn_builder(config, rank=0, world=1, seed=None, epochs=None, **kw):
         per_cycle -= 1
     rng = np.random.default_rng(seed)
     epoch = 0
-    while epochs is None or epoch < epochs:
-        order = [fns[i] for i in rng.permutation(len(fns))]
-        for s in range(0, len(order) - per_cycle + 1, per_cycle):
-            try:
-                yield from make_dataset(config, order[s:s + per_cycle], batch_size, is_training=True, seed=int(rng.integers(0, 2 ** 63)), **kw)
-            except (OSError, ValueError) as e:                     # an unreadable shard: reported, the cycle skipped (dataloader.py:948-951)
-                print(f'records: {e}', flush=True)
-        epoch += 1
+    workers, processes = kw.get('workers', 0), kw.get('processes', False)
+    pool = _make_pool(workers, processes)                          # one pool for every cycle of every epoch
+    try:
+        while epochs is None or epoch < epochs:
+            order = [fns[i] for i in rng.permutation(len(fns))]
+            for s in range(0, len(order) - per_cycle + 1, per_cycle):
+                try:
+                    yield from make_dataset(config, order[s:s + per_cycle], batch_size, is_training=True, seed=int(rng.integers(0, 2 ** 63)), pool=pool, **kw)
+                except (OSError, ValueError) as e:                 # an unreadable shard: reported, the cycle skipped (dataloader.py:948-951)
+                    print(f'records: {e}', flush=True)
+            epoch += 1
+    finally:
+        _close_pool(pool, processes)
 
 
 def zip_longest_skip(lists):
@@ -887,6 +926,168 @@ def zip_longest_skip(lists):
         its = alive
         if group:
             yield group
+
+
+# ------------------------------------------------------------------------------------------------ the reader in a process of its own
+def _float_shapes(config, batch_size):
+    c = merged_data_config(config)
+    h1, w1 = c['output_grid']
+    images = (batch_size, c['num_segments'] * h1 * w1, c['vit_patch_size'] ** 2 * 3)
+    audio = (batch_size, c['num_segments'] * c['num_audio_subsegments'] * c['audio_seq_length'], c['num_mels'] + 1)
+    dt = np.uint16 if c.get('use_bfloat16', True) else np.float32
+    return {'images': (images, dt), 'audio_clips': (audio, dt)}
+
+
+def _slot_views(buf, shapes):
+    out, off = {}, 0
+    for k in ('images', 'audio_clips'):
+        shape, dt = shapes[k]
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        out[k] = np.ndarray(shape, dtype=dt, buffer=buf, offset=off)
+        off += (n + 4095) // 4096 * 4096
+    return out, off
+
+
+class _FeederStop(Exception):
+    pass
+
+
+def _feeder_main(config, rank, world, seed, epochs, kw, shm_names, shapes, full, free, stop):
+    """Body of the feeder process: input_fn_builder with its parser pool, every batch's float arrays written into a shared-memory slot, the integer
+    streams (a few hundred KB) sent through the queue.  No torch, no GPU."""
+    shms = []
+    try:
+        from multiprocessing import shared_memory
+        shms = [shared_memory.SharedMemory(name=n) for n in shm_names]
+        views = [_slot_views(m.buf, shapes)[0] for m in shms]
+
+        import queue
+
+        def slot_of():
+            while True:                                           # blocks while the consumer holds every slot; leaves when it closes the feeder
+                if stop.is_set():
+                    raise _FeederStop()
+                try:
+                    i = free.get(timeout=0.25)
+                    return i, views[i]
+                except queue.Empty:
+                    pass
+        gen = input_fn_builder(config, rank=rank, world=world, seed=seed, epochs=epochs, as_numpy=True, slot_of=slot_of, **kw)
+        try:
+            for b in gen:
+                slot = b.pop('_slot')
+                full.put((slot, {k: v for k, v in b.items() if k not in ('images', 'audio_clips')}))
+                if stop.is_set():
+                    break
+            full.put(None)
+        finally:
+            gen.close()                                           # (unwinds make_dataset: its parser pool is terminated and joined)
+    except _FeederStop:
+        pass
+    except BaseException as e:                                    # noqa: BLE001 -- reported to the consumer, which raises
+        full.put(('error', f'{type(e).__name__}: {e}'))
+    finally:
+        for m in shms:
+            m.close()
+
+
+class ShardFeeder:
+    """`input_fn_builder` in a PROCESS of its own, batches handed over through a ring of shared-memory slots.
+
+    Why a process: the reader's Python (collecting and unpickling the parser pool's results, assembling batches: ~20 ms per base batch) would share the
+    trainer's GIL with the step's host work (planner ~6 ms, graph launch ~4 ms) inside a 29 ms step.  Here the trainer's process only wraps a slot's float
+    arrays as tensors (zero copy) and hands them to loader.PrefetchLoader, whose staging copy reads them once.  Measured end to end on the GPU box
+    (scripts/records_feed_bench.py, profiles/r05_shard_fed_step.txt: shards on local disk -> 14 parser processes -> this feeder -> PrefetchLoader ->
+    hipGraph replay, 150 steps over several shard cycles): 31.4 ms per step (30.5 with data.fast_image_resize) against 29.1 with resident batches.
+
+    A batch's float tensors are views of a slot that is reused `slots - 1` batches later: a consumer must have copied them by its next `next()` --
+    PrefetchLoader does (it stages into pinned memory inside the call that fetched the batch).  Iterate it; `close()` (or leaving a `with`) stops the
+    feeder and releases the shared memory."""
+
+    def __init__(self, config, rank=0, world=1, seed=None, epochs=None, workers=16, slots=4, **kw):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        self.config = config
+        c = merged_data_config(config)
+        bsz = max(config.get('device', {}).get('batch_size', world) // world, 1)
+        self.shapes = _float_shapes(config, bsz)
+        self.use_bf16 = bool(c.get('use_bfloat16', True))
+        size = sum((int(np.prod(sh)) * np.dtype(dt).itemsize + 4095) // 4096 * 4096 for sh, dt in self.shapes.values())
+        self.shms = [shared_memory.SharedMemory(create=True, size=size) for _ in range(slots)]
+        self.views = [_slot_views(m.buf, self.shapes)[0] for m in self.shms]
+        ctx = mp.get_context('spawn')
+        self.full, self.free, self.stop = ctx.Queue(), ctx.Queue(), ctx.Event()
+        for i in range(slots):
+            self.free.put(i)
+        kw = dict(kw, workers=workers, processes=workers > 0)
+        self.proc = ctx.Process(target=_feeder_main, args=(config, rank, world, seed, epochs, kw, [m.name for m in self.shms], self.shapes, self.full,
+                                                            self.free, self.stop), daemon=False)
+        self.proc.start()
+        self.held = None
+        self.closed = self.exhausted = False
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import torch
+        if self.held is not None:                                 # the consumer is done with the previous batch (it asked for the next one)
+            self.free.put(self.held)
+            self.held = None
+        import queue
+        if self.exhausted:
+            raise StopIteration
+        while True:
+            try:
+                item = self.full.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not self.proc.is_alive():
+                    raise RuntimeError(f'the feeder process died (exit code {self.proc.exitcode})') from None
+        if item is None:
+            self.exhausted = True
+            raise StopIteration
+        if item[0] == 'error':
+            self.exhausted = True
+            raise RuntimeError(f'the feeder process failed: {item[1]}')
+        slot, ints = item
+        self.held = slot
+        batch = dict(ints)
+        for k, v in self.views[slot].items():
+            batch[k] = torch.from_numpy(v.view(np.int16)).view(torch.bfloat16) if self.use_bf16 else torch.from_numpy(v)
+        return batch
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        self.stop.set()                                           # the feeder leaves its loop, closes its generator (parser pool included) and exits
+        self.proc.join(timeout=15)
+        if self.proc.is_alive():
+            self.proc.terminate()
+            self.proc.join(timeout=10)
+        for q in (self.full, self.free):
+            q.close()
+            q.cancel_join_thread()
+        self.views = None
+        for m in self.shms:
+            try:
+                m.close()
+                m.unlink()
+            except (BufferError, FileNotFoundError):              # a batch view still alive in the caller: the segment goes with the process
+                pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                         # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 # ------------------------------------------------------------------------------------------------ fixtures

@@ -315,3 +315,35 @@ def test_example_codec_against_the_protobuf_runtime():
     mine = R.parse_example(rec)
     assert set(back.features.feature) == set(mine)
     assert R.parse_example(back.SerializeToString()).keys() == mine.keys()
+
+
+def test_shard_feeder_process_delivers_the_same_batches(tmp_path):
+    """records.ShardFeeder: the reader in a process of its own (shared-memory slots for the float arrays) yields what input_fn_builder yields in process,
+    through loader.PrefetchLoader, and releases its shared memory."""
+    import torch
+    from merlot_reserve_amd.loader import PrefetchLoader
+    cfg = tiny_config()
+    rng = np.random.default_rng(21)
+    for s in range(2):
+        R.write_tfrecord(tmp_path / f'train{s:05d}of00002.tfrecord', [R.make_synthetic_record(cfg, rng) for _ in range(5)])
+    cfg['data'] = dict(cfg['data'], train_fns=str(tmp_path / 'train{:05d}of00002.tfrecord'), num_train_files=2)
+    cfg['device'] = dict(cfg.get('device', {}), batch_size=2, shuffle_buffer_size=4, n_fns_per_cycle=2)
+    ref = list(R.input_fn_builder(cfg, rank=0, world=1, seed=5, epochs=1))
+    assert len(ref) == 5
+    with R.ShardFeeder(cfg, rank=0, world=1, seed=5, epochs=1, workers=2, slots=3) as feeder:
+        names = [m.name for m in feeder.shms]
+        got = []
+        for b in PrefetchLoader(feeder, 'cpu', depth=2):          # the loader copies a slot's arrays before it asks for the next batch
+            got.append({k: (v.clone() if torch.is_tensor(v) else v.copy()) for k, v in b.items()})
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert set(a) == set(b)
+        for k in b:
+            if torch.is_tensor(b[k]):
+                assert a[k].dtype == b[k].dtype == torch.bfloat16 and torch.equal(a[k], b[k]), k
+            else:
+                assert np.array_equal(a[k], b[k]), k
+    from multiprocessing import shared_memory
+    for n in names:
+        with pytest.raises(FileNotFoundError):
+            shared_memory.SharedMemory(name=n)
