@@ -493,7 +493,8 @@ def main():
         ach_xx = fl_xx / (ms_xx * 1e-3) / 1e12
         traffic, traffic_src = None, None       # HBM bytes per GEMM launch from the committed PMC passes (scripts/pmc_step.sh): rocprofv3
         traffic_commit, traffic_step = None, None
-        for cand in ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
+        step_bytes_all = None
+        for cand in ('r06_pmc_hbm_traffic.json', 'r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):     # counters cannot be read from inside this process
             pmc = os.path.join(ROOT, 'profiles', cand)
             if not os.path.exists(pmc):
                 continue
@@ -502,6 +503,7 @@ def main():
                 g = [v for k, v in p['kernels'].items() if 'gemm' in k]
                 traffic = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g) / sum(v['launches'] for v in g)
                 traffic_step = p.get('bytes_per_step_gemm')
+                step_bytes_all = p.get('bytes_per_step_all_kernels')
                 traffic_src = cand
                 traffic_commit = p.get('commit', 'not recorded (collected before round 4)')
                 break
@@ -525,6 +527,22 @@ def main():
     if rank == 0:
         vseg = 2 * B * world * args.steps
         step_flops = algorithmic_flops_per_record(config) * B
+        if roof is not None:
+            # What bounds the STEP: the matrix-core time of its algorithmic FLOPs against the HBM time of the bytes its kernels really move (the PMC
+            # passes' HBM-side bytes of EVERY kernel of a step), at the 8 TB/s of the data sheet and at the 6.3 TB/s a streaming copy reaches
+            # (MI355X_MICROARCH.md).  `bound` names the larger floor; the `achieved` / `peak` / `frac` fields stay those of the dominant kernel
+            # family (the GEMMs, matrix-core-bound by themselves: 19.5 TFLOP against 43 GB of operands), `step_hbm` prices the step against HBM.
+            floors = {'mfma': step_flops / MFMA_BF16_PEAK * 1e3}
+            if step_bytes_all:
+                floors['hbm_at_8TBs'] = step_bytes_all / 8e12 * 1e3
+                floors['hbm_at_6.3TBs'] = step_bytes_all / 6.3e12 * 1e3
+                step_s = dt / args.steps
+                roof['step_hbm'] = {'bytes_per_step_all_kernels': step_bytes_all, 'achieved': step_bytes_all / step_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                                    'frac': step_bytes_all / step_s / 8e12, 'source': f'profiles/{traffic_src}'}
+            roof['step_floors_ms'] = {k: round(v, 2) for k, v in floors.items()}
+            roof['bound'] = 'hbm' if floors.get('hbm_at_8TBs', 0.0) > floors['mfma'] else 'mfma'
+            roof['bound_note'] = ('the step as a whole: the larger of step_floors_ms (its kernels move more HBM time than its FLOPs take matrix-core time); '
+                                  'achieved / peak / frac are the GEMM family against the matrix cores, step_hbm is the step against HBM')
         out = {
             'metric': 'video-segments/sec (whole node) pretrain step', 'value': vseg / dt, 'unit': 'video-segments/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,

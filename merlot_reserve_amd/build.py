@@ -218,7 +218,9 @@ def build(force=False, verbose=True):
         raise RuntimeError('kernels with spilled vector registers (build.py SPILL_ALLOWED lists the tolerated ones):\n' +
                            '\n'.join(f'{f}: {k}: {n} VGPRs' for f, k, n in spills))
     # -z defs: an undefined kernel stub (a template the host pass silently failed to emit) fails the build instead of the first launch
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs + ['-ldl']
+    # --version-script: the dynamic symbol table is include/mreserve_hip.h's C names (mr_*) and nothing else -- the mangled C++ helpers the
+    # translation units share, kernel handles and device stubs stay local (tests/test_cabi_exports.py reads `nm -D`)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-z,defs', '-Wl,--version-script=' + os.path.join(CSRC, 'exports.map'), '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
     with open(STAMP, 'w') as f:
         f.write(_flag_stamp())

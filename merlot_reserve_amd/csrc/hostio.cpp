@@ -71,7 +71,8 @@ extern "C" int64_t mr_tfrecord_scan(const void* buf, int64_t n, int64_t* offsets
             mr_set_error("mr_tfrecord_scan: record %ld: corrupted length field at byte %ld", (long)count, (long)pos);
             return MR_EINVAL;
         }
-        if (len > (uint64_t)(n - pos - 16)) {
+        // signed first: a shard cut 12-15 bytes into a record leaves n - pos - 16 negative, which the cast below would turn into a huge bound
+        if (n - pos < 16 || len > (uint64_t)(n - pos - 16)) {
             mr_set_error("mr_tfrecord_scan: record %ld at byte %ld: %llu data bytes run past the end of the buffer", (long)count, (long)pos, (unsigned long long)len);
             return MR_EINVAL;
         }

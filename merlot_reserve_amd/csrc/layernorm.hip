@@ -3,6 +3,7 @@
 // statistics in fp32 with var = E[x^2] - E[x]^2, y = (x - mean) * (rsqrt(var + eps) * scale) + bias.
 #include <string.h>
 #include "mr_common.h"
+#include "mr_options.h"
 
 namespace {
 
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* __restrict__ 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
                                                      int H, float eps) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 2;     // (uniform: row bases in scalar registers)
     if (row0 >= rows) return;
     const bool two = row0 + 1 < rows;
     const int nch = H >> 3;
@@ -182,6 +183,141 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
         partials[(int64_t)blockIdx.x * 2 * H + c] = red[c] + red[2 * H + c] + red[4 * H + c] + red[6 * H + c];
 }
 
+// Round 6.  The kernel above holds 161 registers (three waves per SIMD), so of its 1024 workgroups only 768 were resident and the last
+// 256 ran as a second round on a quarter of the chip's wave slots: 3.5 TB/s.  This one keeps <= 128 registers -- gamma stays packed, xhat and
+// g = dy * gamma are formed twice (before and after the row sums) instead of being held across them -- in 512-thread workgroups, two per CU, so
+// the WHOLE grid is resident from the first cycle (every wave has two rows of loads in flight at once) and a launch leaves at most 512 partial rows
+// (half the bytes for the deferred reduction to read).  Same arithmetic, same order per row and per column partial as the kernel above.
+constexpr int PART_ROWS2 = 512;
+template <int MC, bool ADD>
+__global__ __launch_bounds__(512, 4) void ln_bwd2_kernel(const __bf16* __restrict__ dy, int64_t lddy, const __bf16* __restrict__ x,
+                                                         int64_t ldx, const __bf16* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, __bf16* dx, int64_t lddx,
+                                                         const __bf16* dx_add, int64_t ldadd, float* __restrict__ partials,
+                                                         int64_t rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2H]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row bases live in scalar registers)
+    const int nch = H >> 3;
+    float pg[MC][8], pb[MC][8];
+    u32x4 gmr[MC];
+#pragma unroll
+    for (int k = 0; k < MC; ++k) {
+        const int c = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pg[k][e] = 0.f; pb[k][e] = 0.f; }
+        gmr[k] = u32x4{0u, 0u, 0u, 0u};
+        if (c < nch) gmr[k] = *reinterpret_cast<const u32x4*>(gamma + 8 * c);
+    }
+    const int64_t rstride = (int64_t)gridDim.x * 8;
+    int64_t row = (int64_t)blockIdx.x * 8 + wave;
+    u32x4 rx[MC], rd[MC];
+    float mu = 0.f, rs = 0.f;
+    auto fetch = [&](int64_t r, u32x4 (&X)[MC], u32x4 (&D)[MC], float& m_, float& r_) {
+        m_ = mean[r];
+        r_ = rstd[r];
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            X[k] = u32x4{0u, 0u, 0u, 0u}; D[k] = X[k];
+            if (c < nch) {
+                X[k] = *reinterpret_cast<const u32x4*>(x + r * ldx + 8 * c);
+                D[k] = *reinterpret_cast<const u32x4*>(dy + r * lddy + 8 * c);
+            }
+        }
+    };
+    if (row < rows) fetch(row, rx, rd, mu, rs);
+    for (; row < rows; row += rstride) {
+        // this row's residual-path gradient (wanted after the row sums) and the NEXT row's x / dy are requested before any arithmetic
+        u32x4 ra[MC], nx[MC], nd[MC];
+        if (ADD) {
+#pragma unroll
+            for (int k = 0; k < MC; ++k) {
+                const int c = lane + 64 * k;
+                ra[k] = u32x4{0u, 0u, 0u, 0u};
+                if (c < nch) ra[k] = *reinterpret_cast<const u32x4*>(dx_add + row * ldadd + 8 * c);
+            }
+        }
+        float nmu = 0.f, nrs = 0.f;
+        const bool more = row + rstride < rows;
+        if (more) fetch(row + rstride, nx, nd, nmu, nrs);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                float xv[8], dv[8], gm[8];
+                unpack8(rx[k], xv);
+                unpack8(rd[k], dv);
+                unpack8(gmr[k], gm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mu) * rs;
+                    const float gg = dv[e] * gm[e];
+                    s1 += gg;
+                    s2 += gg * xh;
+                    pg[k][e] += dv[e] * xh;
+                    pb[k][e] += dv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        // (opaque to the optimiser: otherwise common-subexpression elimination keeps the 32 floats of xhat / g alive across the sums)
+#pragma unroll
+        for (int k = 0; k < MC; ++k) asm volatile("" : "+v"(rx[k]), "+v"(rd[k]));
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+                float xv[8], dv[8], gm[8], o[8];
+                unpack8(rx[k], xv);
+                unpack8(rd[k], dv);
+                unpack8(gmr[k], gm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mu) * rs;
+                    const float gg = dv[e] * gm[e];
+                    o[e] = rs * (gg - s1 - xh * s2);
+                }
+                if (ADD) {
+                    float old[8];
+                    unpack8(ra[k], old);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += old[e];
+                }
+                *reinterpret_cast<u32x4*>(dx + row * lddx + 8 * c) = pack8(o);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < MC; ++k) { rx[k] = nx[k]; rd[k] = nd[k]; }
+            mu = nmu;
+            rs = nrs;
+        }
+    }
+    // the 8 waves' column partials through LDS in two steps (4 rows of [2H] floats), fixed order ((w0 + w4) + (w1 + w5)) + ((w2 + w6) + (w3 + w7))
+    auto put = [&](bool add) {
+        float* dst = red + (wave & 3) * 2 * H;
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dst[8 * c + e] = add ? dst[8 * c + e] + pg[k][e] : pg[k][e];
+                    dst[H + 8 * c + e] = add ? dst[H + 8 * c + e] + pb[k][e] : pb[k][e];
+                }
+            }
+        }
+    };
+    if (wave < 4) put(false);
+    __syncthreads();
+    if (wave >= 4) put(true);
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 512)
+        partials[(int64_t)blockIdx.x * 2 * H + c] = (red[c] + red[2 * H + c]) + (red[4 * H + c] + red[6 * H + c]);
+}
+
 // Column reduction of fp32 partial rows, two deterministic levels:
 //   level 1 (grid.y = RED_Y): block (x, y) sums rows y, y + RED_Y, ... of its 64 columns into mid[y, c]
 //   level 2 (grid.y = 1, nparts = RED_Y): sums mid and writes bf16; columns [0, split) -> out0, [split, ncols) -> out1.
@@ -300,7 +436,15 @@ extern "C" int mr_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
     return MR_OK;
 }
 
-extern "C" int64_t mr_layernorm_bwd_nparts(int64_t rows) { const int64_t n = (rows + 3) / 4; return n > PART_ROWS ? PART_ROWS : n; }
+// workgroups (= partial rows) of a backward launch: the round-6 kernel (option "ln_impl" = 1, the default; H <= 1024) runs 8 rows per workgroup
+// and step, at most 512 workgroups; the round-5 kernel 4 rows, at most 1024
+// (H > 1024 keeps the round-5 kernel on the same grid: the count depends on `rows` and the option alone, as the C-ABI's nparts query does)
+static int64_t ln_bwd_blocks(int64_t rows) {
+    if (mr_opts().ln_impl != 0) { const int64_t n = (rows + 7) / 8; return n > PART_ROWS2 ? PART_ROWS2 : n; }
+    const int64_t n = (rows + 3) / 4;
+    return n > PART_ROWS ? PART_ROWS : n;
+}
+extern "C" int64_t mr_layernorm_bwd_nparts(int64_t rows) { return ln_bwd_blocks(rows); }
 extern "C" int64_t mr_layernorm_bwd_workspace(int64_t H) { return (int64_t)(PART_ROWS + RED_Y) * 2 * H * sizeof(float); }
 
 extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma, const float* mean,
@@ -311,13 +455,20 @@ extern "C" int mr_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
     MR_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * MAXC, "mr_layernorm_bwd: H=%ld unsupported", (long)H);
     MR_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "mr_layernorm_bwd: leading dims must be multiples of 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int64_t nblk = (rows + 3) / 4;
-    if (nblk > PART_ROWS) nblk = PART_ROWS;
-    auto kern = (H <= 1024) ? ln_bwd_kernel<2> : ln_bwd_kernel<MAXC>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), (size_t)(8 * H * sizeof(float)), s,
-                       static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
-                       static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
-                       ldadd, static_cast<float*>(partials), rows, (int)H);
+    const int64_t nblk = ln_bwd_blocks(rows);
+    if ((mr_opts().ln_impl != 0) && H <= 1024) {
+        auto kern = dx_add != nullptr ? ln_bwd2_kernel<2, true> : ln_bwd2_kernel<2, false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), (size_t)(8 * H * sizeof(float)), s,
+                           static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
+                           static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
+                           ldadd, static_cast<float*>(partials), rows, (int)H);
+    } else {
+        auto kern = (H <= 1024) ? ln_bwd_kernel<2> : ln_bwd_kernel<MAXC>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), (size_t)(8 * H * sizeof(float)), s,
+                           static_cast<const __bf16*>(dy), lddy, static_cast<const __bf16*>(x), ldx,
+                           static_cast<const __bf16*>(gamma), mean, rstd, static_cast<__bf16*>(dx), lddx, static_cast<const __bf16*>(dx_add),
+                           ldadd, static_cast<float*>(partials), rows, (int)H);
+    }
     if (dgamma != nullptr)      // else: deferred, the caller reduces `partials` with mr_reduce_partials
         launch_reduce(static_cast<const float*>(partials), (int)nblk, (int)(2 * H), (int)H,
                       static_cast<float*>(partials) + (int64_t)PART_ROWS * 2 * H, static_cast<__bf16*>(dgamma), static_cast<__bf16*>(dbeta), s);

@@ -47,6 +47,7 @@ static int* opt_field(MrOptions& o, const char* name) {
     if (!strcmp(name, "gemm5_stagger")) return &o.gemm5_stagger;
     if (!strcmp(name, "attn_onepass")) return &o.attn_onepass;
     if (!strcmp(name, "attn_tile_modes")) return &o.attn_tile_modes;
+    if (!strcmp(name, "ln_impl")) return &o.ln_impl;
     if (!strcmp(name, "gemm_trace")) return &o.trace;
     return nullptr;
 }

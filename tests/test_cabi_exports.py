@@ -25,6 +25,18 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().mr_version() >= 1
 
 
+def test_dynamic_symbol_table_is_the_header_and_nothing_else():
+    """`nm -D`: the defined dynamic symbols are exactly the header's C names -- no mangled C++ helper, kernel handle or device stub leaks
+    (csrc/exports.map, the link's version script)."""
+    import subprocess
+    import __graft_entry__
+    __graft_entry__.build()
+    from merlot_reserve_amd import _lib
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_errors_are_reported_not_thrown():
     from merlot_reserve_amd import _lib
     lib = _lib.load()

@@ -39,6 +39,12 @@ def test_tfrecord_framing_round_trip_and_corruption(tmp_path):
     assert R.read_tfrecord(bytes(bad), verify=False)[3] == b'tail'
     with pytest.raises(ValueError, match='past the end|truncated'):
         R.read_tfrecord(bytes(raw[:-3]))
+    # a file cut 12..15 bytes into its last record (header whole, no room for the data checksum): the scanner's bound check must not wrap
+    last = len(raw) - (16 + len(recs[-1]))
+    for cut in (12, 13, 14, 15):
+        for verify in (True, False):
+            with pytest.raises(ValueError, match='past the end'):
+                R.read_tfrecord(bytes(raw[:last + cut]), verify=verify)
     bad = bytearray(raw)
     bad[16] ^= 4                                                         # the second record's length field
     with pytest.raises(ValueError, match='record 1'):
