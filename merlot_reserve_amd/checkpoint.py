@@ -149,12 +149,19 @@ def latest_checkpoint(ckpt_dir, prefix='ckpt_'):
     return os.path.join(ckpt_dir, sorted(names, key=_natural_key)[-1]) if names else None
 
 
-def save_checkpoint(state, path, keep=None, overwrite=True, no_optimizer=False, prefix='ckpt_'):
+def save_checkpoint(state, path, keep=None, overwrite=True, no_optimizer=False, prefix='ckpt_', rank=None):
     """state: {'step': int, 'params': tree, 'opt_state': tree or None} (or an object with those attributes / a
-    .state_dict()).  fp32 leaves are written as fp16 (checkpoint.py:26-37), bf16 leaves unchanged."""
+    .state_dict()).  fp32 leaves are written as fp16 (checkpoint.py:26-37), bf16 leaves unchanged.
+
+    Data-parallel runs: with partitioned Adam moments (Trainer(shard_optimizer=True), MerlotReserveVCR(shard_optimizer=True))
+    `state.state_dict()` gathers the moments from every rank -- a COLLECTIVE -- so EVERY rank must call save_checkpoint; pass `rank=`
+    and only rank 0 writes the file (the others take part in the gather and return the path).  `if rank == 0: save_checkpoint(...)`
+    around a sharded state would leave rank 0 waiting in the all-gather.  rank=None (the default) always writes."""
     if hasattr(state, 'state_dict'):
         state = state.state_dict()
     step = int(state['step'])
+    if rank is not None and int(rank) != 0:
+        return os.path.join(path, f'{prefix}{step}')
     sd = {'step': step, 'params': state['params'], 'opt_state': None if no_optimizer else state.get('opt_state')}
     sd = _treemap_cast(torch.float32, torch.float16, tree_map(lambda x: _as_tensor(x) if isinstance(x, (torch.Tensor, np.ndarray)) else x, sd))
     os.makedirs(path, exist_ok=True)

@@ -416,8 +416,10 @@ __global__ __launch_bounds__(256) void masked_lm_rows_kernel(const float* __rest
     const float lse = mx + logf(den);
     const int lab = labels[row];
     if (lane == 0) {
-        const bool on = lab != 0;
-        scratch[row] = on ? lse - x[lab] : 0.f;
+        // P:268-272: nll = -(log_softmax * one_hot(label)).sum(), mask = label != 0.  A label outside [0, V) (an "ignore index" such as -100) has an
+        // all-zero one_hot row in jax.nn.one_hot: its nll is 0, it still counts in the mask -- and nothing outside the logits row is read.
+        const bool on = lab != 0, in_range = lab >= 0 && (int64_t)lab < V;
+        scratch[row] = (on && in_range) ? lse - x[lab] : 0.f;
         scratch[n + row] = on ? 1.f : 0.f;
         scratch[2 * n + row] = lse;
     }
@@ -448,8 +450,11 @@ __global__ __launch_bounds__(256) void masked_lm_grad_kernel(const float* __rest
     const float* x = logits + row * ldl;
     float* d = dlogits + row * ldl;
     const int lab = labels[row];
-    const float w = scratch[n + row] / out[1], lse = scratch[2 * n + row];
-    for (int64_t c = lane; c < V; c += 64) d[c] = w * (expf(x[c] - lse) - (c == lab ? 1.0f : 0.0f));
+    // (a label outside [0, V) contributes a constant 0 to the loss: zero gradient.  With EVERY row masked out[1] is 0 and both the loss and this
+    // gradient are 0 / 0 = NaN, as the reference's `.sum() / mask.sum()` is.)
+    const bool in_range = lab >= 0 && (int64_t)lab < V;
+    const float w = in_range ? scratch[n + row] / out[1] : 0.f, lse = scratch[2 * n + row];
+    for (int64_t c = lane; c < V; c += 64) d[c] = in_range ? w * (expf(x[c] - lse) - (c == lab ? 1.0f : 0.0f)) : 0.f;
 }
 
 // loss_out[0] += coef * sum_l row[l];  diag[s] = sum over rows with source s of row[l], diag[3 + s] = their count (P:296-300)

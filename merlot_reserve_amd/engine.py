@@ -600,9 +600,7 @@ class PretrainEngine(TowerEngine):
         # joint tower: one gather assembles [token embeddings | audio spans | vision tokens | zero padding]
         ops.segment_sum([emb, self.audio_seq, self.imgs_seq], self._pl('joint_gather_indptr'), self._pl('joint_gather_idx'), tj.xin)
         if not d.do_rotary:                # pretrain_model.py:146-148 + modeling.py:335-341: no coordinates, x += pe (every position, padding included)
-            pe = W['joint_transformer/pe']
-            for n_ in range(d.Nj):
-                ops.add_(tj.xin[n_ * d.Sj:(n_ + 1) * d.Sj], pe)
+            ops.add_rows_periodic(tj.xin, W['joint_transformer/pe'])          # one launch for all d.Nj sequences
         self.encoder_forward(tj, 'joint_transformer', self._joint_rot(), self._pl('joint_code'))
         self.fgemm(tj.xf, 'head/kernel', self.hj, bias=W['head/bias'])
         ops.segment_sum([self.hj], self._pl('pool_indptr'), self._pl('pool_idx'), self.Xpool)

@@ -327,6 +327,45 @@ class FinetuneTrainState:
     def apply_shard(self, lo, hi, mu, nu):
         self.apply_range(lo, hi, mu=mu, nu=nu, transposed=False)
 
+    # ---- checkpoint form: flax `to_state_dict` of the finetuning chain (finetune/optimization.py:77-90): '0' = the bf16 Adam state
+    # {count, mu, nu}, '1' = subtract_old_weights' orig_params (bf16), '2' = add_decayed_weights (empty), '3' = the schedule's count,
+    # '4' = scale (empty).  (The reference notes that ITS finetuning state cannot be restarted; this one can.)  With partitioned
+    # moments (shard_optimizer=True) state_dict() gathers them from every rank: a COLLECTIVE, see checkpoint.save_checkpoint(rank=).
+    def state_dict(self):
+        m, p = self._model, self._model.params_store
+        mu, nu = (p.mu, p.nu) if m.shards is None else m.shards.full_moments()
+        count = torch.tensor(self.step, dtype=torch.int32)
+        return {'step': self.step, 'params': p.master_tree(),
+                'opt_state': {'0': {'count': count, 'mu': p._to_tree(mu), 'nu': p._to_tree(nu)}, '1': {'orig_params': p._to_tree(p.orig)},
+                              '2': {}, '3': {'count': count.clone()}, '4': {}}}
+
+    def load_state_dict(self, sd):
+        m, p = self._model, self._model.params_store
+        p.load_tree(sd['params'])
+        self.step = int(sd.get('step', 0))
+        opt = sd.get('opt_state')
+        if not opt:
+            return self
+
+        def flat(tree):
+            host = torch.zeros(p.total, dtype=torch.bfloat16)
+            for name, *_ in p.specs:
+                o, n = p.offsets[name]
+                leaf = tree
+                for k in name.split('/'):
+                    leaf = leaf[k]
+                host[o:o + n] = leaf.reshape(-1).to(torch.bfloat16)
+            return host
+        mu, nu = flat(opt['0']['mu']), flat(opt['0']['nu'])
+        if m.shards is None:
+            p.mu.copy_(mu)
+            p.nu.copy_(nu)
+        else:
+            m.shards.store_moments(mu.to(p.device), nu.to(p.device))
+        if opt.get('1') and 'orig_params' in opt['1']:
+            p.orig.copy_(flat(opt['1']['orig_params']))
+        return self
+
 
 def construct_finetuning_train_state(opt_config, model, params=None, only_state=False):
     """FO:56-105.  Returns (state, tx_fns) like the reference (tx_fns is None: the chain is one fused kernel)."""

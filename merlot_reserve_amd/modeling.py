@@ -231,8 +231,7 @@ class TransformerEncoder(_Module):
                 raise KeyError(f"rotary_coords is None and the parameters hold no '{p}/pe' (learned position embeddings, mreserve/modeling.py:335-341): "
                                'this encoder was initialised with rotary coordinates')
             assert tuple(pe.shape) == (S, H), f'pe has shape {tuple(pe.shape)}, the sequence (with CLS, if any) needs {(S, H)}'
-            for n_ in range(nseq):
-                ops.add_(xin[n_ * S:(n_ + 1) * S], pe)
+            ops.add_rows_periodic(xin, pe)
             rot = None
         else:
             rc = _np(rotary_coords, np.float64)

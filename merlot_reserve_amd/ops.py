@@ -413,6 +413,28 @@ def segment_sum(srcs, indptr, indices, dst, scale=1.0, accumulate=False):
     return dst
 
 
+_PERIODIC = {}
+
+
+def add_rows_periodic(x, table):
+    """x[r] += table[r % S] for every row r of x [n * S, H] (S = table.shape[0]): the learned position table added to every sequence
+    (mreserve/modeling.py:335-341) as ONE launch -- a segment sum with one static entry per row, accumulated onto x -- instead of one add per
+    sequence.  fp32 tensors (the correctness program) keep the per-sequence adds."""
+    S = table.shape[0]
+    n = x.shape[0] // S
+    assert x.shape[0] == n * S and x.shape[1] == table.shape[1]
+    if x.dtype == F32:
+        for i in range(n):
+            add_(x[i * S:(i + 1) * S], table)
+        return x
+    key = (n, S, str(x.device))
+    if key not in _PERIODIC:
+        _PERIODIC[key] = (torch.arange(n * S + 1, dtype=torch.int32, device=x.device),
+                          (torch.arange(n * S, dtype=torch.int32, device=x.device) % S).contiguous())
+    indptr, idx = _PERIODIC[key]
+    return segment_sum([table], indptr, idx, x, accumulate=True)
+
+
 @_timed('rowops')
 def rows_mean_fwd(src, rows, dst):
     G, R = rows.shape

@@ -44,7 +44,7 @@ class MerlotReservePretrainer:
         if 'model' not in config or 'data' not in config:
             raise ValueError("config must have 'model' and 'data' sections (the reference's YAML schema)")
         from .config import Dims
-        Dims(config, 1)             # refuses the flags this build does not implement (do_rotary = False, ...) before any buffer exists
+        Dims(config, 1)             # refuses what this build does not implement (size_per_head != 64) before any buffer exists
         return cls(config, **kwargs)
 
     # -- parameters -------------------------------------------------------------------------------------------------

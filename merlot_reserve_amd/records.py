@@ -275,8 +275,10 @@ def flip_if_vertical(image):
 
 
 def resize_and_pad(image, desired_output_size, rng, random_scale_min=0.1, random_scale_max=2.0, do_random_scale=False, shrink_both_sides=True,
-                   do_flip_if_vertical=True, resize_method='random'):
-    """data_utils.py:42-147 on a float32 [H, W, 3] image in [0, 1].  Returns (image [dh, dw, 3], image_info [7])."""
+                   do_flip_if_vertical=True, resize_method='random', keep_u8=False):
+    """data_utils.py:42-147 on a float32 [H, W, 3] image in [0, 1].  Returns (image [dh, dw, 3], image_info [7]).
+    keep_u8 (a uint8 image, the 8-bit resampling path): the result stays uint8 -- resampled, cropped and zero-padded bytes; the caller scales by
+    1 / 255 (or maps bytes to bf16 through a 256-entry table) once, on the final [dh, dw, 3] pixels only."""
     from PIL import Image
     if do_flip_if_vertical:
         image = flip_if_vertical(image)
@@ -303,29 +305,56 @@ def resize_and_pad(image, desired_output_size, rng, random_scale_min=0.1, random
         method = [R.BOX, R.BICUBIC, R.BILINEAR, R.HAMMING, R.LANCZOS, R.LANCZOS, R.BICUBIC, R.NEAREST][int(rng.integers(0, 8))]
     else:
         method = Image.Resampling.BILINEAR
-    image = _resize_f32(image if image.dtype == np.uint8 else np.asarray(image, dtype=np.float32), max(scaled_height, 1), max(scaled_width, 1), method)
-    image = np.clip(image, 0.0, 1.0)
+    if keep_u8 and image.dtype == np.uint8:
+        image = np.asarray(Image.fromarray(image).resize((max(scaled_width, 1), max(scaled_height, 1)), method))     # (8-bit output: already inside [0, 255])
+    else:
+        image = _resize_f32(image if image.dtype == np.uint8 else np.asarray(image, dtype=np.float32), max(scaled_height, 1), max(scaled_width, 1), method)
+        image = np.clip(image, 0.0, 1.0)
     image = image[offset_y:offset_y + dh, offset_x:offset_x + dw]
-    out = np.zeros((dh, dw, image.shape[2]), dtype=np.float32)          # pad_to_bounding_box(image, 0, 0, dh, dw)
+    out = np.zeros((dh, dw, image.shape[2]), dtype=image.dtype)         # pad_to_bounding_box(image, 0, 0, dh, dw)
     out[:image.shape[0], :image.shape[1]] = image
     info = np.array([min(scaled_height, dh) / dh, min(scaled_width, dw) / dw, 1.0 / scale, height, width, offset_y / height, offset_x / width],
                     dtype=np.float32)
     return out, info
 
 
-def load_and_resize_img(encoded_jpg, config, rng):
-    """dataloader.py:63-85: encoded JPEG -> [(H / P) (W / P), P P 3] patches in space_to_depth order (dy, dx, c)."""
+_U8_TO_BF16 = None
+
+
+def u8_to_bf16_bits(x):
+    """uint8 pixels -> the bf16 bit patterns of float32(v) / 255 (what bf16_bits(x / 255) gives), through a 256-entry table: the 8-bit image path
+    never materialises float32 frames (16 frames of 192 x 320 x 3 per record: 11.8 MB of floats and their rounding pass, ~13 ms of a 97-ms record)."""
+    global _U8_TO_BF16
+    if _U8_TO_BF16 is None:
+        _U8_TO_BF16 = bf16_bits(np.arange(256, dtype=np.float32) / np.float32(255.0))
+    return _U8_TO_BF16[x]
+
+
+def load_and_resize_img(encoded_jpg, config, rng, as_bf16_bits=False):
+    """dataloader.py:63-85: encoded JPEG -> [(H / P) (W / P), P P 3] patches in space_to_depth order (dy, dx, c).
+    data.fast_image_resize: the frame is resampled as 8-bit RGB (PIL's SIMD resampler, one call instead of three float planes) and only the final
+    patches are scaled -- to float32, or with as_bf16_bits straight to bf16 bit patterns (uint16)."""
     from PIL import Image
     P = config['vit_patch_size']
     h1, w1 = config['output_grid']
-    img = np.asarray(Image.open(io.BytesIO(encoded_jpg)).convert('RGB'))
-    if not config.get('fast_image_resize', False):           # the reference resamples floats (convert_image_dtype before resize_and_pad)
+    fast = config.get('fast_image_resize', False)
+    im = Image.open(io.BytesIO(encoded_jpg))
+    if fast:
+        # DCT-domain downscale while decoding, when the stored frame is at least twice the largest size the random scale can ask for (never for the
+        # corpus' 288 x 512 frames at the 192 x 320 grid; a no-op then)
+        smax = config.get('random_scale_max', 1.1) if config.get('do_random_scale', True) else 1.0
+        im.draft('RGB', (int(w1 * P * smax) + 1, int(h1 * P * smax) + 1))
+    img = np.asarray(im.convert('RGB'))
+    if not fast:                                             # the reference resamples floats (convert_image_dtype before resize_and_pad)
         img = img.astype(np.float32) / np.float32(255.0)
     img, _info = resize_and_pad(img, (h1 * P, w1 * P), rng, do_random_scale=config.get('do_random_scale', True),
                                 random_scale_max=config.get('random_scale_max', 1.1), random_scale_min=config.get('random_scale_min', 1.05),
                                 shrink_both_sides=config.get('shrink_both_sides', True), do_flip_if_vertical=config.get('do_flip_if_vertical', True),
-                                resize_method='random')
-    return np.ascontiguousarray(img.reshape(h1, P, w1, P, 3).transpose(0, 2, 1, 3, 4)).reshape(h1 * w1, P * P * 3)
+                                resize_method='random', keep_u8=fast)
+    img = np.ascontiguousarray(img.reshape(h1, P, w1, P, 3).transpose(0, 2, 1, 3, 4)).reshape(h1 * w1, P * P * 3)
+    if img.dtype == np.uint8:
+        return u8_to_bf16_bits(img) if as_bf16_bits else img.astype(np.float32) / np.float32(255.0)
+    return bf16_bits(img) if as_bf16_bits else img
 
 
 def load_audio(encoded_audio, magic_number, playback_speed, config, rng):
@@ -586,7 +615,7 @@ def merged_data_config(config):
     return c
 
 
-def dataset_parser(record, config, rng=None, token_is_valid=None):
+def dataset_parser(record, config, rng=None, token_is_valid=None, as_bf16_bits=False):
     """dataloader.py:449-712 for one serialised record (or an already parsed Example dict).  `config` is the merged data + model section (or the
     whole config).  Returns numpy features: images [nseg, hw, P P 3] f32, audio_clips [nseg, nsub, T, 65] f32, text2audio / audio2text
     [groups x seqs, lang_seq_len, 3], audio_text_matching [seq_len, 3], random_text [num_text_seqs, seq_len, 3], text_spans [nspans, span_len],
@@ -600,9 +629,10 @@ def dataset_parser(record, config, rng=None, token_is_valid=None):
     segs = _segments_of(example, nseg)
     feats = {}
 
-    feats['images'] = np.stack([load_and_resize_img(s['image/encoded'], config, rng) for s in segs])
+    # (as_bf16_bits: images and audio_clips leave as uint16 bf16 bit patterns, converted where they are produced -- the batch will be bf16 anyway)
+    feats['images'] = np.stack([load_and_resize_img(s['image/encoded'], config, rng, as_bf16_bits=as_bf16_bits) for s in segs])
     if config.get('disable_imgs_dataloader', False):
-        feats['images'] *= 0.0
+        feats['images'] = np.zeros_like(feats['images'])
     audio, audio_start, audio_end = [], [], []
     for s in segs:
         if len(s['playback_speed']) != 1:
@@ -614,6 +644,8 @@ def dataset_parser(record, config, rng=None, token_is_valid=None):
     feats['audio_clips'] = np.stack(audio)
     if config.get('disable_audio_dataloader', False):
         feats['audio_clips'] *= 0.0
+    if as_bf16_bits:
+        feats['audio_clips'] = bf16_bits(feats['audio_clips'])
 
     num_audio_spans = nseg * nsub
     ntrg = int(num_audio_spans * config['mask_rate'])
@@ -773,16 +805,56 @@ def handle_batch(records, use_bfloat16=True, device='cpu', as_numpy=False, out=N
 
 
 # ------------------------------------------------------------------------------------------------ shards -> batches (dataloader.py:864-955)
+_ATTACHED = {}          # worker process: shared-memory segments of the parent's record slots, by name
+
+
+def _slot_arrays(name, offset, rec_shapes):
+    """This process' views of one record slot of the segment `name` (attached once per worker.  The pool's workers are children of the creating
+    process and share its resource tracker, whose books are a set: attaching registers the name a second time without effect, and the creator's unlink
+    clears it)."""
+    m = _ATTACHED.get(name)
+    if m is None:
+        from multiprocessing import shared_memory
+        m = shared_memory.SharedMemory(name=name)
+        _ATTACHED.clear()                                         # (a new cycle's segment replaces the previous one)
+        _ATTACHED[name] = m
+    return _rec_views(m.buf, offset, rec_shapes)
+
+
+def _rec_views(buf, offset, rec_shapes):
+    out, off = {}, offset
+    for k in ('images', 'audio_clips'):
+        shape, dt = rec_shapes[k]
+        out[k] = np.ndarray(shape, dtype=dt, buffer=buf, offset=off)
+        off += (int(np.prod(shape)) * np.dtype(dt).itemsize + 4095) // 4096 * 4096
+    return out
+
+
 def _parse_job(args):
-    """One record in a parser worker (module level: picklable).  Floats leave as bf16 bit patterns when the batch will be bf16 anyway."""
-    rec, seed, merged, token_is_valid, as_bf16 = args
+    """One record in a parser worker (module level: picklable).  Floats leave as bf16 bit patterns when the batch will be bf16 anyway -- and, when the
+    job names a record slot (round 6: `_RecordSlots`), through shared memory: the worker writes images / audio_clips into the slot and returns only the
+    token streams (a few KB) through the pool's pipe.  6.3 MB per base record crossed that pipe pickled before, which held a 16-process pool to
+    136 records / s whatever the workers could parse."""
+    rec, seed, merged, token_is_valid, as_bf16 = args[:5]
+    slot = args[5] if len(args) > 5 else None
+    if as_bf16 and 'fast_image_resize' not in merged:             # a bf16 batch: 8-bit resampling by default (one 8-bit step is 1 / 255, a bf16 step
+        merged = dict(merged, fast_image_resize=True)             # between 0.5 and 1 is 1 / 256); data.fast_image_resize: false keeps the float resampler
     try:
-        f = dataset_parser(rec, merged, rng=np.random.default_rng(seed), token_is_valid=token_is_valid)
-    except ValueError as e:                                       # (the reference's iterator logs a failing record and goes on: dataloader.py:948-951)
-        print(f'records: skipping a record: {e}', flush=True)
+        f = dataset_parser(rec, merged, rng=np.random.default_rng(seed), token_is_valid=token_is_valid, as_bf16_bits=as_bf16)
+    except Exception as e:                                        # noqa: BLE001 -- the reference's iterator wraps the cycle in `except Exception`, logs and goes on
+        # (dataloader.py:948-951): a corrupt JPEG raises PIL.UnidentifiedImageError / OSError, a truncated protobuf IndexError or struct.error,
+        # a record with a missing feature KeyError -- one bad record must cost one record, not the cycle's shards and not the feeder
+        print(f'records: skipping a record: {type(e).__name__}: {e}', flush=True)
         return None
-    if as_bf16:
-        f['images'], f['audio_clips'] = bf16_bits(f['images']), bf16_bits(f['audio_clips'])
+    if slot is not None:
+        name, offset, rec_shapes, idx = slot
+        dst = _slot_arrays(name, offset, rec_shapes)
+        for k in ('images', 'audio_clips'):
+            if f[k].dtype != dst[k].dtype:                        # (cannot happen with the shapes make_dataset derives from the same config)
+                return f
+        for k in ('images', 'audio_clips'):
+            dst[k][...] = f[k].reshape(dst[k].shape)
+            f[k] = ('@slot', idx)
     return f
 
 
@@ -796,6 +868,59 @@ def _make_pool(workers, processes):
     return ThreadPoolExecutor(max_workers=workers)
 
 
+class _RecordSlots:
+    """Shared-memory slots for the float arrays of parsed records (parent side).  One segment of `count` slots; the parent names a free slot in every job
+    it hands to the process pool and reads the record's images / audio_clips from its own mapping when the (small) result arrives.  A record keeps its
+    slot until handle_batch has copied it into a batch.  None of this is required for correctness: with no segment (no /dev/shm room) or no free slot a
+    job travels through the pool's pipe as before."""
+
+    def __init__(self, config, count):
+        self.shm, self.free, self.count = None, [], 0
+        c = merged_data_config(config)
+        shp = _float_shapes(config, 1)
+        self.rec_shapes = {k: (tuple(sh[1:]), dt) for k, (sh, dt) in shp.items()}
+        self.rec_bytes = sum((int(np.prod(sh)) * np.dtype(dt).itemsize + 4095) // 4096 * 4096 for sh, dt in self.rec_shapes.values())
+        try:
+            st = os.statvfs('/dev/shm')
+            room = st.f_bavail * st.f_frsize
+        except OSError:
+            room = 0
+        count = int(min(count, (room // 2) // self.rec_bytes, (1 << 30) // self.rec_bytes))      # at most half of what is free, at most 1 GiB
+        if count < 1:
+            return
+        try:
+            from multiprocessing import shared_memory
+            self.shm = shared_memory.SharedMemory(create=True, size=count * self.rec_bytes)
+        except OSError:
+            return
+        self.count, self.free = count, list(range(count))
+
+    def take(self):
+        """(name, byte offset, per-record shapes, index) of a free slot for a job, or None."""
+        if not self.free:
+            return None
+        i = self.free.pop()
+        return (self.shm.name, i * self.rec_bytes, self.rec_shapes, i)
+
+    def views(self, i):
+        return _rec_views(self.shm.buf, i * self.rec_bytes, self.rec_shapes)
+
+    def release(self, i):
+        self.free.append(i)
+
+    def close(self):
+        if self.shm is not None:
+            try:
+                self.shm.close()
+            except BufferError:                                   # a view of a slot is still alive somewhere: the mapping goes with the process
+                pass
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+            self.shm = None
+
+
 def _close_pool(pool, processes):
     if pool is None:
         return
@@ -807,7 +932,7 @@ def _close_pool(pool, processes):
 
 
 def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_valid=None, workers=0, device='cpu', processes=False, as_numpy=False,
-                 slot_of=None, pool=None):
+                 slot_of=None, pool=None, rec_slots=None):
     """Generator of per-device batches from the shards `fns`: records of the shards interleaved round-robin (tf.data's parallel reads), passed through
     a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
     dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
@@ -837,26 +962,46 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     if own_pool:
         pool = _make_pool(workers, processes)
     chunk_size = max(batch_size, 2 * workers) if (pool is not None and processes) else batch_size      # keep every worker busy between two flushes
+    # parsed records come back through shared memory when the pool is made of processes (see _parse_job): two chunks in flight / being batched + a
+    # batch's worth of leftovers
+    own_slots = rec_slots is None and pool is not None and processes
+    if own_slots:
+        rec_slots = _RecordSlots(config, 2 * chunk_size + batch_size)
+    if not (pool is not None and processes):
+        rec_slots = None
     try:
         done, chunk, pending = [], [], None
 
         def submit():
             """Hand the chunk to the pool and return a handle whose results are collected one chunk LATER: the workers parse chunk k + 1 while this
             process assembles the batches of chunk k (a blocking map left both sides idle half of the time: 16 workers gave what 8 did)."""
-            jobs = [(rec, s, merged, token_is_valid, use_bf16) for rec, s in chunk]
+            slots = [None if rec_slots is None else rec_slots.take() for _ in chunk]
+            jobs = [(rec, s, merged, token_is_valid, use_bf16) + (() if sl is None else (sl,)) for (rec, s), sl in zip(chunk, slots)]
             chunk.clear()
             if pool is None:
-                return map(_parse_job, jobs)
-            return pool.map_async(_parse_job, jobs) if processes else pool.map(_parse_job, jobs)
+                return map(_parse_job, jobs), slots
+            return (pool.map_async(_parse_job, jobs) if processes else pool.map(_parse_job, jobs)), slots
 
         def collect(handle):
+            handle, slots = handle
             parsed = handle.get() if (pool is not None and processes) else handle
-            done.extend(r for r in parsed if r is not None)
+            for r, sl in zip(parsed, slots):
+                if r is not None and sl is not None and isinstance(r['images'], tuple):
+                    r.update(rec_slots.views(sl[3]))              # this process' views of the slot the worker filled
+                    r['_rslot'] = sl[3]
+                elif sl is not None:                              # a skipped record (or one that came through the pipe after all): the slot is free again
+                    rec_slots.release(sl[3])
+                if r is not None:
+                    done.append(r)
 
         def ready():
             while len(done) >= batch_size:
                 out = None if slot_of is None else slot_of()      # (ShardFeeder: a free shared-memory slot; blocks until the consumer released one)
                 b = handle_batch(done[:batch_size], use_bfloat16=use_bf16, device=device, as_numpy=as_numpy, out=None if out is None else out[1])
+                for r in done[:batch_size]:                       # handle_batch copied the float arrays: the records' slots are free
+                    if '_rslot' in r:
+                        r.pop('images'), r.pop('audio_clips')
+                        rec_slots.release(r.pop('_rslot'))
                 if out is not None:
                     b['_slot'] = out[0]
                 yield b
@@ -881,6 +1026,9 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     finally:
         if own_pool:
             _close_pool(pool, processes)
+        if own_slots:
+            done.clear()
+            rec_slots.close()
 
 
 def input_fn_builder(config, rank=0, world=1, seed=None, epochs=None, **kw):
@@ -905,8 +1053,8 @@ def input_fn_builder(config, rank=0, world=1, seed=None, epochs=None, **kw):
             for s in range(0, len(order) - per_cycle + 1, per_cycle):
                 try:
                     yield from make_dataset(config, order[s:s + per_cycle], batch_size, is_training=True, seed=int(rng.integers(0, 2 ** 63)), pool=pool, **kw)
-                except (OSError, ValueError) as e:                 # an unreadable shard: reported, the cycle skipped (dataloader.py:948-951)
-                    print(f'records: {e}', flush=True)
+                except Exception as e:                             # noqa: BLE001 -- an unreadable shard: reported, the cycle skipped (dataloader.py:948-951 catches Exception)
+                    print(f'records: {type(e).__name__}: {e}', flush=True)
             epoch += 1
     finally:
         _close_pool(pool, processes)

@@ -21,6 +21,31 @@ import torch
 PADDING, START, END, MASK, MASKAUDIO, AUDIOSPAN, LTOVPOOL, RESETCTX = 0, 1, 2, 3, 4, 5, 6, 9
 
 
+# ----------------------------------------------------------------------------- storage rounding (round 6)
+# The bf16 training program keeps every tensor it writes to HBM in bf16 and accumulates in fp32 in between (the reference's bf16 mode:
+# flax modules with dtype = bfloat16, P:323-324).  Inside `with bf16_storage():` this restatement rounds at exactly those points -- the
+# output of a LayerNorm, of a Dense WITH its fused epilogue (bias + "rotary", bias + GELU, + residual: one rounding, after the epilogue,
+# as merlot_reserve_amd/engine.py's launches store them), the softmax weights as the second product's operand, the attention output, pooled
+# rows, the normalised embeddings -- so that what is left between it and the HIP program is summation order and 1-ulp rounding flips, an
+# order of magnitude below the 2^-8 of the storage format.  Outside the context nothing changes (the exact fp32 / fp64 oracle).
+_STORE = None
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _STORE
+        self._prev, _STORE = _STORE, (lambda t: t.to(torch.bfloat16).to(t.dtype))
+        return self
+
+    def __exit__(self, *exc):
+        global _STORE
+        _STORE = self._prev
+
+
+def _st(t):
+    return t if _STORE is None else _STORE(t)
+
+
 # ----------------------------------------------------------------------------- coordinates
 def get_rotary_coordinates(seq_len, center_origin=True):
     """M:21-35. 1-D coordinates; the origin is skipped when centred."""
@@ -84,7 +109,7 @@ def layer_norm(x, p, eps=1e-5):
     mean2 = (x * x).mean(-1, keepdim=True)
     var = mean2 - mean * mean
     mul = torch.rsqrt(var + eps) * p['scale']
-    return (x - mean) * mul + p['bias']
+    return _st((x - mean) * mul + p['bias'])
 
 
 def dense(x, p):
@@ -117,22 +142,23 @@ def attention_layer(p, x, sinusoids, attention_bias):
     query_key, value = qkv[..., :2 * nh, :], qkv[..., 2 * nh:, :]
     if sinusoids is not None:
         query_key = apply_rotary(query_key, sinusoids)
+    query_key, value = _st(query_key), _st(value)            # (stored once, behind the bias + "rotary" epilogue)
     query, key = query_key[..., :nh, :], query_key[..., nh:, :]
-    probs = dot_product_attention_weights(query, key, attention_bias)
-    o = torch.einsum('...hqk,...khd->...qhd', probs, value)
-    return torch.einsum('...nd,ndh->...h', o, p['attn_proj']['kernel'])
+    probs = _st(dot_product_attention_weights(query, key, attention_bias))
+    o = _st(torch.einsum('...hqk,...khd->...qhd', probs, value))
+    return torch.einsum('...nd,ndh->...h', o, p['attn_proj']['kernel'])       # (stored behind the residual add: transformer_layer)
 
 
 def mlp_block(p, x):
     """M:244-256. out has no bias."""
-    x1 = my_gelu(dense(x, p['intermediate']))
+    x1 = _st(my_gelu(dense(x, p['intermediate'])))
     return x1 @ p['out']['kernel']
 
 
 def transformer_layer(p, x, sinusoids, attention_bias):
     """M:259-280."""
-    x = x + attention_layer(p['attention_layer'], layer_norm(x, p['pre_attn_ln']), sinusoids, attention_bias)
-    x = x + mlp_block(p['mlp_layer'], layer_norm(x, p['pre_mlp_ln']))
+    x = _st(x + attention_layer(p['attention_layer'], layer_norm(x, p['pre_attn_ln']), sinusoids, attention_bias))
+    x = _st(x + mlp_block(p['mlp_layer'], layer_norm(x, p['pre_mlp_ln'])))
     return x
 
 
@@ -153,7 +179,7 @@ def transformer_encoder(p, x, num_layers, rotary_coords=None, attention_mask=Non
         sinusoids = torch.as_tensor(construct_rotary_sinusoids(rotary_coords)).to(x.dtype)
     else:                                  # M:335-341: learned position embeddings pe [S, H] (S includes the CLS position), no rotary
         sinusoids = None
-        x = x + p['pe'][None].to(x.dtype)
+        x = _st(x + p['pe'][None].to(x.dtype))
 
     if (is_valid is not None) and (attention_mask is None):
         attention_mask = is_valid[..., None] & is_valid[..., None, :]
@@ -170,7 +196,7 @@ def transformer_encoder(p, x, num_layers, rotary_coords=None, attention_mask=Non
     x_ln = layer_norm(x, p['final_ln'])
     info = {}
     if add_cls_token:
-        info['cls'] = dense(x_ln[..., 0, :], p['cls_proj'])
+        info['cls'] = _st(dense(x_ln[..., 0, :], p['cls_proj']))
         info['seq'] = x_ln[..., 1:, :]
     else:
         info['seq'] = x_ln
@@ -179,12 +205,12 @@ def transformer_encoder(p, x, num_layers, rotary_coords=None, attention_mask=Non
 
 def multihead_attnpool(p, inputs_q, inputs_kv):
     """flax 0.3.4 nn.MultiHeadDotProductAttention (biases on q/k/v/out)."""
-    q = torch.einsum('...h,hnd->...nd', inputs_q, p['query']['kernel']) + p['query']['bias']
-    k = torch.einsum('...h,hnd->...nd', inputs_kv, p['key']['kernel']) + p['key']['bias']
-    v = torch.einsum('...h,hnd->...nd', inputs_kv, p['value']['kernel']) + p['value']['bias']
+    q = _st(torch.einsum('...h,hnd->...nd', inputs_q, p['query']['kernel']) + p['query']['bias'])
+    k = _st(torch.einsum('...h,hnd->...nd', inputs_kv, p['key']['kernel']) + p['key']['bias'])
+    v = _st(torch.einsum('...h,hnd->...nd', inputs_kv, p['value']['kernel']) + p['value']['bias'])
     w = dot_product_attention_weights(q, k)
-    o = torch.einsum('...hqk,...khd->...qhd', w, v)
-    return torch.einsum('...nd,ndh->...h', o, p['out']['kernel']) + p['out']['bias']
+    o = _st(torch.einsum('...hqk,...khd->...qhd', w, v))
+    return _st(torch.einsum('...nd,ndh->...h', o, p['out']['kernel']) + p['out']['bias'])
 
 
 def vision_transformer(p, x, num_layers, grid_h, grid_w, pooling_ratio=2):
@@ -192,14 +218,14 @@ def vision_transformer(p, x, num_layers, grid_h, grid_w, pooling_ratio=2):
     N, hw, pp3 = x.shape
     assert hw == grid_h * grid_w
     H = p['embedding']['kernel'].shape[-1]
-    x = dense(x, p['embedding'])
+    x = _st(dense(x, p['embedding']))
     coords = get_rotary_coordinates_2d(grid_h, grid_w)
     t_out = transformer_encoder(p['transformer'], x, num_layers, rotary_coords=coords, add_cls_token=True)
     h2, w2 = grid_h // pooling_ratio, grid_w // pooling_ratio
     b2 = N * h2
     seq = t_out['seq'].reshape(b2, pooling_ratio, w2, pooling_ratio, H).transpose(-4, -3)
     seq = seq.reshape(b2 * w2, pooling_ratio ** 2, H)
-    pooled = multihead_attnpool(p['seq_attnpool'], seq.mean(-2, keepdim=True), seq)
+    pooled = multihead_attnpool(p['seq_attnpool'], _st(seq.mean(-2, keepdim=True)), seq)
     t_out['seq_attnpool'] = pooled.reshape(N, h2 * w2, H)
     return t_out
 
@@ -211,12 +237,12 @@ def audio_transformer(p, x, num_layers, pooling_ratio, patch_size=2):
     seq_len = raw_len // patch_size
     k = p['embedding']['kernel']                         # [2, 65, H]
     H = k.shape[-1]
-    x = x.reshape(N, seq_len, patch_size * nm) @ k.reshape(patch_size * nm, H) + p['embedding']['bias']
+    x = _st(x.reshape(N, seq_len, patch_size * nm) @ k.reshape(patch_size * nm, H) + p['embedding']['bias'])
     coords = get_rotary_coordinates(seq_len)[:, None] / seq_len
     t_out = transformer_encoder(p['transformer'], x, num_layers, rotary_coords=coords, add_cls_token=True)
     l2 = seq_len // pooling_ratio
     seq = t_out['seq'].reshape(-1, pooling_ratio, H)
-    pooled = multihead_attnpool(p['seq_attnpool'], seq.mean(-2, keepdim=True), seq)
+    pooled = multihead_attnpool(p['seq_attnpool'], _st(seq.mean(-2, keepdim=True)), seq)
     t_out['seq_attnpool'] = pooled.reshape(N, l2, H)
     return t_out
 
@@ -431,14 +457,14 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
         coords = None
     joint_enc = transformer_encoder(params['joint_transformer'], x, cfg.joint_num_layers, rotary_coords=coords,
                                     attention_mask=attnmask)['seq']
-    joint_enc = dense(joint_enc, params['head'])
+    joint_enc = _st(dense(joint_enc, params['head']))
     mm_out = dict(zip(keys, torch.split(joint_enc, real_bsizes, dim=0)))
     mm_out['text2audio'] = mm_out['text2audio'][:, :lang_seq_len]
     mm_out['audio2text'] = mm_out['audio2text'][:, :lang_seq_len]
 
     is_pool = batch['audio_text_matching'] == LTOVPOOL
     v2a_idx = torch.cumsum(is_pool.to(torch.int64), -1) - 1
-    a2v = one_hot_pool(is_pool, v2a_idx, mm_out['audio_text_matching'], num_segments)['x'].reshape(
+    a2v = _st(one_hot_pool(is_pool, v2a_idx, mm_out['audio_text_matching'], num_segments)['x']).reshape(
         batch_size * num_segments, H)
 
     t2a_pool = one_hot_pool(batch['text2audio'] == MASKAUDIO, batch['text2audio/audio_ptr'], mm_out['text2audio'],
@@ -448,7 +474,7 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
     idx_sort = torch.argsort(-is_selected, dim=-1, stable=True)
     best_idxs = idx_sort[:, :ntrg].reshape(batch_size * ntrg)
     bi = torch.arange(batch_size).repeat_interleave(ntrg)
-    t2a_sel = t2a_pool['x'][bi, best_idxs]
+    t2a_sel = _st(t2a_pool['x'][bi, best_idxs])
     a2t_sel = audio_cls[bi, best_idxs]
     extra_idxs = idx_sort[:, ntrg:].reshape(batch_size * (num_audio_spans - ntrg))
     bi2 = torch.arange(batch_size).repeat_interleave(num_audio_spans - ntrg)
@@ -476,7 +502,7 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
     # lax.top_k: descending, lower index first on ties
     best_sp = torch.sort(score.reshape(-1), descending=True, stable=True)[1][:n_inc * batch_size]
 
-    t2sp_sel = t2sp_sel.reshape(batch_size * num_text_spans, H)[best_sp]
+    t2sp_sel = _st(t2sp_sel.reshape(batch_size * num_text_spans, H)[best_sp])      # (one segment sum over the three streams' lists, stored once)
     t2sp_src = t2sp_src.reshape(batch_size * num_text_spans)[best_sp]
     sp2t_sel = span_transformer(params['span_encoder'], txt_embs['text_spans'][best_sp],
                                 batch['text_spans'][best_sp] != PADDING, cfg.span_num_layers)
@@ -491,7 +517,7 @@ def pretrain_forward(params, config, batch, split_from_here, gumbel_z, return_de
         temp = torch.exp(outputs[k].pop('log_scale') / 2.0)
         for k2 in ['x', 'y', 'y_extra']:
             if k2 in outputs[k]:
-                outputs[k][k2] = unit_normalize(outputs[k][k2]) * temp
+                outputs[k][k2] = _st(unit_normalize(outputs[k][k2]) * temp)
     if return_debug:
         dbg = {'idx_sort': idx_sort, 'best_sp': best_sp, 'joint_x': x, 'joint_coords': coords,
                'joint_mask': attnmask, 'imgs_seq': imgs_seq, 'audio_seq': audio_seq, 'audio_cls': audio_cls,

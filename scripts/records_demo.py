@@ -1,5 +1,6 @@
 """The real-data reader on synthetic shards: writes a few TFRecord shards with the reference's record layout (records.make_synthetic_record: frames stored
-at 360 x 640 like the corpus' JPEGs), reads them back through records.make_dataset at several worker counts and prints records / s -- what one GPU's step
+at 288 x 512 -- the reference's data/process.py:418-423 resizes every extracted 360p frame to shorter side 288, longer side <= 512, before it is encoded;
+round 5 timed 360 x 640 frames, 1.56 x the pixels; pass `hw=360x640` as the third argument for that), reads them back through records.make_dataset at several worker counts and prints records / s -- what one GPU's step
 consumes is B / ms_per_step (base, B = 4: ~133 records / s).  CPU only.   python scripts/records_demo.py [n_records] [tmpdir]"""
 import os, sys, tempfile, time
 import numpy as np
@@ -11,6 +12,7 @@ from merlot_reserve_amd.config import load_config
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     tmp = sys.argv[2] if len(sys.argv) > 2 else tempfile.mkdtemp(prefix='mr_records_')
+    hw = tuple(int(v) for v in sys.argv[3].split('x')) if len(sys.argv) > 3 else (288, 512)
     cfg = load_config('base')
     cfg['device'] = dict(cfg.get('device', {}), shuffle_buffer_size=8)
     rng = np.random.default_rng(0)
@@ -18,18 +20,18 @@ def main():
     fns = []
     for s in range(2):
         fn = os.path.join(tmp, f'train{s:05d}of00002.tfrecord')
-        R.write_tfrecord(fn, [R.make_synthetic_record(cfg, rng, frame_hw=(360, 640)) for _ in range(n // 2)])
+        R.write_tfrecord(fn, [R.make_synthetic_record(cfg, rng, frame_hw=hw) for _ in range(n // 2)])
         fns.append(fn)
     size = sum(os.path.getsize(f) for f in fns)
-    print(f'wrote {n} records, {size / 1e6:.1f} MB ({size / n / 1e3:.0f} KB / record) in {time.time() - t0:.1f} s')
+    print(f'frames stored at {hw[0]} x {hw[1]}; wrote {n} records, {size / 1e6:.1f} MB ({size / n / 1e3:.0f} KB / record) in {time.time() - t0:.1f} s')
     t0 = time.time()
     recs = [r for f in fns for r in R.read_tfrecord(f)]
     print(f'container: {len(recs)} records scanned + checksummed in {(time.time() - t0) * 1e3:.1f} ms ({size / 1e6 / (time.time() - t0):.0f} MB/s)')
     t0 = time.time()
     ex = [R.parse_example(r) for r in recs]
     print(f'tf.train.Example parse: {(time.time() - t0) / len(recs) * 1e3:.2f} ms / record')
-    for workers, procs, fast in ((0, False, False), (8, False, False), (8, True, False), (16, True, False), (0, False, True), (8, True, True), (16, True, True)):
-        cfg['data']['fast_image_resize'] = fast
+    for workers, procs, fast in ((0, False, False), (8, True, False), (16, True, False), (0, False, True), (8, True, True), (16, True, True)):
+        cfg['data']['fast_image_resize'] = fast          # (False: the float resampler of rounds 1-5; True: the 8-bit path, the default for bf16 batches since round 6)
         t0 = time.time()
         nb = sum(1 for _ in R.make_dataset(cfg, fns, 4, is_training=True, seed=1, workers=workers, processes=procs))
         dt = time.time() - t0

@@ -144,3 +144,30 @@ def test_autograd_of_the_oracle_matches_finite_differences():
         fd = (vals[0] - vals[1]) / (2 * eps)
         an = float((t.grad * direction).sum())
         assert abs(fd - an) <= 1e-4 * max(abs(an), abs(fd)) + 2e-8, (name, fd, an)
+
+
+def test_bf16_storage_hook_is_off_by_default_and_rounds_at_bf16_scale():
+    """oracle/ref_torch.py `bf16_storage()` (round 6: the oracle evaluated with the bf16 program's storage format, used by the tight forward bound of
+    tests/test_trainer_fullsize_gpu.py): outside the context the restatement is bit-for-bit what it was (the float64 cross-check above runs on
+    it); inside, every output is bf16-representable and within a few 2^-8 of the exact forward; the context restores the previous state."""
+    cfg, tree, batch, splits, z = _setup(5, B=1)
+    tree = tree_to(tree_to(tree, torch.bfloat16), torch.float32)          # bf16-representable weights, as the bf16 program reads them
+    osp, oz = oracle_draws(splits, z)
+    ob = oracle_batch(batch, torch.float32)
+    with torch.no_grad():
+        exact = R.pretrain_forward(tree, cfg, ob, osp, oz)
+        with R.bf16_storage():
+            stored = R.pretrain_forward(tree, cfg, ob, osp, oz)
+        again = R.pretrain_forward(tree, cfg, ob, osp, oz)
+    assert R._STORE is None
+    n = 0
+    for k in exact:
+        for k2 in ('x', 'y', 'y_extra'):
+            if k2 in exact[k]:
+                a, s, b = exact[k][k2], stored[k][k2], again[k][k2]
+                assert torch.equal(a, b), 'the hook must leave no trace outside its context'
+                assert torch.equal(s, s.to(torch.bfloat16).to(torch.float32)), 'outputs are stored in bf16'
+                e = float((a - s).norm() / a.norm())
+                assert 1e-4 < e < 3e-2, (k, k2, e)
+                n += 1
+    assert n == 7

@@ -180,6 +180,33 @@ def test_fast_image_resize_is_the_float_path_within_one_8bit_step():
     assert all(np.array_equal(a[k], b[k]) for k in ('text2audio', 'audio2text', 'random_text', 'text_spans', 'audio_clips'))
 
 
+def test_8bit_path_to_bf16_bits_without_float_frames():
+    """Round 6: on the 8-bit path a worker maps the final uint8 patches to bf16 bit patterns through a 256-entry table (records.u8_to_bf16_bits) --
+    exactly bf16(float32(v) / 255), i.e. what rounding the float form of the same 8-bit frames gives; audio likewise leaves as bf16 bits."""
+    assert np.array_equal(R.u8_to_bf16_bits(np.arange(256, dtype=np.uint8)), R.bf16_bits(np.arange(256, dtype=np.float32) / np.float32(255.0)))
+    cfg = tiny_config()
+    rec = R.make_synthetic_record(cfg, np.random.default_rng(3), frame_hw=(120, 200))
+    c = dict(R.merged_data_config(cfg), fast_image_resize=True)
+    a = R.dataset_parser(rec, c, rng=np.random.default_rng(5))
+    b = R.dataset_parser(rec, c, rng=np.random.default_rng(5), as_bf16_bits=True)
+    assert a['images'].dtype == np.float32 and b['images'].dtype == np.uint16 and b['audio_clips'].dtype == np.uint16
+    assert np.array_equal(R.bf16_bits(a['images']), b['images']) and np.array_equal(R.bf16_bits(a['audio_clips']), b['audio_clips'])
+    assert np.array_equal(a['text2audio'], b['text2audio'])
+    # a worker's job: a bf16 batch takes the 8-bit path unless the config says otherwise
+    tiv = R.make_token_is_valid()
+    merged = R.merged_data_config(cfg)
+    j = R._parse_job((rec, 5, merged, tiv, True))
+    assert np.array_equal(j['images'], b['images'])
+    jf = R._parse_job((rec, 5, dict(merged, fast_image_resize=False), tiv, True))
+    assert jf['images'].dtype == np.uint16 and not np.array_equal(jf['images'], b['images'])
+    one_step = np.abs(R_bf16_to_f32(jf['images']) - R_bf16_to_f32(b['images'])).max()
+    assert one_step <= 1.0 / 255 + 2.0 / 256, one_step
+
+
+def R_bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
 def test_batch_matches_the_synthetic_layout_and_feeds_the_planner(tmp_path):
     from merlot_reserve_amd.planner import build_plan
     from merlot_reserve_amd.synthetic import make_draws
@@ -353,3 +380,25 @@ def test_shard_feeder_process_delivers_the_same_batches(tmp_path):
     for n in names:
         with pytest.raises(FileNotFoundError):
             shared_memory.SharedMemory(name=n)
+
+
+def test_one_bad_record_costs_one_record(tmp_path, capsys):
+    """The advisor's round-5 finding: a corrupt JPEG (PIL.UnidentifiedImageError / OSError) or a truncated protobuf (IndexError) used to end the
+    cycle or the feeder; the reference's iterator catches Exception, logs and goes on (pretrain/dataloader.py:948-951).  Seven records, one with a
+    garbled frame and one cut in the middle of the message: the five good ones still arrive."""
+    cfg = tiny_config()
+    cfg['device'] = dict(cfg.get('device', {}), shuffle_buffer_size=1, batch_size=1, n_fns_per_cycle=1)
+    rng = np.random.default_rng(8)
+    recs = [R.make_synthetic_record(cfg, rng) for _ in range(7)]
+    ex = R.parse_example(recs[2])
+    jpeg_key = next(k for k, v in ex.items() if isinstance(v, list) and v and isinstance(v[0], bytes) and v[0][:2] == b'\xff\xd8')
+    ex[jpeg_key] = [b'\xff\xd8 not a jpeg at all' + bytes(50)]
+    recs[2] = R.make_example(ex)
+    recs[4] = recs[4][:len(recs[4]) // 2]                                 # the wire format ends inside a field
+    fn = tmp_path / 'train00000of00001.tfrecord'
+    R.write_tfrecord(fn, recs)
+    for kw in ({}, {'workers': 2}):
+        got = list(R.make_dataset(cfg, [str(fn)], 1, is_training=False, seed=3, **kw))
+        assert len(got) == 5, len(got)
+    out = capsys.readouterr().out
+    assert out.count('skipping a record') == 4
