@@ -168,6 +168,7 @@ struct G256Args {
     // slice of B stays L2-resident while its A strips stream through.  (With the plain row-major order every XCD swept
     // all of B once per round of 256 tiles: rocprofv3 FETCH_SIZE showed 6x the operand bytes leaving L2 per launch.)
     int xmode, px, py, tm, tn;
+    int xpanel;            // tile columns per panel of a cell's walk (0 = XPANEL; option "gemm_xpanel", an experiment knob)
     int tiles_n[MAXG], tile_start[MAXG + 1];
     mr_gemm_args p[MAXG];
 };
@@ -184,7 +185,8 @@ __device__ __forceinline__ Item make_item(const G256Args& ga, int w, int bn, int
         const int n_lo = xj * ga.tn / ga.py, hn = (xj + 1) * ga.tn / ga.py - n_lo;
         const int q = r * PX + sl;
         it.valid = q < hm * hn;
-        const int gw = hn < XPANEL ? hn : XPANEL;
+        const int xp_ = ga.xpanel > 0 ? ga.xpanel : XPANEL;
+        const int gw = hn < xp_ ? hn : xp_;
         const int panel = q / (hm * gw), rem = q - panel * hm * gw;
         const int left = hn - panel * gw, pw = left < gw ? left : gw;          // the last panel may be narrower
         const int m = rem / (pw > 0 ? pw : 1), n = panel * gw + rem - m * pw;
@@ -221,7 +223,8 @@ __device__ __forceinline__ void item_pp(const G256Args& ga, int bperm, int q, in
         const int m_lo = xi * ga.tm / ga.px, hm = (xi + 1) * ga.tm / ga.px - m_lo;
         const int n_lo = xj * ga.tn / ga.py, hn = (xj + 1) * ga.tn / ga.py - n_lo;
         const int qq = q * px_ + sl;
-        const int gw = hn < XPANEL ? hn : XPANEL;
+        const int xp_ = ga.xpanel > 0 ? ga.xpanel : XPANEL;
+        const int gw = hn < xp_ ? hn : xp_;
         const int panel = qq / (hm * gw), rem = qq - panel * hm * gw;
         const int left = hn - panel * gw, pw = left < gw ? left : gw;          // the last panel may be narrower
         const int m = rem / (pw > 0 ? pw : 1), n = panel * gw + rem - m * pw;

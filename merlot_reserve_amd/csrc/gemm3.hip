@@ -685,6 +685,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
         for (int px = 1; px <= 8; px *= 2) {
             const int py = 8 / px;
             if (px > tm || py > tn) continue;
+            if (mr_opts().xpx > 0 && px != mr_opts().xpx) continue;
             int64_t rounds = 0;
             for (int xi = 0; xi < px; ++xi)
                 for (int xj = 0; xj < py; ++xj) {
@@ -697,7 +698,7 @@ int mr_gemm3_launch(const mr_gemm_args* a, hipStream_t s) {
             const double cost = (double)rounds * 1e12 + traffic;
             if (cost < best) { best = cost; ga.px = px; ga.py = py; }
         }
-        if (best < 1e300) { ga.xmode = 1; ga.tm = (int)tm; ga.tn = (int)tn; }
+        if (best < 1e300) { ga.xmode = 1; ga.tm = (int)tm; ga.tn = (int)tn; ga.xpanel = mr_opts().xpanel; }
     }
     ga.tiles_n[0] = (int)tn;
     ga.tile_start[0] = 0;

@@ -48,6 +48,8 @@ static int* opt_field(MrOptions& o, const char* name) {
     if (!strcmp(name, "attn_onepass")) return &o.attn_onepass;
     if (!strcmp(name, "attn_tile_modes")) return &o.attn_tile_modes;
     if (!strcmp(name, "ln_impl")) return &o.ln_impl;
+    if (!strcmp(name, "gemm_xpx")) return &o.xpx;
+    if (!strcmp(name, "gemm_xpanel")) return &o.xpanel;
     if (!strcmp(name, "gemm_trace")) return &o.trace;
     return nullptr;
 }

@@ -16,6 +16,8 @@ struct MrOptions {
     int gemm5_stagger = -1;    // "gemm5_stagger"
     int attn_onepass = -1;     // "attn_onepass"
     int attn_tile_modes = 1;   // "attn_tile_modes"
+    int xpx = 0;               // "gemm_xpx": force the XCD partition px x (8 / px) of the tile grid (1, 2, 4, 8; 0 = the cost model)
+    int xpanel = 0;            // "gemm_xpanel": tile columns per panel of a cell's walk (0 = 8)
     int ln_impl = 1;           // "ln_impl": 1 = the round-6 LayerNorm kernels (whole grid resident), 0 = round 5's
     int trace = 0;             // "gemm_trace": record the kernel every GEMM launch is routed to (mr_last_gemm_kernel)
 };

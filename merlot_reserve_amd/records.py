@@ -326,8 +326,14 @@ def u8_to_bf16_bits(x):
     never materialises float32 frames (16 frames of 192 x 320 x 3 per record: 11.8 MB of floats and their rounding pass, ~13 ms of a 97-ms record)."""
     global _U8_TO_BF16
     if _U8_TO_BF16 is None:
-        _U8_TO_BF16 = bf16_bits(np.arange(256, dtype=np.float32) / np.float32(255.0))
-    return _U8_TO_BF16[x]
+        t = bf16_bits(np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.uint32)
+        pair = np.arange(65536, dtype=np.uint32)                  # two pixels per lookup: a little-endian uint16 holds (first, second) as (low, high) byte
+        _U8_TO_BF16 = (t, t[pair & 0xff] | (t[pair >> 8] << np.uint32(16)))
+    t, t2 = _U8_TO_BF16
+    x = np.ascontiguousarray(x)
+    if x.size % 2 == 0 and x.dtype == np.uint8:
+        return t2[x.reshape(-1).view(np.uint16)].view(np.uint16).reshape(x.shape)
+    return t[x].astype(np.uint16)
 
 
 def load_and_resize_img(encoded_jpg, config, rng, as_bf16_bits=False):

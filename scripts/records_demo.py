@@ -33,8 +33,14 @@ def main():
     for workers, procs, fast in ((0, False, False), (8, True, False), (16, True, False), (0, False, True), (8, True, True), (16, True, True)):
         cfg['data']['fast_image_resize'] = fast          # (False: the float resampler of rounds 1-5; True: the 8-bit path, the default for bf16 batches since round 6)
         t0 = time.time()
-        nb = sum(1 for _ in R.make_dataset(cfg, fns, 4, is_training=True, seed=1, workers=workers, processes=procs))
+        nb, t_first = 0, None
+        for _ in R.make_dataset(cfg, fns, 4, is_training=True, seed=1, workers=workers, processes=procs):
+            nb += 1
+            if t_first is None:
+                t_first = time.time()          # (the pool has started and the first two chunks are parsed)
         dt = time.time() - t0
+        sustained = (nb - 1) * 4 / max(time.time() - t_first, 1e-9)
+        print(f'   sustained (first batch -> last batch, pool start-up excluded): {sustained:.1f} records / s') if nb > 1 else None
         print(f'workers={workers} {"processes" if procs else "threads"}{" fast_image_resize" if fast else ""}: {nb} batches of 4 in {dt:.2f} s = {nb * 4 / dt:.1f} records / s (incl. pool start-up)')
 
 

@@ -25,7 +25,13 @@ def test_bench_line_contract(dev):
     assert 'workload' in d['config'] and 'model' not in d['config'] and d['config']['hipgraph'] is True
     assert abs(d['value'] - 8 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']          # 4 records = 8 video-segment groups per step
     r = d['roofline']
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
+    assert r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
+    # round 6: what bounds the STEP -- the matrix-core time of its FLOPs against the HBM time of the bytes its kernels move (the committed PMC passes);
+    # `bound` names the larger floor, achieved / peak / frac stay the GEMM family's, step_hbm prices the step against HBM
+    fl = r['step_floors_ms']
+    assert set(fl) >= {'mfma', 'hbm_at_8TBs', 'hbm_at_6.3TBs'} and 5.0 < fl['mfma'] < 12.0 and fl['hbm_at_8TBs'] < fl['hbm_at_6.3TBs'] < d['ms_per_step']
+    assert r['bound'] == ('hbm' if fl['hbm_at_8TBs'] > fl['mfma'] else 'mfma')
+    assert r['step_hbm']['unit'] == 'GB/s' and r['step_hbm']['peak'] == 8000.0 and 0.1 < r['step_hbm']['frac'] < 1.0
     assert 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0
     # round 5: the GEMM launches' algorithmic bytes beside the PMC total, a calibration figure around the timed region, graph == eager

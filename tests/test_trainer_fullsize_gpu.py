@@ -22,7 +22,14 @@ from tests.util import oracle_batch, oracle_draws, relerr, tree_to
 
 pytestmark = pytest.mark.gpu
 
-TOL_BF16_STORAGE = 3e-3        # rel-L2 of every x / y tensor against the oracle with bf16 storage (measured values in DESIGN.md section 4)
+# Round 6 (review item 6).  Measured on MI355X, B = 4: program vs the oracle evaluated with bf16 storage 4.3e-3 .. 6.4e-3 (base), 6.5e-3 .. 8.2e-3 (large) -- about
+# 0.65 of either one's distance to the exact forward (8.1e-3 .. 9.5e-3 base, 1.1e-2 .. 1.2e-2 large): two bf16 evaluations of a 24-layer-deep forward are
+# two realisations of the same rounding noise (the softmax weights alone are rounded in another form by the kernels: unnormalised, per key tile), so their
+# mutual distance cannot go far below sqrt(2) x 0.5 of that noise and the 3e-3 the review hoped for is not there to be had.  What the evaluation does give
+# is a bound that SCALES with the noise: the program may not be further from the exact forward than the restatement's own bf16 evaluation is, times 1.25
+# (measured ratios 1.01 .. 1.04) -- a systematic error of 0.75 x the noise (~0.7 % of a tensor's norm) fails it, where the fixed 2e-2 let 1.7 % through.
+TOL_BF16_STORAGE = 1.5e-2      # rel-L2 of every x / y tensor against the oracle with bf16 storage
+RATIO_BF16_STORAGE = 1.25      # (program - exact) / (bf16-storage oracle - exact), per tensor
 
 
 def _snapshot(p):
@@ -81,18 +88,23 @@ def test_b4_trainer_step_against_oracle(dev, model_name):
     print(f'{model_name} B=4 forward: worst rel-L2 {worst:.3e}; loss {li["loss"]:.5f} vs oracle {float(loss):.5f}')
 
     # ---- (1b) the same forward against the oracle evaluated WITH the program's storage format (oracle/ref_torch.py bf16_storage: bf16 where
-    # engine.py stores bf16, fp32 accumulation in between).  What is left is summation order and 1-ulp rounding flips, so this bound sits an
-    # order of magnitude under the storage format's 2^-8 and would catch a mis-routed weight, epilogue or scale that the 2e-2 above lets through.
+    # engine.py stores bf16, fp32 accumulation in between).  Two bounds come out of it.  (i) program vs that evaluation: what is left is the
+    # softmax weights' rounding (the kernels round the UNnormalised exp(s - running max) of a key tile, the restatement the normalised weights: same
+    # magnitude, other bits), 24 layers deep -- half of the distance to the exact forward.  (ii) the program may not be further from the EXACT forward
+    # than the restatement's own bf16 evaluation is (x RATIO_BF16_STORAGE): a mis-routed weight, epilogue or scale adds to the program's distance only.
     with torch.no_grad(), R.bf16_storage():
         preds_q = R.pretrain_forward(params, cfg, oracle_batch(batch), osp, oz)
         loss_q, _ = R.loss_fn_given_preds([preds_q])
-    worst_q = 0.0
+    worst_q, worst_ratio = 0.0, 0.0
     for k, k2, _ in SECTIONS:
         e = relerr(outs[k][k2], preds_q[k][k2])
-        worst_q = max(worst_q, e)
+        e_exact, q_exact = relerr(outs[k][k2], preds[k][k2]), relerr(preds_q[k][k2], preds[k][k2])
+        worst_q, worst_ratio = max(worst_q, e), max(worst_ratio, e_exact / q_exact)
+        print(f'  {k}/{k2}: program vs bf16-storage oracle {e:.3e}; vs exact: program {e_exact:.3e}, bf16-storage oracle {q_exact:.3e}')
         assert e <= TOL_BF16_STORAGE, f'B = 4 forward vs the bf16-storage oracle {k}/{k2}: rel err {e:.3e}'
+        assert e_exact <= RATIO_BF16_STORAGE * q_exact, f'B = 4 forward {k}/{k2}: {e_exact:.3e} from the exact forward, the oracle in bf16 storage {q_exact:.3e}'
     assert abs(li['loss'] - float(loss_q)) <= 5e-4 * abs(float(loss_q)), (li['loss'], float(loss_q))
-    print(f'{model_name} B=4 forward vs bf16-storage oracle: worst rel-L2 {worst_q:.3e}; loss {li["loss"]:.5f} vs {float(loss_q):.5f}')
+    print(f'{model_name} B=4 forward vs bf16-storage oracle: worst rel-L2 {worst_q:.3e}, worst distance ratio {worst_ratio:.2f}; loss {li["loss"]:.5f} vs {float(loss_q):.5f}')
     del preds_q
 
     # ---- (2) every gradient leaf of an injected dE through the Trainer's bucketed backward (no update)
