@@ -72,6 +72,10 @@ const char* mr_last_error(void);
  *                   allowed: the unmasked instruction sequence; none allowed and every query valid: the tile is skipped; otherwise the general
  *                   path -- bit-identical results | 0 = the general path everywhere (tests, A/B)
  *   "gemm_trace"    1 = every GEMM launch records the kernel it was routed to (mr_last_gemm_kernel; bench.py's per-kernel table)
+ *   "ln_impl"       1 = default: mr_layernorm_bwd runs the round-6 kernel (<= 128 registers, 512-thread workgroups: the whole grid resident; at most
+ *                   512 partial rows) | 0 = round 5's (A/B).  mr_layernorm_bwd_nparts follows the option.
+ *   "gemm_xpx"      0 = default: the XCD partition px x (8 / px) of a persistent GEMM's tile grid comes from the cost model | 1 | 2 | 4 | 8 forces px;
+ *   "gemm_xpanel"   0 = default (8): tile columns per panel of an XCD cell's walk (experiment knobs: scripts/xcd_walk_ab.sh)
  * Environment variables (MR_GEMM3, MR_G3_PH, ...: experiment scripts) are read only by a library built with -DMR_DEBUG_ENV
  * (MR_DEBUG_ENV=1 python -m merlot_reserve_amd.build); the product build ignores the environment.
  * Unknown names return MR_EINVAL. */
@@ -321,6 +325,13 @@ int mr_f32_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const 
  * (MR_DT_BF16) or fp32 (MR_DT_F32); mask: uint8 [nseq, S, S], shared by the heads.  Forward only (the zero-shot API surface): every mask the model builds
  * itself has the block form the code-based kernels take. */
 int mr_attention_fwd_dense_mask(const void* qkv, int32_t dtype, const uint8_t* mask, void* out, int64_t nseq, int64_t S, int64_t nh, void* stream);
+/* Backward of mr_attention_fwd_dense_mask (round 6; the reference differentiates TransformerEncoder under any mask: mreserve/modeling.py:343-358).
+ * dout [nseq*S, H], dqkv [nseq*S, 3H] in `dtype`; every element of dqkv is written.  rot_tab (optional, fp32 [rot_rows, 32]): dq / dk are multiplied by
+ * the "rotary" scales on the way out, like mr_attention_bwd.  workspace: mr_attention_bwd_dense_mask_workspace(nseq, S, nh) bytes (the probabilities
+ * and score gradients, fp32 [nseq, nh, S, S] each).  The bias gradient is the column sum of dqkv (mr_colsum).  S <= 1920. */
+int64_t mr_attention_bwd_dense_mask_workspace(int64_t nseq, int64_t S, int64_t nh);
+int mr_attention_bwd_dense_mask(const void* qkv, int32_t dtype, const uint8_t* mask, const void* dout, void* dqkv, const float* rot_tab,
+                                int64_t rot_rows, void* workspace, int64_t nseq, int64_t S, int64_t nh, void* stream);
 /* qkv [nseq*S, 3H] fp32 (layout of mr_attention_fwd); lse may be NULL */
 int mr_f32_attention_fwd(const float* qkv, const int32_t* code, float* out, float* lse, int64_t nseq, int64_t S,
                          int64_t nh, void* stream);

@@ -85,6 +85,8 @@ PROTOTYPES = {
     'mr_f32_layernorm_fwd': (i32, [vp, i64, vp, vp, vp, i64, i64, i64, f32, vp]),
     'mr_f32_attention_fwd': (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
     'mr_attention_fwd_dense_mask': (i32, [vp, i32, vp, vp, i64, i64, i64, vp]),
+    'mr_attention_bwd_dense_mask_workspace': (i64, [i64, i64, i64]),
+    'mr_attention_bwd_dense_mask': (i32, [vp, i32, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]),
     'mr_f32_poolattn_fwd': (i32, [vp, vp, vp, i64, vp, vp, i64, i64, i64, vp]),
     'mr_f32_segment_sum': (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i64, i64, f32, vp]),
     'mr_f32_rows_mean_fwd': (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),

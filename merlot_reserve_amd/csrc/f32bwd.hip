@@ -374,6 +374,109 @@ __global__ void f32_nan_to_num_kernel(float* __restrict__ y, int64_t n) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- attention backward under an ARBITRARY [L, L] mask
+// The backward twin of dense_mask_attn_fwd_kernel (f32path.hip): TransformerEncoder takes any boolean attention_mask [*, L, L] and the reference's
+// autodiff differentiates through it (mreserve/modeling.py:343-358).  Plain fp32 arithmetic on bf16 or fp32 operands, two kernels, no atomics:
+//   q pass : one wave per (sequence, head, query i).  Scores on the lanes exactly as in the forward (the literal -1e10 where the mask byte is 0, so a row
+//            with no allowed key is uniform over all L keys and its gradient flows, as in the reference), p = softmax, dp_j = dO_i . v_j,
+//            delta = sum_j p_j dp_j, ds_j = p_j (dp_j - delta); P[row, :] and dS[row, :] go to the fp32 workspace; then, one head dim per lane,
+//            dQ_i = (1 / 8) sum_j ds_j K_j.
+//   kv pass: one wave per (sequence, head, key j), one head dim per lane: dV_j = sum_i P[i, j] dO_i, dK_j = (1 / 8) sum_i dS[i, j] Q_i.
+// dq / dk are multiplied by the "rotary" scale table on the way out when one is given (gradient wrt the pre-"rotary" qkv, like mr_attention_bwd).
+// An API-completeness path (a correctness kernel, O(L^2) floats of workspace), not a training kernel of the stock towers, whose masks are of the block form.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_mask_attn_bwd_q_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ mask, const T* __restrict__ dout,
+                                                                    T* __restrict__ dqkv, const float* __restrict__ rot_tab, int64_t rot_rows,
+                                                                    float* __restrict__ Pw, float* __restrict__ dSw, int64_t S, int64_t nh, int64_t nrows) {
+    extern __shared__ float dmb_smem[];                // per wave: q / 8 [64], dO_i [64], then S probabilities, S values of dp / ds
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;          // (sequence, head, query)
+    if (row >= nrows) return;                                     // (wave-uniform; no barrier in this kernel)
+    float* qs = dmb_smem + (size_t)wave * (128 + 2 * S);
+    float* dos = qs + 64;
+    float* sc = dos + 64;
+    float* ds = sc + S;
+    const int64_t qi = row % S, h = (row / S) % nh, seq = row / (S * nh);
+    const int64_t H = nh * 64, ld = 3 * H;
+    const T* base = qkv + seq * S * ld;
+    qs[lane] = (float)base[qi * ld + h * 64 + lane] * 0.125f;
+    dos[lane] = (float)dout[(seq * S + qi) * H + h * 64 + lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the wave's own LDS writes (wave-private region)
+    const uint8_t* mrow = mask + (seq * S + qi) * S;
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < S; j += 64) {
+        const T* kr = base + j * ld + H + h * 64;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) a += qs[d] * (float)kr[d];
+        a += mrow[j] ? 0.f : -1e10f;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int64_t j = lane; j < S; j += 64) {
+        const float pv = __expf(sc[j] - mx);
+        sc[j] = pv;
+        sum += pv;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float delta = 0.f;
+    for (int64_t j = lane; j < S; j += 64) {
+        const T* vr = base + j * ld + 2 * H + h * 64;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) a += dos[d] * (float)vr[d];
+        const float pj = sc[j] * inv;
+        sc[j] = pj;
+        ds[j] = a;
+        delta += pj * a;
+    }
+    delta = wave_sum(delta);
+    float* prow = Pw + row * S;
+    float* drow = dSw + row * S;
+    for (int64_t j = lane; j < S; j += 64) {
+        const float v = sc[j] * (ds[j] - delta);
+        ds[j] = v;
+        prow[j] = sc[j];
+        drow[j] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float acc = 0.f;
+    const T* kcol = base + H + h * 64 + lane;
+    for (int64_t j = 0; j < S; ++j) acc += ds[j] * (float)kcol[j * ld];
+    acc *= 0.125f;
+    if (rot_tab != nullptr && lane < 32) acc *= rot_tab[((seq * S + qi) % rot_rows) * 32 + lane];
+    dqkv[(seq * S + qi) * ld + h * 64 + lane] = (T)acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_mask_attn_bwd_kv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                                     const float* __restrict__ rot_tab, int64_t rot_rows, const float* __restrict__ Pw,
+                                                                     const float* __restrict__ dSw, int64_t S, int64_t nh, int64_t nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;          // (sequence, head, key)
+    if (row >= nrows) return;
+    const int64_t kj = row % S, h = (row / S) % nh, seq = row / (S * nh);
+    const int64_t H = nh * 64, ld = 3 * H;
+    const T* qcol = qkv + seq * S * ld + h * 64 + lane;
+    const T* docol = dout + seq * S * H + h * 64 + lane;
+    const float* pcol = Pw + ((seq * nh + h) * S) * S + kj;        // P[(seq, h, i), kj]: one value per query, the same for every lane
+    const float* dcol = dSw + ((seq * nh + h) * S) * S + kj;
+    float dv = 0.f, dk = 0.f;
+    for (int64_t i = 0; i < S; ++i) {
+        dv += pcol[i * S] * (float)docol[i * H];
+        dk += dcol[i * S] * (float)qcol[i * ld];
+    }
+    dk *= 0.125f;                                                    // s = (q / 8) . k: ds / dk = q / 8 (Q is read as stored, unscaled)
+    if (rot_tab != nullptr && lane < 32) dk *= rot_tab[((seq * S + kj) % rot_rows) * 32 + lane];
+    T* orow = dqkv + (seq * S + kj) * ld + h * 64 + lane;
+    orow[H] = (T)dk;
+    orow[2 * H] = (T)dv;
+}
+
 }  // namespace
 
 extern "C" int mr_f32_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float* dx, int64_t lddx,
@@ -465,5 +568,37 @@ extern "C" int mr_f32_nan_to_num(float* y, int64_t n, void* stream) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(f32_nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), y, n);
     MR_CHECK_LAUNCH("mr_f32_nan_to_num");
+    return MR_OK;
+}
+
+extern "C" int64_t mr_attention_bwd_dense_mask_workspace(int64_t nseq, int64_t S, int64_t nh) {
+    return (nseq > 0 && S > 0 && nh > 0) ? 2 * nseq * nh * S * S * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mr_attention_bwd_dense_mask(const void* qkv, int32_t dtype, const uint8_t* mask, const void* dout, void* dqkv, const float* rot_tab,
+                                           int64_t rot_rows, void* workspace, int64_t nseq, int64_t S, int64_t nh, void* stream) {
+    MR_CHECK_ARG(qkv && mask && dout && dqkv && workspace, "mr_attention_bwd_dense_mask: null pointer");
+    MR_CHECK_ARG(nseq > 0 && S > 0 && nh > 0 && S <= 1920, "mr_attention_bwd_dense_mask: bad shape (S <= 1920: a query's probabilities and score gradients live in LDS)");
+    MR_CHECK_ARG(dtype == MR_DT_BF16 || dtype == MR_DT_F32, "mr_attention_bwd_dense_mask: dtype must be MR_DT_BF16 or MR_DT_F32");
+    MR_CHECK_ARG(!rot_tab || rot_rows > 0, "mr_attention_bwd_dense_mask: rot_rows must be > 0");
+    const int64_t nrows = nseq * nh * S;
+    MR_CHECK_ARG((nrows + 3) / 4 < (1LL << 31), "mr_attention_bwd_dense_mask: too many rows");
+    const dim3 grid((unsigned)((nrows + 3) / 4));
+    const size_t smem = 4 * (128 + 2 * (size_t)S) * sizeof(float);
+    float* Pw = static_cast<float*>(workspace);
+    float* dSw = Pw + nrows * S;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MR_DT_F32) {
+        hipLaunchKernelGGL(dense_mask_attn_bwd_q_kernel<float>, grid, dim3(256), smem, s, static_cast<const float*>(qkv), mask, static_cast<const float*>(dout),
+                           static_cast<float*>(dqkv), rot_tab, rot_rows, Pw, dSw, S, nh, nrows);
+        hipLaunchKernelGGL(dense_mask_attn_bwd_kv_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(qkv), static_cast<const float*>(dout),
+                           static_cast<float*>(dqkv), rot_tab, rot_rows, Pw, dSw, S, nh, nrows);
+    } else {
+        hipLaunchKernelGGL(dense_mask_attn_bwd_q_kernel<__bf16>, grid, dim3(256), smem, s, static_cast<const __bf16*>(qkv), mask, static_cast<const __bf16*>(dout),
+                           static_cast<__bf16*>(dqkv), rot_tab, rot_rows, Pw, dSw, S, nh, nrows);
+        hipLaunchKernelGGL(dense_mask_attn_bwd_kv_kernel<__bf16>, grid, dim3(256), 0, s, static_cast<const __bf16*>(qkv), static_cast<const __bf16*>(dout),
+                           static_cast<__bf16*>(dqkv), rot_tab, rot_rows, Pw, dSw, S, nh, nrows);
+    }
+    MR_CHECK_LAUNCH("mr_attention_bwd_dense_mask");
     return MR_OK;
 }

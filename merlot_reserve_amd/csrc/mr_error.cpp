@@ -25,7 +25,8 @@ extern "C" const char* mr_last_error(void) { return g_err; }
 //    mr_last_gemm_kernel, options "gemm5" / "gemm5_stagger" / "gemm_trace"; environment knobs only in MR_DEBUG_ENV builds (round 4)
 // 5: mr_attention_fwd_dense_mask, mr_masked_lm_xent, mr_crc32c / mr_crc32c_masked / mr_tfrecord_scan, option "attn_tile_modes"; mr_destroy refuses a handle
 //    another thread holds (round 5)
-extern "C" int mr_version(void) { return 5; }
+// 6: mr_attention_bwd_dense_mask (+ _workspace), options "ln_impl" / "gemm_xpx" / "gemm_xpanel"; the dynamic symbol table is the header's names only (round 6)
+extern "C" int mr_version(void) { return 6; }
 
 // ---- option sets: one per handle + the process-wide defaults ----
 static MrOptions g_default_opts;

@@ -235,8 +235,10 @@ class TowerEngine:
                     g2=f'{p}/pre_mlp_ln/scale', b2=f'{p}/pre_mlp_ln/bias', w1=f'{p}/mlp_layer/intermediate/kernel',
                     bb1=f'{p}/mlp_layer/intermediate/bias', w2=f'{p}/mlp_layer/out/kernel')
 
-    def encoder_forward(self, st, prefix, rot, code):
-        """TransformerEncoder body (modeling.py:360-366) on st.xin (CLS row already in place) -> st.xf."""
+    def encoder_forward(self, st, prefix, rot, code, dense_mask=None):
+        """TransformerEncoder body (modeling.py:360-366) on st.xin (CLS row already in place) -> st.xf.
+        dense_mask: uint8 [nseq, S, S] (!= 0 = allowed) -- ANY attention mask (modeling.py:303, 350-356) instead of the position codes; the
+        attention then runs on the plain dense-mask kernels, forward here and backward in encoder_backward (round 6: a correctness path)."""
         W, H, nh = self.W, st.H, st.H // 64
         ops.layernorm_fwd(st.xin, W[f'{prefix}/pre_ln/scale'], W[f'{prefix}/pre_ln/bias'], st.X[0], st.stats[0, 0], st.stats[0, 1])
         for l in range(st.L):
@@ -244,7 +246,10 @@ class TowerEngine:
             x = st.X[l]
             ops.layernorm_fwd(x, W[n['g1']], W[n['b1']], st.ln1[l], st.stats[1 + 2 * l, 0], st.stats[1 + 2 * l, 1])
             self.fgemm(st.ln1[l], n['wqkv'], st.qkv[l], bias=W[n['bqkv']], rot_tab=rot, rot_cols=2 * H)
-            ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
+            if dense_mask is not None:
+                ops.attention_fwd_dense_mask(st.qkv[l], dense_mask, st.att[l], st.nseq, st.S, nh)
+            else:
+                ops.attention_fwd(st.qkv[l], code, st.att[l], st.lse[l], st.nseq, st.S, nh)
             self.fgemm(st.att[l], n['wo'], st.xmid[l], residual=x)
             ops.layernorm_fwd(st.xmid[l], W[n['g2']], W[n['b2']], st.ln2[l], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1])
             self.fgemm(st.ln2[l], n['w1'], st.hact[l], bias=W[n['bb1']], act=ops.ACT_GELU, c2=None if st.hpre is None else st.hpre[l])
@@ -269,7 +274,7 @@ class TowerEngine:
                 best = g
         return best
 
-    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None, extra_wgrads=None):
+    def encoder_backward(self, st, prefix, rot, code, D, layer_done=None, tr=None, extra_wgrads=None, dense_mask=None):
         """D [M,H]: gradient wrt st.xf.  Returns the buffer holding the gradient wrt st.xin (D or one of the scratch
         buffers that rotate through the layers).  Weight gradients go to the flat grad buffer; the four weight
         gradients of a layer -- of TWO layers when that fills the chip better (_wgrad_group) -- are deferred to ONE grouped
@@ -317,9 +322,12 @@ class TowerEngine:
             ops.layernorm_bwd(T_a, st.xmid[l], W[n['g2']], st.stats[2 + 2 * l, 0], st.stats[2 + 2 * l, 1], Dmid,
                               G[n['g2']], G[n['b2']], self.cur.ln_wsA[gi], dx_add=Dcur, jobs=jobs)    # Dmid = d xmid
             self.gemm(Dmid, W[n['wo']], T_a, transB=True)                                   # d att
-            fuse_q = jobs is not None and os.environ.get('MR_NO_ATTN_COLSUM') != '1'          # (A/B switch)
-            ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh,
-                              colsum_ws=self.cur.cs_attn[gi], bias_grad=G[n['bqkv']], jobs=jobs if fuse_q else None)   # (+ column sums of T_q = d bias)
+            fuse_q = jobs is not None and os.environ.get('MR_NO_ATTN_COLSUM') != '1' and dense_mask is None          # (A/B switch)
+            if dense_mask is not None:       # any mask (the forward ran mr_attention_fwd_dense_mask): the plain backward pair; d bias = a column-sum pass below
+                ops.attention_bwd_dense_mask(st.qkv[l], dense_mask, T_a, T_q, rot, st.nseq, st.S, nh)
+            else:
+                ops.attention_bwd(st.qkv[l], code, st.att[l], T_a, st.lse[l], self.cur.delta, T_q, rot, st.nseq, st.S, nh,
+                                  colsum_ws=self.cur.cs_attn[gi], bias_grad=G[n['bqkv']], jobs=jobs if fuse_q else None)   # (+ column sums of T_q = d bias)
             if not fused_bb1:
                 ops.colsum(T_h, G[n['bb1']], self.cur.cs_wsA[gi], jobs=jobs)
             if not fuse_q:

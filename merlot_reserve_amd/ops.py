@@ -341,6 +341,26 @@ def attention_fwd_dense_mask(qkv, mask, out, nseq, S, nh):
 
 
 @_timed('attention')
+def attention_bwd_dense_mask(qkv, mask, dout, dqkv, rot_tab, nseq, S, nh, ws=None):
+    """Backward of attention_fwd_dense_mask (any boolean mask [nseq, S, S]; mreserve/modeling.py:343-358): dqkv [nseq*S, 3H], every element written;
+    the "rotary" scales applied to dq / dk when rot_tab is given.  ws: fp32 workspace of mr_attention_bwd_dense_mask_workspace bytes (allocated if None)."""
+    assert qkv.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous() and qkv.shape == (nseq * S, 3 * nh * 64) and qkv.dtype in (BF16, F32)
+    assert dout.shape == (nseq * S, nh * 64) and dqkv.shape == qkv.shape and dout.dtype == qkv.dtype == dqkv.dtype
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == nseq * S * S and mask.device == qkv.device
+    lib = _lib.load()
+    need = lib.mr_attention_bwd_dense_mask_workspace(nseq, S, nh) // 4
+    if ws is None:
+        ws = torch.empty(need, dtype=F32, device=qkv.device)
+    assert ws.dtype == F32 and ws.numel() >= need
+    if rot_tab is not None:
+        assert rot_tab.dtype == F32 and rot_tab.is_contiguous() and rot_tab.shape[-1] == 32
+    check(lib.mr_attention_bwd_dense_mask(qkv.data_ptr(), MR_DT_F32 if qkv.dtype == F32 else MR_DT_BF16, mask.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
+                                          _ptr(rot_tab), 0 if rot_tab is None else rot_tab.numel() // 32, ws.data_ptr(), nseq, S, nh, _stream()),
+          'mr_attention_bwd_dense_mask')
+    return dqkv
+
+
+@_timed('attention')
 def attention_bwd(qkv, code, out, dout, lse, delta, dqkv, rot_tab, nseq, S, nh, colsum_ws=None, bias_grad=None, jobs=None):
     """With colsum_ws / bias_grad / jobs: the qkv bias gradient (column sums of dqkv) comes out of the backward kernels as
     per-block partial rows in colsum_ws, reduced later with the layer's other deferred jobs (no pass over dqkv)."""

@@ -287,6 +287,65 @@ def test_attention_fwd_bwd(dev, case, onepass, attn_path):
     assert_close(dq2, dqkv.float() * scale, 5e-3, 'attn bwd rot')
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_attention_bwd_dense_mask(dev, dtype):
+    """mr_attention_bwd_dense_mask (round 6: the backward of TransformerEncoder under ANY mask, mreserve/modeling.py:343-358) against autograd of the
+    reference's formula -- additive -1e10 where the mask is 0, so a query row with no allowed key is uniform over all keys and ITS gradient flows --
+    on a causal mask and on a random mask with an entirely masked row; with and without the "rotary" scales on the way out; and equal to the
+    code-based kernels on a mask of the block form."""
+    from merlot_reserve_amd import ops
+    nseq, S, nh = 3, 77, 2
+    H = nh * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(nseq * S, 3 * H, generator=g).to(dtype).to(dev)
+    dout = torch.randn(nseq * S, H, generator=g).to(dtype).to(dev)
+    causal = torch.tril(torch.ones(S, S, dtype=torch.bool))[None].repeat(nseq, 1, 1)
+    rndm = torch.rand(nseq, S, S, generator=g) < 0.6
+    rndm[:, torch.arange(S), torch.arange(S)] = True
+    rndm[1, 5, :] = False                                   # a row with no allowed key
+    tol_o, tol_g = (2e-5, 2e-4) if dtype == torch.float32 else (4e-3, 1.5e-2)
+    for mask in (causal, rndm):
+        m8 = mask.to(torch.uint8).contiguous().to(dev)
+        out = torch.zeros(nseq * S, H, dtype=dtype, device=dev)
+        ops.attention_fwd_dense_mask(qkv, m8, out, nseq, S, nh)
+        qr = qkv.float().clone().requires_grad_(True)
+        q, k, v = qr.reshape(nseq, S, 3, nh, 64).unbind(2)
+        sc = torch.einsum('nqhd,nkhd->nhqk', q / 8.0, k) + torch.where(mask.to(dev), 0.0, -1e10)[:, None]
+        o = torch.einsum('nhqk,nkhd->nqhd', torch.softmax(sc, -1), v).reshape(nseq * S, H)
+        assert_close(out, o, tol_o, 'dense-mask attn out')
+        o.backward(dout.float())
+        dqkv = torch.full_like(qkv, float('nan'))
+        ops.attention_bwd_dense_mask(qkv, m8, dout, dqkv, None, nseq, S, nh)
+        assert torch.isfinite(dqkv.float()).all()
+        for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
+            assert_close(dqkv[:, sl], qr.grad[:, sl], tol_g, f'dense-mask attn {name}')
+        assert float(qr.grad[1 * S + 5, :H].abs().max()) > 0, 'the empty row carries gradient in the reference'
+        tab = torch.rand(S, 32, device=dev) * 2 - 1
+        dq2 = torch.zeros_like(qkv)
+        ops.attention_bwd_dense_mask(qkv, m8, dout, dq2, tab, nseq, S, nh)
+        scale = torch.ones(nseq * S, 3 * H, device=dev)
+        rows = torch.arange(nseq * S, device=dev) % S
+        for h in range(2 * nh):
+            scale[:, h * 64:h * 64 + 32] = tab[rows]
+        assert_close(dq2, qr.grad * scale, tol_g, 'dense-mask attn bwd rot')
+    if dtype != torch.bfloat16:
+        return
+    # a mask of the block form: the code-based kernels on the same problem
+    c = torch.randint(0, 2, (nseq, S), generator=g)
+    c[torch.rand(nseq, S, generator=g) < 0.2] = -1
+    c[:, 0] = 0
+    blockm = ((c[:, :, None] == c[:, None, :]) & (c[:, :, None] >= 0))
+    valid = (c >= 0).reshape(-1, 1).to(dev)
+    dout_v = dout * valid.to(dtype)
+    code = c.to(torch.int32).reshape(-1).to(dev)
+    out1, lse, delta = torch.zeros(nseq * S, H, dtype=dtype, device=dev), torch.zeros(nseq, nh, S, device=dev), torch.zeros(nseq, nh, S, device=dev)
+    ops.attention_fwd(qkv, code, out1, lse, nseq, S, nh)
+    d1, d2 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    ops.attention_bwd(qkv, code, out1, dout_v, lse, delta, d1, None, nseq, S, nh)
+    ops.attention_bwd_dense_mask(qkv, blockm.to(torch.uint8).contiguous().to(dev), dout_v, d2, None, nseq, S, nh)
+    assert relerr(d2, d1) < 1e-2, relerr(d2, d1)
+
+
 def _run_codes(S, runs):
     c = []
     for code, n in runs:
