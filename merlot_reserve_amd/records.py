@@ -1102,8 +1102,9 @@ def _slot_views(buf, shapes):
     return out, off
 
 
-class _FeederStop(Exception):
-    pass
+class _FeederStop(BaseException):
+    """The consumer closed the feeder: raised inside make_dataset's slot request to unwind the generators.  Control flow, not an error -- a
+    BaseException so that the per-cycle `except Exception` of input_fn_builder (the reference's log-and-continue) does not swallow it."""
 
 
 def _feeder_main(config, rank, world, seed, epochs, kw, shm_names, shapes, full, free, stop):

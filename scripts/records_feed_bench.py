@@ -24,7 +24,7 @@ def main():
     B = 4
     rng = np.random.default_rng(0)
     for s in range(4):
-        R.write_tfrecord(os.path.join(tmp, f'train{s:05d}of00004.tfrecord'), [R.make_synthetic_record(cfg, rng, frame_hw=(360, 640)) for _ in range(n // 4)])
+        R.write_tfrecord(os.path.join(tmp, f'train{s:05d}of00004.tfrecord'), [R.make_synthetic_record(cfg, rng, frame_hw=(288, 512)) for _ in range(n // 4)])     # 288 x 512: the corpus' stored size (data/process.py:418-423 of the reference)
     cfg['data'] = dict(cfg['data'], train_fns=os.path.join(tmp, 'train{:05d}of00004.tfrecord'), num_train_files=4)
     cfg['device'] = dict(cfg.get('device', {}), batch_size=B, shuffle_buffer_size=16, n_fns_per_cycle=4)
     dev = torch.device('cuda:0')
@@ -42,7 +42,7 @@ def main():
         tr.train_step_graph(res[i % 2], plans[i % 2])
     torch.cuda.synchronize()
     print(f'resident batches: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms / step', flush=True)
-    for fast in (False, True):
+    for fast in (False, True):                 # (False: the float resampler of rounds 1-5; True: the 8-bit path, the default for bf16 batches since round 6)
         cfg['data']['fast_image_resize'] = fast
         feeder = R.ShardFeeder(cfg, rank=0, world=1, seed=3, workers=workers, slots=4)       # the reader in its own process: no GIL shared with the step's host work
         feed = PrefetchLoader(feeder, dev, depth=2)

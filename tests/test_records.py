@@ -402,3 +402,27 @@ def test_one_bad_record_costs_one_record(tmp_path, capsys):
         assert len(got) == 5, len(got)
     out = capsys.readouterr().out
     assert out.count('skipping a record') == 4
+
+
+def test_closing_an_endless_feeder_stops_it(tmp_path):
+    """An endless stream (epochs=None) whose consumer stops early: close() must unwind the feeder process -- its stop signal travels as a BaseException,
+    so that input_fn_builder's per-cycle `except Exception` (the reference's log-and-continue) cannot swallow it and spin (round 6: it did, for one commit)."""
+    import time
+    cfg = tiny_config()
+    rng = np.random.default_rng(22)
+    for s in range(2):
+        R.write_tfrecord(tmp_path / f'train{s:05d}of00002.tfrecord', [R.make_synthetic_record(cfg, rng) for _ in range(4)])
+    cfg['data'] = dict(cfg['data'], train_fns=str(tmp_path / 'train{:05d}of00002.tfrecord'), num_train_files=2)
+    cfg['device'] = dict(cfg.get('device', {}), batch_size=2, shuffle_buffer_size=2, n_fns_per_cycle=2)
+    feeder = R.ShardFeeder(cfg, rank=0, world=1, seed=5, epochs=None, workers=2, slots=2)
+    names = [m.name for m in feeder.shms]
+    it = iter(feeder)
+    for _ in range(6):                      # more than one epoch of four batches
+        next(it)
+    t0 = time.time()
+    feeder.close()
+    assert time.time() - t0 < 14 and not feeder.proc.is_alive() and feeder.proc.exitcode == 0
+    from multiprocessing import shared_memory
+    for n in names:
+        with pytest.raises(FileNotFoundError):
+            shared_memory.SharedMemory(name=n)
