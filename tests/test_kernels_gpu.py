@@ -127,9 +127,23 @@ def test_gemm_epilogues(dev):
     assert_close(got[:, 1:].reshape(M2, N), ref2, 3e-3, 'row map')
 
 
-@pytest.mark.parametrize('rows,H', [(5, 128), (1000, 768), (333, 1024), (64, 2048)])
-def test_layernorm(dev, rows, H):
+@pytest.fixture
+def ln_impl():
     from merlot_reserve_amd import ops
+
+    def use(v):
+        ops.set_option('ln_impl', v)
+    yield use
+    ops.set_option('ln_impl', 1)
+
+
+@pytest.mark.parametrize('impl', [1, 0], ids=['round6', 'round5'])
+@pytest.mark.parametrize('rows,H', [(5, 128), (1000, 768), (333, 1024), (64, 2048), (9000, 768)])
+def test_layernorm(dev, rows, H, impl, ln_impl):
+    """(impl: option ln_impl -- the round-6 backward kernel, whole grid resident, and round 5's, which H > 1024 still takes; 9000 rows: more rows than
+    resident waves, so the kernels' row loops and prefetch run.)"""
+    from merlot_reserve_amd import ops
+    ln_impl(impl)
     x = rnd((rows, H), dev, scale=2.0, seed=1) + 0.5
     gamma, beta = rnd((H,), dev, seed=2) + 1, rnd((H,), dev, seed=3)
     y = torch.zeros_like(x)
