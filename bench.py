@@ -540,6 +540,7 @@ def main():
                 roof['step_hbm'] = {'bytes_per_step_all_kernels': step_bytes_all, 'achieved': step_bytes_all / step_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                                     'frac': step_bytes_all / step_s / 8e12, 'source': f'profiles/{traffic_src}'}
             roof['step_floors_ms'] = {k: round(v, 2) for k, v in floors.items()}
+            roof['kernel_bound'] = 'mfma'          # the dominant kernel family (the GEMMs) by itself: what achieved / peak / frac / traffic describe
             roof['bound'] = 'hbm' if floors.get('hbm_at_8TBs', 0.0) > floors['mfma'] else 'mfma'
             roof['bound_note'] = ('the step as a whole: the larger of step_floors_ms (its kernels move more HBM time than its FLOPs take matrix-core time); '
                                   'achieved / peak / frac are the GEMM family against the matrix cores, step_hbm is the step against HBM')

@@ -30,7 +30,7 @@ def test_bench_line_contract(dev):
     # `bound` names the larger floor, achieved / peak / frac stay the GEMM family's, step_hbm prices the step against HBM
     fl = r['step_floors_ms']
     assert set(fl) >= {'mfma', 'hbm_at_8TBs', 'hbm_at_6.3TBs'} and 5.0 < fl['mfma'] < 12.0 and fl['hbm_at_8TBs'] < fl['hbm_at_6.3TBs'] < d['ms_per_step']
-    assert r['bound'] == ('hbm' if fl['hbm_at_8TBs'] > fl['mfma'] else 'mfma')
+    assert r['bound'] == ('hbm' if fl['hbm_at_8TBs'] > fl['mfma'] else 'mfma') and r['kernel_bound'] == 'mfma'
     assert r['step_hbm']['unit'] == 'GB/s' and r['step_hbm']['peak'] == 8000.0 and 0.1 < r['step_hbm']['frac'] < 1.0
     assert 0.05 < r['frac'] < 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert r['traffic'] is None or r['traffic'] > 0
