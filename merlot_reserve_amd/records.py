@@ -943,9 +943,11 @@ def make_dataset(config, fns, batch_size, is_training=True, seed=None, token_is_
     a shuffle buffer of config['device']['shuffle_buffer_size'] records when training, parsed, grouped into batches of batch_size with the remainder
     dropped.  `workers` > 0 parses in a pool: threads by default (PIL releases the GIL while it decodes and resamples; ~2x on 8 threads), or
     -- processes=True -- spawned worker PROCESSES that import neither torch nor the library and never touch the GPU; the pool parses chunk k + 1 while
-    this process assembles the batches of chunk k.  Measured on the GPU box's host (EPYC 9575F, a job's share of ~16 cores; scripts/records_demo.py,
-    360 x 640 stored frames, base grid; profiles/r05_reader_throughput.txt): 21.5 records / s on one core, 45 with 8 threads, 119 with 8 processes,
-    136 with 16 (139 with data.fast_image_resize: 8-bit resampling) -- a base step consumes 4 records / 29 ms = 137 records / s per GPU.
+    this process assembles the batches of chunk k and, since round 6, the workers hand their float arrays back through shared-memory record slots
+    (_RecordSlots) instead of the pool's pipe.  Measured on the GPU box's host (EPYC 9575F, a job's share of ~16 cores; scripts/records_demo.py, frames
+    stored at the corpus' 288 x 512, base grid; profiles/r06_reader_throughput.txt): 35.5 records / s on one core (8-bit image path; 29.3 with the float
+    resampler), 256 with 8 processes, 354 with 16 (434 sustained) -- a base step consumes 4 records / 29 ms = 138 records / s per GPU.  (Round 5, 360 x
+    640 frames, results through the pipe: 21.5 / 119 / 136.)
     The record -> random-stream assignment does not depend on the pool, so every mode yields the same batches for the same seed."""
     merged = merged_data_config(config)
     rng = np.random.default_rng(seed)
@@ -1153,7 +1155,8 @@ class ShardFeeder:
     trainer's GIL with the step's host work (planner ~6 ms, graph launch ~4 ms) inside a 29 ms step.  Here the trainer's process only wraps a slot's float
     arrays as tensors (zero copy) and hands them to loader.PrefetchLoader, whose staging copy reads them once.  Measured end to end on the GPU box
     (scripts/records_feed_bench.py, profiles/r05_shard_fed_step.txt: shards on local disk -> 14 parser processes -> this feeder -> PrefetchLoader ->
-    hipGraph replay, 150 steps over several shard cycles): 31.4 ms per step (30.5 with data.fast_image_resize) against 29.1 with resident batches.
+    hipGraph replay, 150 steps over several shard cycles; round 6, profiles/r06_shard_fed_step.txt): 29.84-29.92 ms per step against 29.55 with resident batches
+    (round 5: 31.4 against 29.1).
 
     A batch's float tensors are views of a slot that is reused `slots - 1` batches later: a consumer must have copied them by its next `next()` --
     PrefetchLoader does (it stages into pinned memory inside the call that fetched the batch).  Iterate it; `close()` (or leaving a `with`) stops the
