@@ -882,7 +882,6 @@ class _RecordSlots:
 
     def __init__(self, config, count):
         self.shm, self.free, self.count = None, [], 0
-        c = merged_data_config(config)
         shp = _float_shapes(config, 1)
         self.rec_shapes = {k: (tuple(sh[1:]), dt) for k, (sh, dt) in shp.items()}
         self.rec_bytes = sum((int(np.prod(sh)) * np.dtype(dt).itemsize + 4095) // 4096 * 4096 for sh, dt in self.rec_shapes.values())
