@@ -250,6 +250,7 @@ def gemm_colsum_job(a, b, out, colsum_ws, bias_grad, jobs, **kw):
     return False
 
 
+@_timed('layernorm+reductions')
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
     rows, H = x.shape
     if x.dtype == F32:
