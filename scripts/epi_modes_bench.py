@@ -9,6 +9,9 @@ dev = torch.device('cuda:0')
 BF16 = torch.bfloat16
 WS = torch.zeros(8 * 1024 * 1024, device=dev)
 ops.set_option('gemm_trace', 1)
+for a in [a for a in sys.argv[1:] if '=' in a]:          # NAME=VALUE: a library option for the whole run (e.g. gemm5=3: the 128 x 128-tile kernel for every NT problem)
+    ops.set_option(a.split('=')[0], int(a.split('=')[1]))
+sys.argv = [a for a in sys.argv if '=' not in a]
 lib = _lib.load()
 for spec in sys.argv[1:] or ['2308,4096,1024', '15424,3072,768', '5952,3072,768', '9216,4096,1024']:
     M, N, K = [int(v) for v in spec.split(',')]
