@@ -1368,6 +1368,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(const __bf16* __restr
     };
 
     const int nt = (int)((S + TK - 1) / TK);
+#ifdef MR_ATTN_BWD1_PRIO
+    // experiment (MI355X_MICROARCH.md, "two waves per SIMD", item 4): the second-dispatched half of the workgroup is the arbitration loser of every
+    // segment; one static s_setprio 1 for it, no per-segment flips.  Same instructions, same results.  Measured (round 6, scripts/build_diag.sh prio attention
+    // -fno-slp-vectorize -DMR_ATTN_BWD1_PRIO, scripts/attn_bench.py, alternating on one box): base ViT 77.4-77.5 us against 76.3-77.1, large ViT 100.5-101.1 against
+    // 99.0-99.5, S = 130 58.8 against 56.8-57.3 -- 0.5-3 % SLOWER here (this kernel's halves are not in the compute / load alternation the guide measured): off.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
         MR_ASTAMP(0);
