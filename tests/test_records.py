@@ -426,3 +426,29 @@ def test_closing_an_endless_feeder_stops_it(tmp_path):
     for n in names:
         with pytest.raises(FileNotFoundError):
             shared_memory.SharedMemory(name=n)
+
+
+def test_record_slots_fall_back_to_the_pipe_without_shared_memory_room(tmp_path, monkeypatch):
+    """Parsed records travel through shared-memory record slots when the pool is made of processes (round 6); with no room under /dev/shm (or fewer slots
+    than jobs) they travel through the pool's pipe as before -- same batches either way."""
+    import os
+    cfg = tiny_config()
+    cfg['device'] = dict(cfg.get('device', {}), shuffle_buffer_size=2, batch_size=2, n_fns_per_cycle=1)
+    rng = np.random.default_rng(31)
+    fn = tmp_path / 'train00000of00001.tfrecord'
+    R.write_tfrecord(fn, [R.make_synthetic_record(cfg, rng) for _ in range(6)])
+    with_slots = list(R.make_dataset(cfg, [str(fn)], 2, is_training=True, seed=7, workers=2, processes=True))
+    slots = R._RecordSlots(cfg, 5)
+    assert slots.count == 5 and slots.take()[3] == 4 and len(slots.free) == 4
+    slots.close()
+
+    class NoRoom:
+        f_bavail, f_frsize = 0, 4096
+    monkeypatch.setattr(os, 'statvfs', lambda p: NoRoom())
+    none = R._RecordSlots(cfg, 5)
+    assert none.count == 0 and none.take() is None
+    none.close()
+    through_pipe = list(R.make_dataset(cfg, [str(fn)], 2, is_training=True, seed=7, workers=2, processes=True))
+    assert len(with_slots) == len(through_pipe) == 3
+    for a, b in zip(with_slots, through_pipe):
+        assert np.array_equal(a['text2audio'], b['text2audio']) and bool((a['images'] == b['images']).all()) and bool((a['audio_clips'] == b['audio_clips']).all())
