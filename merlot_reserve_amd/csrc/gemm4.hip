@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void gemm4_kernel(const G256Args ga) {
             const int wrow0 = cm0 + wr * 128, wcol0 = cn0 + wc * WCOLS;
             constexpr int MR_EPI_MI = 8;
 #define MR_EPI_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MR_EPI_FULL_LINES 0      // (full-line stores: the trade of halves costs this kernel spilled registers at its allocation limit; gemm3.hip only)
 #include "gemm3_epilogue.inc"
+#undef MR_EPI_FULL_LINES
 #undef MR_EPI_ROW_FENCE
 #ifndef MR_G3_NOSTORE
             have_stores = true;

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(NW * 64, (Geo5<NW, TM, NS>::OCC)) void gemm5_kernel
             const int wrow0 = cm0 + wr * (TM / 2), wcol0 = cn0 + wc * WCOLS;
             constexpr int MR_EPI_MI = MI;
 #define MR_EPI_ROW_FENCE() do {} while (0)
+#define MR_EPI_FULL_LINES 0      // (full-line stores: the trade of halves costs this kernel spilled registers at its allocation limit; gemm3.hip only)
 #include "gemm3_epilogue.inc"
+#undef MR_EPI_FULL_LINES
 #undef MR_EPI_ROW_FENCE
 #ifndef MR_G3_NOSTORE
             have_stores = true;
