@@ -115,6 +115,28 @@ def cpu_baseline(config, threads=None):
                       f'{m["joint_num_layers"]}/{m["span_num_layers"]} layers): {dt:.1f} s at {best} threads, x{scale:.2f} algorithmic-FLOP ratio to full depth'}
 
 
+def calibrate_hbm(dev, launches=24):
+    """The box's MEMORY speed on one fixed streaming kernel (round 6): the calibration GEMM prices a box's matrix cores only, and a third of the
+    step is memory time -- boxes with equal calibration_tflops differed by 2 % in ms_per_step.  mr_add_bf16 over three 384-MB bf16 buffers
+    (1.15 GB per launch: past the 256-MB Infinity Cache), `launches` back to back, HIP events -> TB/s of bytes read + written."""
+    import torch
+    from merlot_reserve_amd import ops
+    n = 192 * 1024 * 1024
+    a = torch.full((n,), 0.5, dtype=torch.bfloat16, device=dev)
+    b = torch.full((n,), 0.25, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.add_(a, b, y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(launches):
+        ops.add_(a, b, y)
+    e1.record()
+    torch.cuda.synchronize()
+    return 3.0 * n * 2 * launches / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def calibrate(dev, launches=72):
     """The box's speed on ONE fixed kernel, so that ms_per_step of different rounds / boxes can be compared: `launches` back-to-back launches
     (~50 ms) of the shipped plain NT mr_gemm at 8192^3 on gaussian bf16 data, HIP events on the launching stream -> TFLOP/s.  Boxes of
@@ -357,6 +379,7 @@ def main():
         restore()
         del snap, ref_master
     calib = [calibrate(dev)] if rank == 0 and not args.no_calibration else []
+    calib_hbm = [calibrate_hbm(dev)] if rank == 0 and not args.no_calibration else []
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -365,6 +388,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0 and not args.no_calibration:
         calib.append(calibrate(dev))
+        calib_hbm.append(calibrate_hbm(dev))
         if abs(calib[0] - calib[1]) > 0.03 * max(calib):
             degraded.append(f'calibration GEMM before / after the timed region disagree by more than 3 % ({calib[0]:.0f} vs {calib[1]:.0f} TFLOP/s): the box did not hold one speed')
     if dist is not None:
@@ -557,6 +581,7 @@ def main():
                        'hipgraph': bool(use_graph), 'ms_per_step_inputs_from_host': h2d_ms,
                        'step_tflop_algorithmic': step_flops / 1e12,
                        'calibration_tflops': [round(c_, 1) for c_ in calib],
+                       'calibration_hbm_tbs': [round(c_, 3) for c_ in calib_hbm],       # (round 6) mr_add_bf16 over 1.15 GB per launch before / after the timed region: the box's memory speed
                        'calibration_note': 'shipped plain NT mr_gemm at 8192^3 (gaussian bf16), ~50 ms of back-to-back launches before / after the timed region; '
                                            'compare rounds and boxes by ms_per_step x mean(calibration_tflops)',
                        'graph_equals_eager': graph_equals_eager,

@@ -38,6 +38,8 @@ def test_bench_line_contract(dev):
     assert 20e9 < r['algorithmic_bytes_per_step'] < 80e9 and (r['traffic_ratio'] is None or 0.8 < r['traffic_ratio'] < 3.0)
     cal = d['config']['calibration_tflops']
     assert len(cal) == 2 and all(500.0 < c_ < 2500.0 for c_ in cal)
+    hbm = d['config']['calibration_hbm_tbs']                # round 6: the box's memory speed beside its matrix-core speed
+    assert len(hbm) == 2 and all(1.5 < c_ < 8.0 for c_ in hbm)
     assert d['config']['graph_equals_eager'] is True
     b = d['breakdown']
     assert set(b['ms_per_step']) >= {'gemm', 'attention', 'layernorm+reductions', 'optimizer'} and b['sum_ms'] > 0
