@@ -424,6 +424,20 @@ def _sharded_worker(rank, world, port, ret):
     p0, p1 = models[0].params_store, models[1].params_store
     out['vcr'] = torch.equal(p0.master, p1.master) and torch.equal(p0.work, p1.work) and torch.equal(vmu, p0.mu.cpu()) and torch.equal(vnu, p0.nu.cpu()) \
         and bool((p0.mu != 0).any())
+    # round 6 (the advisor's finding): the finetuning state has a checkpoint form too; with partitioned moments state_dict() is a COLLECTIVE, so EVERY rank
+    # calls checkpoint.save_checkpoint(state, dir, rank=rank) and rank 0 alone writes -- the sharded state's file equals the replicated one's
+    import tempfile
+    from merlot_reserve_amd import checkpoint as C
+    sdv = [st.state_dict() for st in states]
+    out['vcr_state_dict'] = torch.equal(flat(sdv[0]['opt_state']['0']['mu']), flat(sdv[1]['opt_state']['0']['mu'])) and \
+        torch.equal(flat(sdv[0]['opt_state']['0']['nu']), flat(sdv[1]['opt_state']['0']['nu'])) and \
+        torch.equal(flat(sdv[0]['opt_state']['1']['orig_params']), flat(sdv[1]['opt_state']['1']['orig_params']))
+    tmp = tempfile.mkdtemp(prefix=f'mr_ckpt_r{rank}_')
+    fn = C.save_checkpoint(states[1], tmp, rank=rank)                 # both ranks enter the gather; only rank 0's directory gets a file
+    out['ckpt_written_by_rank0_only'] = os.path.exists(fn) == (rank == 0)
+    if rank == 0:
+        back = C.load_checkpoint(fn)
+        out['ckpt_moments'] = torch.equal(flat(back['opt_state']['0']['mu']), flat(sdv[0]['opt_state']['0']['mu'])) and int(back['step']) == 2
     ret[rank] = out
     dist.destroy_process_group()
 
