@@ -130,6 +130,35 @@ def test_nt_epilogues(dev, forced):
     assert_close(got[:, 1:].reshape(M2, N), a2.float() @ w.float().T + bias.float(), 3e-3, 'row map')
 
 
+@pytest.mark.parametrize('M,N,K', [(9000, 3072, 256), (15424, 3072, 768), (7000, 2048, 192)])
+def test_aux_epilogue_over_several_tiles_per_workgroup(dev, M, N, K):
+    """The aux + column-sum epilogue (fc2's dgrad) at shapes with several tiles per persistent workgroup (432 / 732 tiles), where a tile's stores are in
+    flight under the next tile's first k-tiles and (round 6) leave as whole 128-byte lines: against the fp32 reference, and BIT FOR BIT between the 256-wide
+    (full-line stores) and the 192-wide (half-line stores) instance of the same problem -- same k order per element."""
+    from merlot_reserve_amd import _lib, ops
+    lib = _lib.load()
+    a, w = rnd((M, K), dev, seed=21), rnd((N, K), dev, scale=0.1, seed=22)
+    aux = rnd((M, N), dev, seed=23)
+    ref = (a.float() @ w.float().T).to(BF16).float() * aux.float()
+    outs = []
+    try:
+        for width in (256, 192):
+            lib.mr_set_option(b'gemm3', width)
+            lib.mr_set_option(b'gemm_trace', 1)
+            cs = torch.full((lib.mr_gemm_colsum_rows(M), N), float('nan'), device=dev)
+            out = torch.full((M + 2, N), float('nan'), dtype=BF16, device=dev)
+            ops.gemm(a, w, out[:M], transB=True, aux=aux, colsum=cs)
+            assert f'gemm3_kernel<{width},4' in lib.mr_last_gemm_kernel().decode()
+            assert_close(out[:M], ref, 4e-3, f'aux multiply, {width}-wide')
+            assert torch.isnan(out[M:].float()).all(), 'rows past M were written'
+            assert_close(cs.sum(0), out[:M].float().sum(0), 2e-3, 'column sums of the stored output')
+            outs.append(out[:M].clone())
+    finally:
+        lib.mr_set_option(b'gemm3', 1)
+        lib.mr_set_option(b'gemm_trace', 0)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_schedules_agree_bit_for_bit(dev):
     """The ping-pong schedules and the one-wave-per-SIMD kernel add a tile's k-blocks in the same order with the same MFMA: identical outputs."""
     from merlot_reserve_amd import _lib, ops
